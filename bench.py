@@ -1,0 +1,284 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X-native linux-fg hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload pipeline|scale]
+
+Metric (BASELINE.json): interpolated frames/s at 1080p -> 4K RGBA8, with the achieved rate of the
+dominant kernel against its roofline.  A "step" is one pass of the hot path over one synthetic
+frame pair per GPU, inputs already resident in HBM:
+
+  pipeline (default; BASELINE config 3, north_star order)
+      scale(curr 1080p -> 4K)  ->  motion(prev4K, curr4K; blockSize 8, searchRadius 16)
+      ->  interpolate(prev4K, curr4K, mv, t = 0.5)          = one interpolated 4K frame
+  scale (BASELINE config 2): the Lanczos kernel alone, 1080p -> 4K, one upscaled frame per step.
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), launched by torch.distributed.run.
+Frame pairs are independent, so the work shards one pair per GPU with no data-path collective except
+the one the path really has: the shared previous 4K frame is broadcast from rank 0 each step
+(double-buffered, issued one step ahead so it overlaps the kernels).  Weak scaling.
+
+The CPU baseline is the oracle (oracle/lfg_oracle.c, a restatement of the reference shaders -- NOT
+lavapipe, which this image lacks) timed on a bounded sample on the host cores, rank 0, N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md:36 (spec; 6290 measured copy)
+FP32_VALU_PEAK_TFLOPS = 157.3  # ibid. :41 (counts an FMA as 2; an add-only stream tops out at 78.65)
+
+SIZES = {"540p": (960, 540), "1080p": (1920, 1080), "4k": (3840, 2160), "8k": (7680, 4320)}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=["pipeline", "scale"], default="pipeline")
+    ap.add_argument("--input", choices=list(SIZES), default="1080p", help="input size; output is 2x")
+    ap.add_argument("--factors", default="0.5", help="comma-separated interpolation factors per pair")
+    ap.add_argument("--content", choices=["translated", "uncorrelated"], default="translated")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(stage: str, w_in: int, h_in: int, w: int, h: int) -> int:
+    """every stage reads each input once and writes each output once;
+    frames 4 B/px, motion vectors 2 B/px."""
+    if stage == "scale":
+        return 4 * (w_in * h_in + w * h)
+    if stage == "motion":
+        return 8 * w * h + 2 * w * h
+    if stage == "interpolate":
+        return 8 * w * h + 2 * w * h + 4 * w * h
+    raise ValueError(stage)
+
+
+def motion_flops(w: int, h: int, block: int = 8, radius: int = 16) -> float:
+    """Algorithmic flops of motion.comp with per-position distance reuse: per candidate, one distance
+    per pixel (4 sub, 4 mul, 3 add, 1 sqrt = 12 flops) and block*block adds per pixel."""
+    cand = (2 * radius + 1) ** 2
+    return float(w) * h * cand * (block * block + 12)
+
+
+def cpu_baseline(w_in, h_in, w, h, factors, workload):
+    """Oracle timed on a bounded sample (~10-20 s) of the same workload on the host cores."""
+    import oracle
+    from linux_fg_amd import synth
+    threads = oracle.default_threads()
+    prev_in, curr_in = synth.make_pair(w_in, h_in, stream=0)
+    # scale: a band of output rows, full width
+    band = max(8, min(h, 64 * threads // 8))
+    t0 = time.perf_counter()
+    oracle.scale(curr_in, w, h, roi=(0, 0, w, band), threads=threads)
+    t_scale = (time.perf_counter() - t0) * (h / band)
+    if workload == "scale":
+        return {"value": 1.0 / t_scale, "unit": "upscaled frames/s", "cores": threads, "kind": "port",
+                "sample": f"oracle scale.comp restatement on {band} of {h} output rows at {w_in}x{h_in}->{w}x{h}, "
+                          f"extrapolated by rows; {threads} threads"}
+    # motion + interpolate at output resolution on synthetic frames of that size
+    prev, curr = synth.make_pair(w, h, stream=0)
+    mw, mh = 128, max(4, threads)                                    # crop away from the borders
+    x0, y0 = w // 2, h // 2
+    t0 = time.perf_counter()
+    mv_roi = oracle.motion(prev, curr, roi=(x0, y0, x0 + mw, y0 + mh), threads=threads)
+    t_motion = (time.perf_counter() - t0) * (w * h / (mw * mh))
+    iband = max(8, min(h, 128 * threads // 8))
+    t0 = time.perf_counter()
+    oracle.interpolate(prev, curr, mv_roi, 0.5, roi=(0, 0, w, iband), threads=threads)
+    t_interp = (time.perf_counter() - t0) * (h / iband)
+    t_pair = t_scale + t_motion + len(factors) * t_interp
+    return {"value": len(factors) / t_pair, "unit": "interpolated frames/s", "cores": threads, "kind": "port",
+            "sample": (f"oracle (CPU restatement of the reference shaders, not lavapipe): scale on {band}/{h} rows, "
+                       f"motion on a {mw}x{mh}-pixel crop of the {w}x{h} frame, interpolate on {iband}/{h} rows, "
+                       f"each extrapolated by area; {threads} threads; per-frame seconds scale/motion/interpolate = "
+                       f"{t_scale:.3f}/{t_motion:.1f}/{t_interp:.3f}")}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from linux_fg_amd import capi, synth
+
+    w_in, h_in = SIZES[args.input]
+    w, h = 2 * w_in, 2 * h_in
+    factors = [float(x) for x in args.factors.split(",") if x]
+    steps = args.steps if args.steps is not None else (200 if args.workload == "scale" else 20)
+    warmup = args.warmup if args.warmup is not None else (20 if args.workload == "scale" else 3)
+
+    ctx = capi.Context(local_rank)
+    stream = torch.cuda.current_stream(dev)
+    ctx.set_stream(stream.cuda_stream)
+
+    def dev_frame(host: np.ndarray):
+        t = torch.from_numpy(np.ascontiguousarray(host)).to(dev)
+        return t, capi.Context.wrap(t.data_ptr(), host.shape[1], host.shape[0], capi.FORMAT_RGBA8)
+
+    def empty_frame(width, height, fmt=capi.FORMAT_RGBA8):
+        ch = 4 if fmt == capi.FORMAT_RGBA8 else 2
+        t = torch.empty((height, width, ch), dtype=torch.uint8, device=dev)
+        return t, capi.Context.wrap(t.data_ptr(), width, height, fmt)
+
+    # Synthetic inputs, uploaded once before timing.  The previous frame is shared by all ranks
+    # (seed of stream 0); each rank's current frame is that frame translated by its own vector.
+    prev_in = synth.make_prev(w_in, h_in, synth.BASE_SEED)
+    if args.content == "translated":
+        curr_in = synth.translate(prev_in, (3 + rank, -2), synth.BASE_SEED + rank)
+    else:
+        curr_in = synth.noise_bytes(w_in, h_in, (synth.BASE_SEED + 7919 * (rank + 1)) & 0xFFFFFFFF)
+    t_prev_in, f_prev_in = dev_frame(prev_in)
+    t_curr_in, f_curr_in = dev_frame(curr_in)
+    t_curr4, f_curr4 = empty_frame(w, h)
+    t_out, f_out = empty_frame(w, h)
+    t_mv, f_mv = empty_frame(w, h, capi.FORMAT_MV_S8X2)
+    prev_slots = [empty_frame(w, h) for _ in range(2 if world > 1 else 1)]
+    for _, f in prev_slots:
+        ctx.scale(f_prev_in, f)                     # rank 0's copy is the broadcast source
+    torch.cuda.synchronize(dev)
+
+    pending = [None, None]
+
+    def issue_broadcast(slot):
+        if world > 1:
+            pending[slot] = dist.broadcast(prev_slots[slot][0], src=0, async_op=True)
+
+    def step(k):
+        slot = k % len(prev_slots)
+        if world > 1:
+            if pending[slot] is not None:
+                pending[slot].wait()                # orders the current stream after the broadcast
+                pending[slot] = None
+            issue_broadcast((k + 1) % 2)            # next step's shared frame, overlapped with this step
+        f_prev4 = prev_slots[slot][1]
+        ctx.scale(f_curr_in, f_curr4)
+        if args.workload == "pipeline":
+            ctx.motion(f_prev4, f_curr4, f_mv, 8, 16.0)
+            for t in factors:
+                ctx.interpolate(f_prev4, f_curr4, f_mv, f_out, t)
+
+    def barrier_sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    if world > 1:
+        issue_broadcast(0)
+    for k in range(warmup):
+        step(k)
+    ctx.profile_reset()
+    ctx.profile_enable(args.workload == "pipeline")   # events around every stage launch (ms-scale kernels)
+    barrier_sync()
+    t0 = time.perf_counter()
+    for k in range(warmup, warmup + steps):
+        step(k)
+    barrier_sync()
+    elapsed = time.perf_counter() - t0
+    for p in pending:
+        if p is not None:
+            p.wait()
+    torch.cuda.synchronize(dev)
+
+    if args.workload == "scale":
+        # kernel duration from a second, event-bracketed pass: per-launch events would dominate the
+        # wall clock of a ~10 us kernel, so they stay out of the pass `value` is computed from.
+        ctx.profile_enable(True)
+        for k in range(steps):
+            step(k)
+        torch.cuda.synchronize(dev)
+    stage_ms = {}
+    for name, sid in (("scale", capi.STAGE_SCALE), ("motion", capi.STAGE_MOTION), ("interpolate", capi.STAGE_INTERPOLATE)):
+        ms, n = ctx.profile_get(sid)
+        if n:
+            stage_ms[name] = ms / n
+    ctx.profile_enable(False)
+
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    units_per_step = len(factors) if args.workload == "pipeline" else 1
+    value = world * steps * units_per_step / elapsed
+
+    if rank == 0:
+        stages = {}
+        for name, avg in stage_ms.items():
+            b = algorithmic_bytes(name, w_in, h_in, w, h)
+            gbs = b / (avg * 1e-3) / 1e9
+            stages[name] = {"avg_ms": round(avg, 5), "algorithmic_bytes": b, "hbm_gbs": round(gbs, 1),
+                            "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
+        dominant = max(stage_ms, key=stage_ms.get)
+        if dominant == "motion":
+            fl = motion_flops(w, h)
+            tf = fl / (stage_ms["motion"] * 1e-3) / 1e12
+            roofline = {"kernel": "motion_tiled_8_16_kernel", "bound": "valu", "achieved": round(tf, 2),
+                        "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_VALU_PEAK_TFLOPS, 4),
+                        "traffic": None,
+                        "note": ("motion.comp is fp32-VALU bound, not HBM bound (SURVEY.md F7): flops = W*H*1089*(64 adds "
+                                 "+ 12 per distance); the 157.3 TFLOP/s peak counts an FMA as 2, an add-only stream "
+                                 "tops out at 78.65; the same kernel against HBM is in stages.motion")}
+        else:
+            s = stages[dominant]
+            roofline = {"kernel": {"scale": "scale_2x_kernel", "interpolate": "interpolate_kernel"}[dominant],
+                        "bound": "hbm", "achieved": s["hbm_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": s["hbm_frac"], "traffic": None}
+        total_bytes = sum(algorithmic_bytes(n, w_in, h_in, w, h) * (len(factors) if n == "interpolate" else 1)
+                          for n in stage_ms)
+        line = {
+            "metric": "interpolated frames/s, 1080p->4K RGBA8" if args.workload == "pipeline" else "upscaled frames/s, 1080p->4K RGBA8 (Lanczos only)",
+            "value": round(value, 3),
+            "unit": "frames/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 arithmetic on u8 RGBA (u8 in, u8 out; int8 motion vectors)",
+            "data": "synthetic",
+            "config": {"workload": (f"{args.input}->{2 * h_in}p " + ("scale+motion(8,16)+interpolate" if args.workload == "pipeline" else "scale only")),
+                       "input": [w_in, h_in], "output": [w, h], "factors": factors if args.workload == "pipeline" else [],
+                       "content": args.content, "parallelism": f"one frame pair per GPU x{world}" + (", RCCL broadcast of the shared previous 4K frame per step" if world > 1 else "")},
+            "roofline": roofline,
+            "stages": stages,
+            "path_hbm": {"algorithmic_bytes_per_step": total_bytes,
+                         "achieved_gbs": round(total_bytes * steps / elapsed / 1e9 * 1.0, 1),
+                         "frac_of_8TBs": round(total_bytes * steps / elapsed / 1e9 / HBM_PEAK_GBS, 5)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(w_in, h_in, w, h, factors, args.workload)
+        print(json.dumps(line), flush=True)
+
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,188 @@
+/*
+ * linuxfg_hip.h -- C-ABI of the MI355X-native linux-fg hot path
+ *                  (upscale -> motion -> interpolate).
+ *
+ * This is the drop-in boundary.  The reference (xXJSONDeruloXx/linux-fg) has no plugin
+ * or FFI layer: its boundary is the C++ class surface VulkanContext / FrameManager /
+ * Scaler.  Everything those classes do on the hot path through
+ * Vulkan is provided here through plain C: opaque context, POD frame descriptor, plain
+ * pointers and sizes, int return codes.  The C++ mirror of the reference classes in
+ * linux-fg_amd/host/ and the ctypes binding in linux-fg_amd/capi.py call nothing else.
+ *
+ * Conventions
+ *   - every fallible call returns 0 on success, a negative lfg_status otherwise, and
+ *     latches a message readable with lfg_last_error() (the reference returns bool and
+ *     latches Logger::GetLastError, src/logger.hpp:33-41); nothing throws across this ABI;
+ *   - a context is bound to ONE GPU and ONE HIP stream and is not thread-safe (the
+ *     reference is single-threaded, one VkQueue: src/vulkan_context.cpp:130-151);
+ *   - compute calls ENQUEUE on the context's stream and return; lfg_sync() waits
+ *     (the reference waits with vkQueueWaitIdle after every submit, src/scaler.cpp:393);
+ *   - frames are row-major, `pitch` bytes per row, RGBA8 = 4 bytes per pixel in memory
+ *     order R,G,B,A (channel order is irrelevant to the kernels: all four are treated alike);
+ *   - there is no CPU fallback: without a usable GPU lfg_context_create() fails.
+ *
+ * All citations are file:line under the reference checkout.
+ */
+#ifndef LINUXFG_HIP_H
+#define LINUXFG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LFG_ABI_VERSION 1
+
+typedef enum lfg_status {
+    LFG_OK = 0,
+    LFG_ERR_INVALID = -1,     /* bad argument (null, size mismatch, unsupported parameter) */
+    LFG_ERR_DEVICE = -2,      /* HIP runtime error; text in lfg_last_error() */
+    LFG_ERR_NOMEM = -3,
+    LFG_ERR_UNSUPPORTED = -4
+} lfg_status;
+
+typedef enum lfg_format {
+    /* VK_FORMAT_R8G8B8A8_UNORM, the only colour format the reference creates
+     * (src/frame_manager.hpp:15). 4 bytes per pixel. */
+    LFG_FORMAT_RGBA8_UNORM = 0,
+    /* Motion vectors, two signed bytes per pixel (x, y), whole pixels in [-127,127].
+     * The reference declares the MV image rgba32f (shaders/motion.comp:7) and stores
+     * vec4(best, 0, 1) (:56); best is always integer-valued for the integer search radii
+     * the host pushes (src/frame_manager.cpp:333), so two int8 hold it losslessly at 1/8
+     * of the bytes.  lfg_mv_export_rgba32f() reproduces the reference's image verbatim. */
+    LFG_FORMAT_MV_S8X2 = 1
+} lfg_format;
+
+/* Replaces `struct Frame` {VkImage, VkDeviceMemory, VkImageView, width, height, format}
+ * (src/frame_manager.hpp:9-16): a device pointer plus geometry.  Caller-owned POD. */
+typedef struct lfg_frame {
+    void    *data;      /* device memory; NULL = empty frame (VK_NULL_HANDLE) */
+    uint32_t width;
+    uint32_t height;
+    uint32_t pitch;     /* bytes per row, >= width * bytes-per-pixel */
+    uint32_t format;    /* lfg_format */
+    uint32_t owned;     /* 1: allocated by lfg_frame_create and freed by lfg_frame_destroy */
+    uint32_t reserved;
+} lfg_frame;
+
+typedef struct lfg_context lfg_context;
+typedef struct lfg_ring lfg_ring;
+
+/* Kernel stages, for lfg_profile_get(). */
+typedef enum lfg_stage {
+    LFG_STAGE_SCALE = 0,
+    LFG_STAGE_MOTION = 1,
+    LFG_STAGE_INTERPOLATE = 2,
+    LFG_STAGE_COUNT = 3
+} lfg_stage;
+
+/* ---------------------------------------------------------------- library / context */
+
+int         lfg_abi_version(void);
+/* Number of HIP devices visible to this process (0 if none); does not create a context. */
+int         lfg_device_count(void);
+
+/* Replaces VulkanContext::Initialize (src/vulkan_context.cpp:3-23: instance, physical
+ * device pick :88-105, logical device + one compute queue :117-151).  device_ordinal < 0
+ * picks device 0 (the reference prefers a discrete GPU, else index 0).  The context owns
+ * one HIP stream (the compute queue) unless lfg_context_set_stream() adopts another. */
+int         lfg_context_create(int device_ordinal, lfg_context **out_ctx);
+/* Replaces VulkanContext::Cleanup / FrameManager::Cleanup / Scaler::Cleanup.  NULL is a no-op. */
+void        lfg_context_destroy(lfg_context *ctx);
+/* Adopt an externally owned hipStream_t (e.g. PyTorch's current stream) as the compute
+ * queue, so the caller's events and collectives order against these kernels.  NULL restores
+ * the context's own stream. */
+int         lfg_context_set_stream(lfg_context *ctx, void *hip_stream);
+void       *lfg_context_get_stream(lfg_context *ctx);
+int         lfg_context_device(const lfg_context *ctx);
+/* vkQueueWaitIdle (src/scaler.cpp:393, src/frame_manager.cpp:194). */
+int         lfg_sync(lfg_context *ctx);
+/* Logger::GetLastError (src/logger.hpp:38).  ctx == NULL reads the creation-time error. */
+const char *lfg_last_error(const lfg_context *ctx);
+
+/* ---------------------------------------------------------------- frames */
+
+/* FrameManager::CreateFrame (src/frame_manager.cpp:30-69): device-local storage for a
+ * width x height image; pitch is tight (width * bpp rounded up to 16 bytes is NOT applied:
+ * rows are tightly packed so a frame is one contiguous upload). */
+int  lfg_frame_create(lfg_context *ctx, uint32_t width, uint32_t height, uint32_t format, lfg_frame *out);
+/* FrameManager::DestroyFrame (src/frame_manager.cpp:71-81): idempotent, NULL-safe. */
+void lfg_frame_destroy(lfg_context *ctx, lfg_frame *frame);
+/* Describe caller-owned device memory (e.g. a torch tensor) as a frame; never freed here. */
+int  lfg_frame_wrap(void *device_ptr, uint32_t width, uint32_t height, uint32_t pitch, uint32_t format,
+                    lfg_frame *out);
+/* FrameManager::CopyFrameData (src/frame_manager.cpp:83-145): same-size check, then a
+ * device-to-device copy on the stream. */
+int  lfg_frame_copy(lfg_context *ctx, const lfg_frame *src, lfg_frame *dst);
+
+/* FrameManager::CreateStagingBuffer / DestroyStagingBuffer (src/frame_manager.cpp:199-214):
+ * host-visible memory the device can DMA from; here pinned host memory. */
+int  lfg_staging_create(lfg_context *ctx, size_t bytes, void **out_host_ptr);
+void lfg_staging_destroy(lfg_context *ctx, void *host_ptr);
+
+/* Upload = WindowCapture::CopyToStagingBuffer (src/window_capture.cpp:472-568): `bytes` must be
+ * >= width*height*bpp (the reference's size check, :478-481); rows tightly packed.  Download =
+ * the readback in Scaler::ProcessFrame (src/scaler.cpp:479-536).  Both are asynchronous on the
+ * stream when `host` is pinned (lfg_staging_create / ring memory); call lfg_sync() before
+ * touching the host bytes. */
+int  lfg_frame_upload(lfg_context *ctx, lfg_frame *dst, const void *host, size_t bytes);
+int  lfg_frame_download(lfg_context *ctx, const lfg_frame *src, void *host, size_t bytes);
+
+/* Pinned-host frame ring: replaces the per-frame staging alloc/free of the reference
+ * (src/window_capture.cpp:474-487,564; src/scaler.cpp:480-487,614).  `slots` buffers of
+ * `slot_bytes` each; acquire blocks until the slot's last transfer has completed. */
+int  lfg_ring_create(lfg_context *ctx, uint32_t slots, size_t slot_bytes, lfg_ring **out_ring);
+void lfg_ring_destroy(lfg_ring *ring);
+int  lfg_ring_acquire(lfg_ring *ring, void **out_host_ptr, uint32_t *out_slot);
+/* Upload slot -> frame (or download frame -> slot) asynchronously and mark the slot busy
+ * until that transfer finishes. */
+int  lfg_ring_upload(lfg_ring *ring, uint32_t slot, lfg_frame *dst);
+int  lfg_ring_download(lfg_ring *ring, uint32_t slot, const lfg_frame *src);
+
+/* ---------------------------------------------------------------- the three stages */
+
+/* shaders/scale.comp as dispatched by Scaler::ScaleFrame (src/scaler.cpp:260-395):
+ * Lanczos-3 resample of `in` to `out`'s size; push constants inputSize/outputSize are taken
+ * from the frames (src/scaler.cpp:348-351).  Any sizes; out == 2 x in takes the LDS-tiled path. */
+int  lfg_scale(lfg_context *ctx, const lfg_frame *in, lfg_frame *out);
+
+/* shaders/motion.comp as dispatched by FrameManager::InterpolateFrames
+ * (src/frame_manager.cpp:325-344): per-pixel full-search block match of `curr` against `prev`.
+ * `mv` is an LFG_FORMAT_MV_S8X2 frame of the same size.  The reference pushes blockSize = 8,
+ * searchRadius = 16.0f (:332-333); other values are accepted when searchRadius is a whole
+ * number in [0,127] and 1 <= blockSize <= 64. */
+int  lfg_motion(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *curr, lfg_frame *mv,
+                int block_size, float search_radius);
+
+/* shaders/interpolate.comp (src/frame_manager.cpp:351-366): MV-displaced bilinear fetch of prev
+ * and curr, blended by `factor`.  Literal reference semantics (MV in pixels added to normalised
+ * UV). */
+int  lfg_interpolate(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *curr, const lfg_frame *mv,
+                     lfg_frame *out, float factor);
+
+/* FrameManager::InterpolateFrames(previous, current, output, factor)
+ * (src/frame_manager.cpp:216-372): motion (blockSize 8, searchRadius 16) then interpolate, with
+ * the motion-vector image as a context-owned temporary (the reference creates and destroys it
+ * per call, :226-230,369; here it persists between calls and is invisible to the caller). */
+int  lfg_interpolate_frames(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *curr,
+                            lfg_frame *out, float factor);
+
+/* Write the motion vectors as the reference's rgba32f image: vec4(mv.x, mv.y, 0, 1) per pixel
+ * (shaders/motion.comp:56) into `device_rgba32f` (width*height*16 bytes, device memory). */
+int  lfg_mv_export_rgba32f(lfg_context *ctx, const lfg_frame *mv, void *device_rgba32f);
+
+/* ---------------------------------------------------------------- measurement */
+
+/* When enabled, every stage launch is bracketed by HIP events on the context's stream; the
+ * accumulated device time and launch count per stage are read with lfg_profile_get() (which
+ * synchronises).  Disabled by default; lfg_profile_reset() clears the accumulators. */
+int  lfg_profile_enable(lfg_context *ctx, int enabled);
+int  lfg_profile_reset(lfg_context *ctx);
+int  lfg_profile_get(lfg_context *ctx, int stage, double *out_total_ms, uint64_t *out_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LINUXFG_HIP_H */

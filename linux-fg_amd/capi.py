@@ -1,0 +1,201 @@
+"""ctypes binding of the C-ABI in include/linuxfg_hip.h (liblinuxfg_hip.so).
+
+This is the only way Python code (tests/, bench.py, __graft_entry__) reaches the HIP path.
+There is no fallback: if the library is missing, does not export a declared symbol, or no GPU
+is present, the failure is raised, never papered over.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblinuxfg_hip.so")
+
+FORMAT_RGBA8 = 0
+FORMAT_MV_S8X2 = 1
+STAGE_SCALE, STAGE_MOTION, STAGE_INTERPOLATE = 0, 1, 2
+_BPP = {FORMAT_RGBA8: 4, FORMAT_MV_S8X2: 2}
+
+
+class LfgError(RuntimeError):
+    pass
+
+
+class Frame(ctypes.Structure):
+    """struct lfg_frame."""
+    _fields_ = [("data", ctypes.c_void_p), ("width", ctypes.c_uint32), ("height", ctypes.c_uint32),
+                ("pitch", ctypes.c_uint32), ("format", ctypes.c_uint32), ("owned", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32)]
+
+
+_vp, _i, _u32, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_size_t
+_FP = ctypes.POINTER(Frame)
+
+# name -> (restype, argtypes): every entry point include/linuxfg_hip.h declares.
+SIGNATURES = {
+    "lfg_abi_version": (_i, []),
+    "lfg_device_count": (_i, []),
+    "lfg_context_create": (_i, [_i, ctypes.POINTER(_vp)]),
+    "lfg_context_destroy": (None, [_vp]),
+    "lfg_context_set_stream": (_i, [_vp, _vp]),
+    "lfg_context_get_stream": (_vp, [_vp]),
+    "lfg_context_device": (_i, [_vp]),
+    "lfg_sync": (_i, [_vp]),
+    "lfg_last_error": (ctypes.c_char_p, [_vp]),
+    "lfg_frame_create": (_i, [_vp, _u32, _u32, _u32, _FP]),
+    "lfg_frame_destroy": (None, [_vp, _FP]),
+    "lfg_frame_wrap": (_i, [_vp, _u32, _u32, _u32, _u32, _FP]),
+    "lfg_frame_copy": (_i, [_vp, _FP, _FP]),
+    "lfg_staging_create": (_i, [_vp, _sz, ctypes.POINTER(_vp)]),
+    "lfg_staging_destroy": (None, [_vp, _vp]),
+    "lfg_frame_upload": (_i, [_vp, _FP, _vp, _sz]),
+    "lfg_frame_download": (_i, [_vp, _FP, _vp, _sz]),
+    "lfg_ring_create": (_i, [_vp, _u32, _sz, ctypes.POINTER(_vp)]),
+    "lfg_ring_destroy": (None, [_vp]),
+    "lfg_ring_acquire": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_u32)]),
+    "lfg_ring_upload": (_i, [_vp, _u32, _FP]),
+    "lfg_ring_download": (_i, [_vp, _u32, _FP]),
+    "lfg_scale": (_i, [_vp, _FP, _FP]),
+    "lfg_motion": (_i, [_vp, _FP, _FP, _FP, _i, ctypes.c_float]),
+    "lfg_interpolate": (_i, [_vp, _FP, _FP, _FP, _FP, ctypes.c_float]),
+    "lfg_interpolate_frames": (_i, [_vp, _FP, _FP, _FP, ctypes.c_float]),
+    "lfg_mv_export_rgba32f": (_i, [_vp, _FP, _vp]),
+    "lfg_profile_enable": (_i, [_vp, _i]),
+    "lfg_profile_reset": (_i, [_vp]),
+    "lfg_profile_get": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load liblinuxfg_hip.so and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LfgError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+class Context:
+    """One GPU, one stream (lfg_context).  Mirrors the reference's VulkanContext + FrameManager calls."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self.lib = load()
+        h = _vp()
+        rc = self.lib.lfg_context_create(device, ctypes.byref(h))
+        if rc != 0:
+            raise LfgError(f"lfg_context_create failed ({rc}): {self.lib.lfg_last_error(None).decode()}")
+        self.h = h
+        self._frames: list[Frame] = []
+        if stream is not None:
+            self.set_stream(stream)
+
+    # -- plumbing
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise LfgError(f"{what} failed ({rc}): {self.lib.lfg_last_error(self.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            for f in self._frames:
+                self.lib.lfg_frame_destroy(self.h, ctypes.byref(f))
+            self._frames.clear()
+            self.lib.lfg_context_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream: int | None):
+        self._check(self.lib.lfg_context_set_stream(self.h, _vp(stream or 0)), "lfg_context_set_stream")
+
+    def sync(self):
+        self._check(self.lib.lfg_sync(self.h), "lfg_sync")
+
+    # -- frames
+    def create_frame(self, width: int, height: int, fmt: int = FORMAT_RGBA8) -> Frame:
+        f = Frame()
+        self._check(self.lib.lfg_frame_create(self.h, width, height, fmt, ctypes.byref(f)), "lfg_frame_create")
+        self._frames.append(f)
+        return f
+
+    def destroy_frame(self, f: Frame):
+        self.lib.lfg_frame_destroy(self.h, ctypes.byref(f))
+        self._frames = [g for g in self._frames if g is not f]
+
+    @staticmethod
+    def wrap(device_ptr: int, width: int, height: int, fmt: int = FORMAT_RGBA8, pitch: int | None = None) -> Frame:
+        f = Frame()
+        rc = load().lfg_frame_wrap(_vp(device_ptr), width, height, pitch or width * _BPP[fmt], fmt, ctypes.byref(f))
+        if rc != 0:
+            raise LfgError(f"lfg_frame_wrap failed ({rc})")
+        return f
+
+    def upload(self, f: Frame, host: np.ndarray):
+        a = np.ascontiguousarray(host)
+        self._check(self.lib.lfg_frame_upload(self.h, ctypes.byref(f), a.ctypes.data_as(_vp), a.nbytes), "lfg_frame_upload")
+        self.sync()                      # `a` is pageable and may be a temporary
+
+    def download(self, f: Frame) -> np.ndarray:
+        if f.format == FORMAT_RGBA8:
+            out = np.empty((f.height, f.width, 4), np.uint8)
+        else:
+            out = np.empty((f.height, f.width, 2), np.int8)
+        self._check(self.lib.lfg_frame_download(self.h, ctypes.byref(f), out.ctypes.data_as(_vp), out.nbytes), "lfg_frame_download")
+        self.sync()
+        return out
+
+    def frame_from(self, host: np.ndarray, fmt: int = FORMAT_RGBA8) -> Frame:
+        f = self.create_frame(host.shape[1], host.shape[0], fmt)
+        self.upload(f, host)
+        return f
+
+    def copy(self, src: Frame, dst: Frame):
+        self._check(self.lib.lfg_frame_copy(self.h, ctypes.byref(src), ctypes.byref(dst)), "lfg_frame_copy")
+
+    # -- stages (enqueue only)
+    def scale(self, src: Frame, dst: Frame):
+        self._check(self.lib.lfg_scale(self.h, ctypes.byref(src), ctypes.byref(dst)), "lfg_scale")
+
+    def motion(self, prev: Frame, curr: Frame, mv: Frame, block_size: int = 8, search_radius: float = 16.0):
+        self._check(self.lib.lfg_motion(self.h, ctypes.byref(prev), ctypes.byref(curr), ctypes.byref(mv),
+                                        block_size, search_radius), "lfg_motion")
+
+    def interpolate(self, prev: Frame, curr: Frame, mv: Frame, out: Frame, factor: float = 0.5):
+        self._check(self.lib.lfg_interpolate(self.h, ctypes.byref(prev), ctypes.byref(curr), ctypes.byref(mv),
+                                             ctypes.byref(out), factor), "lfg_interpolate")
+
+    def interpolate_frames(self, prev: Frame, curr: Frame, out: Frame, factor: float = 0.5):
+        self._check(self.lib.lfg_interpolate_frames(self.h, ctypes.byref(prev), ctypes.byref(curr),
+                                                    ctypes.byref(out), factor), "lfg_interpolate_frames")
+
+    # -- measurement
+    def profile_enable(self, on: bool = True):
+        self._check(self.lib.lfg_profile_enable(self.h, int(on)), "lfg_profile_enable")
+
+    def profile_reset(self):
+        self._check(self.lib.lfg_profile_reset(self.h), "lfg_profile_reset")
+
+    def profile_get(self, stage: int):
+        ms, n = ctypes.c_double(), ctypes.c_uint64()
+        self._check(self.lib.lfg_profile_get(self.h, stage, ctypes.byref(ms), ctypes.byref(n)), "lfg_profile_get")
+        return ms.value, n.value

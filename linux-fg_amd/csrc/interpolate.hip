@@ -1,0 +1,141 @@
+// interpolate.hip -- motion-displaced blend, the MI355X-native replacement of
+// shaders/interpolate.comp (reference: /root/reference/shaders/interpolate.comp:15-40, dispatched by
+// src/frame_manager.cpp:351-366).
+//
+// Literal reference semantics: the motion vector is in whole pixels and is added to
+// the NORMALISED uv (interpolate.comp:16), so a non-zero component shifts the sample by whole image
+// fractions or pushes it out of [0,1], where that source contributes vec4(0) (:17-20).
+//
+// The arithmetic repeats the oracle's operation order exactly (the library is built with
+// -ffp-contract=off): uv division, bilinear weights per the Vulkan rules with fp32 fractions,
+// mix(x,y,a) = x*(1-a) + y*a, clamp, *255, round half to even.  UNORM8 -> float uses the exact
+// two-op form in lfg_device.hpp.  Output therefore matches the oracle bit for bit.
+//
+// Roofline: HBM.  Algorithmic bytes per pixel = 4 (prev) + 4 (curr) + 2 (mv) + 4 (out) = 14.
+// One thread produces four horizontally adjacent pixels: one 8-byte MV load, one 16-byte store.
+#include "lfg_device.hpp"
+#include "lfg_internal.hpp"
+
+namespace lfg {
+
+struct V4 { float x, y, z, w; };
+
+__device__ __forceinline__ V4 texel_unorm(const uint8_t *__restrict__ img, int pitch, int x, int y) {
+    const uint32_t p = *reinterpret_cast<const uint32_t *>(img + (size_t)y * (size_t)pitch + (size_t)x * 4u);
+    return V4{unorm8_to_float(byte0(p)), unorm8_to_float(byte1(p)),
+              unorm8_to_float(byte2(p)), unorm8_to_float(byte3(p))};
+}
+
+// texture() on a LINEAR / CLAMP_TO_EDGE sampler with normalised coordinates
+// (src/frame_manager.cpp:555-561), oracle choice (3).
+__device__ __forceinline__ V4 texture_bilinear(const uint8_t *__restrict__ img, int W, int H, int pitch,
+                                               float s, float t) {
+    const float u = s * (float)W - 0.5f;
+    const float v = t * (float)H - 0.5f;
+    const float fu = __builtin_floorf(u), fv = __builtin_floorf(v);
+    const float a = u - fu, b = v - fv;
+    int i0 = (int)fu, j0 = (int)fv;
+    int i1 = i0 + 1, j1 = j0 + 1;
+    i0 = clampi(i0, 0, W - 1); i1 = clampi(i1, 0, W - 1);
+    j0 = clampi(j0, 0, H - 1); j1 = clampi(j1, 0, H - 1);
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b);
+    const float w01 = (1.0f - a) * b, w11 = a * b;
+    const V4 t00 = texel_unorm(img, pitch, i0, j0);
+    if (a == 0.0f && b == 0.0f) return t00;     // w00 == 1, the other three products are exactly 0
+    const V4 t10 = texel_unorm(img, pitch, i1, j0);
+    const V4 t01 = texel_unorm(img, pitch, i0, j1);
+    const V4 t11 = texel_unorm(img, pitch, i1, j1);
+    V4 r;
+    r.x = ((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x;
+    r.y = ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y;
+    r.z = ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z;
+    r.w = ((w00 * t00.w + w10 * t10.w) + w01 * t01.w) + w11 * t11.w;
+    return r;
+}
+
+// interpolate.comp:15-22
+__device__ __forceinline__ V4 sample_with_motion(const uint8_t *__restrict__ img, int W, int H, int pitch,
+                                                 float uvx, float uvy, float mx, float my, float scale) {
+    const float sx = uvx + mx * scale, sy = uvy + my * scale;
+    if (sx < 0.0f || sy < 0.0f || sx > 1.0f || sy > 1.0f) return V4{0.f, 0.f, 0.f, 0.f};
+    return texture_bilinear(img, W, H, pitch, sx, sy);
+}
+
+__device__ __forceinline__ float mixf(float x, float y, float a) { return x * (1.0f - a) + y * a; }
+
+__global__ __launch_bounds__(256) void interpolate_kernel(
+    const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
+    const int8_t *__restrict__ mv, int mvPitch, uint8_t *__restrict__ out, int outPitch,
+    int W, int H, float t) {
+    const int qx = blockIdx.x * 64 + (threadIdx.x & 63);         // group of four pixels
+    const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int px0 = qx * 4;
+    if (px0 >= W || py >= H) return;
+    const float uvy = ((float)py + 0.5f) / (float)H;
+    const int8_t *mrow = mv + (size_t)py * (size_t)mvPitch;
+    uint8_t *orow = out + (size_t)py * (size_t)outPitch;
+    const bool full = (px0 + 3 < W) && ((mvPitch & 7) == 0) && ((outPitch & 15) == 0);
+
+    int8_t m[8];
+    if (full) {
+        const uint2 mm = *reinterpret_cast<const uint2 *>(mrow + (size_t)px0 * 2u);
+        m[0] = (int8_t)(mm.x & 0xff); m[1] = (int8_t)((mm.x >> 8) & 0xff);
+        m[2] = (int8_t)((mm.x >> 16) & 0xff); m[3] = (int8_t)(mm.x >> 24);
+        m[4] = (int8_t)(mm.y & 0xff); m[5] = (int8_t)((mm.y >> 8) & 0xff);
+        m[6] = (int8_t)((mm.y >> 16) & 0xff); m[7] = (int8_t)(mm.y >> 24);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int px = min(px0 + i, W - 1);
+            m[2 * i] = mrow[(size_t)px * 2u]; m[2 * i + 1] = mrow[(size_t)px * 2u + 1];
+        }
+    }
+
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int px = px0 + i;
+        const float uvx = ((float)px + 0.5f) / (float)W;
+        const float mx = (float)m[2 * i], my = (float)m[2 * i + 1];
+        const V4 p = sample_with_motion(prev, W, H, prevPitch, uvx, uvy, mx, my, -t);
+        const V4 c = sample_with_motion(curr, W, H, currPitch, uvx, uvy, mx, my, 1.0f - t);
+        o[i] = to_unorm8(mixf(p.x, c.x, t)) | (to_unorm8(mixf(p.y, c.y, t)) << 8) |
+               (to_unorm8(mixf(p.z, c.z, t)) << 16) | (to_unorm8(mixf(p.w, c.w, t)) << 24);
+    }
+    if (full) {
+        *reinterpret_cast<uint4 *>(orow + (size_t)px0 * 4u) = uint4{o[0], o[1], o[2], o[3]};
+    } else {
+        for (int i = 0; i < 4 && px0 + i < W; ++i)
+            *reinterpret_cast<uint32_t *>(orow + (size_t)(px0 + i) * 4u) = o[i];
+    }
+}
+
+hipError_t launch_interpolate(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
+                              const lfg_frame &mv, const lfg_frame &out, float factor) {
+    const int quads = ((int)out.width + 3) / 4;
+    dim3 grid((quads + 63) / 64, (out.height + 3) / 4);
+    hipLaunchKernelGGL(interpolate_kernel, grid, dim3(256), 0, s,
+                       (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
+                       (const int8_t *)mv.data, (int)mv.pitch, (uint8_t *)out.data, (int)out.pitch,
+                       (int)out.width, (int)out.height, factor);
+    return hipGetLastError();
+}
+
+// vec4(best, 0, 1) per pixel, as shaders/motion.comp:56 stores it.
+__global__ __launch_bounds__(256) void mv_export_kernel(const int8_t *__restrict__ mv, int mvPitch,
+                                                        float4 *__restrict__ out, int W, int H) {
+    const int px = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (px >= W || py >= H) return;
+    const int8_t *m = mv + (size_t)py * (size_t)mvPitch + (size_t)px * 2u;
+    out[(size_t)py * (size_t)W + (size_t)px] = float4{(float)m[0], (float)m[1], 0.0f, 1.0f};
+}
+
+hipError_t launch_mv_export(hipStream_t s, const lfg_frame &mv, float *rgba32f) {
+    dim3 grid((mv.width + 63) / 64, (mv.height + 3) / 4);
+    hipLaunchKernelGGL(mv_export_kernel, grid, dim3(256), 0, s, (const int8_t *)mv.data, (int)mv.pitch,
+                       reinterpret_cast<float4 *>(rgba32f), (int)mv.width, (int)mv.height);
+    return hipGetLastError();
+}
+
+}  // namespace lfg

@@ -1,0 +1,458 @@
+// lfg_capi.cpp -- implementation of the C-ABI in include/linuxfg_hip.h.
+// The only translation units that touch HIP are this file and the three kernel files.
+// There is no CPU fallback anywhere: every entry point needs a live HIP device.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "lfg_internal.hpp"
+
+#define LFG_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+std::string g_create_error;       // lfg_last_error(NULL)
+
+int fail(lfg_context *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->error = msg; else g_create_error = msg;
+    return code;
+}
+
+int fail_hip(lfg_context *ctx, hipError_t e, const char *what) {
+    return fail(ctx, e == hipErrorOutOfMemory ? LFG_ERR_NOMEM : LFG_ERR_DEVICE,
+                std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define LFG_HIP(ctx, call)                                            \
+    do {                                                              \
+        hipError_t e_ = (call);                                       \
+        if (e_ != hipSuccess) return fail_hip((ctx), e_, #call);      \
+    } while (0)
+
+uint32_t bytes_per_pixel(uint32_t format) {
+    switch (format) {
+        case LFG_FORMAT_RGBA8_UNORM: return 4;
+        case LFG_FORMAT_MV_S8X2: return 2;
+        default: return 0;
+    }
+}
+
+bool frame_ok(const lfg_frame *f, uint32_t format) {
+    return f && f->data && f->width > 0 && f->height > 0 && f->format == format &&
+           f->pitch >= f->width * bytes_per_pixel(format);
+}
+
+bool same_size(const lfg_frame *a, const lfg_frame *b) { return a->width == b->width && a->height == b->height; }
+
+// ---- Lanczos tables: the per-axis part of shaders/scale.comp:16-41, same fp32 operation order.
+
+float lanczos_ref(float x) {                                   // scale.comp:16-20
+    if (x == 0.0f) return 1.0f;
+    const float px = 3.14159265359f * x;
+    const float s1 = (float)std::sin((double)px);
+    const float s2 = (float)std::sin((double)(px / 3.0f));
+    return 3.0f * s1 * s2 / (px * px);
+}
+
+int build_axis_table(lfg_context *ctx, int in_size, int out_size, lfg::AxisTable **out) {
+    for (auto &t : ctx->tables)
+        if (t.in_size == in_size && t.out_size == out_size) { *out = &t; return LFG_OK; }
+
+    std::vector<int> start((size_t)out_size);
+    std::vector<float> weight((size_t)out_size * 6u);
+    const float ts = 1.0f / (float)in_size;                    // scale.comp:23
+    for (int p = 0; p < out_size; ++p) {
+        const float uv = ((float)p + 0.5f) / (float)out_size;  // scale.comp:57
+        const float pp = uv * (float)in_size - 0.5f;           // :24
+        const float fl = std::floor(pp);
+        const float f = pp - fl;                               // :25 fract
+        const float s = fl - 2.0f;                             // :26
+        double raw[6], sum = 0.0;
+        for (int k = 0; k < 6; ++k) {
+            const float sp = (s + (float)k + 0.5f) * ts;       // :33
+            const bool skip = sp < 0.0f || sp > 1.0f;          // :34-37
+            raw[k] = skip ? 0.0 : (double)lanczos_ref((float)k - f - 2.0f);   // :39-41
+            sum += raw[k];
+        }
+        start[(size_t)p] = (int)s;
+        for (int k = 0; k < 6; ++k) weight[(size_t)p * 6u + (size_t)k] = (float)(raw[k] / sum);   // :48
+    }
+    lfg::AxisTable t;
+    t.in_size = in_size; t.out_size = out_size;
+    t.pattern_2x = (out_size == 2 * in_size);
+    if (t.pattern_2x)
+        for (int k = 0; k < in_size; ++k)
+            if (start[(size_t)(2 * k)] != k - 3 || start[(size_t)(2 * k + 1)] != k - 2) { t.pattern_2x = false; break; }
+
+    LFG_HIP(ctx, hipMalloc((void **)&t.d_start, start.size() * sizeof(int)));
+    hipError_t e = hipMalloc((void **)&t.d_weight, weight.size() * sizeof(float));
+    if (e != hipSuccess) { (void)hipFree(t.d_start); return fail_hip(ctx, e, "hipMalloc(weights)"); }
+    // Synchronous copies: pageable host vectors go out of scope when this function returns.
+    e = hipMemcpy(t.d_start, start.data(), start.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(t.d_weight, weight.data(), weight.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(t.d_start); (void)hipFree(t.d_weight); return fail_hip(ctx, e, "hipMemcpy(tables)"); }
+    ctx->tables.push_back(t);
+    *out = &ctx->tables.back();
+    return LFG_OK;
+}
+
+// Bounded cache: called at the top of lfg_scale, before any table pointer is taken, so the two
+// lookups that follow can never evict each other.
+void trim_axis_tables(lfg_context *ctx) {
+    while (ctx->tables.size() > 14) {
+        (void)hipStreamSynchronize(ctx->stream);               // a queued kernel may still read it
+        (void)hipFree(ctx->tables.front().d_start); (void)hipFree(ctx->tables.front().d_weight);
+        ctx->tables.erase(ctx->tables.begin());
+    }
+}
+
+// ---- profiling
+
+struct StageTimer {
+    lfg_context *ctx;
+    hipEvent_t b = nullptr, e = nullptr;
+    int stage;
+    StageTimer(lfg_context *c, int st) : ctx(c), stage(st) {
+        if (!ctx->profile) return;
+        if (!ctx->prof_free.empty()) { b = ctx->prof_free.back().first; e = ctx->prof_free.back().second; ctx->prof_free.pop_back(); }
+        else if (hipEventCreate(&b) != hipSuccess || hipEventCreate(&e) != hipSuccess) { b = e = nullptr; return; }
+        (void)hipEventRecord(b, ctx->stream);
+    }
+    ~StageTimer() {
+        if (!b) return;
+        (void)hipEventRecord(e, ctx->stream);
+        lfg::ProfileSlot s; s.begin = b; s.end = e; s.stage = stage;
+        ctx->prof_pending.push_back(s);
+    }
+};
+
+int drain_profile(lfg_context *ctx) {
+    if (ctx->prof_pending.empty()) return LFG_OK;
+    LFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &s : ctx->prof_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.begin, s.end) == hipSuccess) { ctx->prof_ms[s.stage] += ms; ctx->prof_n[s.stage] += 1; }
+        ctx->prof_free.emplace_back(s.begin, s.end);
+    }
+    ctx->prof_pending.clear();
+    return LFG_OK;
+}
+
+}  // namespace
+
+struct lfg_ring {
+    lfg_context *ctx = nullptr;
+    uint32_t slots = 0;
+    size_t slot_bytes = 0;
+    uint8_t *base = nullptr;                 // pinned host memory, slots * slot_bytes
+    std::vector<hipEvent_t> done;            // last transfer touching each slot
+    std::vector<uint8_t> busy;
+    uint32_t next = 0;
+};
+
+// ================================================================== library / context
+
+LFG_EXPORT int lfg_abi_version(void) { return LFG_ABI_VERSION; }
+
+LFG_EXPORT int lfg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+LFG_EXPORT int lfg_context_create(int device_ordinal, lfg_context **out_ctx) {
+    if (!out_ctx) return fail(nullptr, LFG_ERR_INVALID, "lfg_context_create: out_ctx is NULL");
+    *out_ctx = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, LFG_ERR_DEVICE, std::string("lfg_context_create: no HIP device (") +
+                                                 (e != hipSuccess ? hipGetErrorString(e) : "count 0") + "); there is no CPU fallback");
+    const int dev = device_ordinal < 0 ? 0 : device_ordinal;
+    if (dev >= n) return fail(nullptr, LFG_ERR_INVALID, "lfg_context_create: device ordinal out of range");
+    LFG_HIP(nullptr, hipSetDevice(dev));
+    lfg_context *ctx = new (std::nothrow) lfg_context();
+    if (!ctx) return fail(nullptr, LFG_ERR_NOMEM, "lfg_context_create: out of host memory");
+    ctx->device = dev;
+    e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; return fail_hip(nullptr, e, "hipStreamCreate"); }
+    ctx->stream = ctx->own_stream;
+    ctx->tables.reserve(17);                 // AxisTable pointers handed out stay valid
+    *out_ctx = ctx;
+    return LFG_OK;
+}
+
+LFG_EXPORT void lfg_context_destroy(lfg_context *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream != ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    for (auto &s : ctx->prof_pending) { (void)hipEventDestroy(s.begin); (void)hipEventDestroy(s.end); }
+    for (auto &p : ctx->prof_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (auto &t : ctx->tables) { (void)hipFree(t.d_start); (void)hipFree(t.d_weight); }
+    if (ctx->mv_tmp.data && ctx->mv_tmp.owned) (void)hipFree(ctx->mv_tmp.data);
+    (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+LFG_EXPORT int lfg_context_set_stream(lfg_context *ctx, void *hip_stream) {
+    if (!ctx) return LFG_ERR_INVALID;
+    int rc = drain_profile(ctx);
+    if (rc != LFG_OK) return rc;
+    LFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return LFG_OK;
+}
+
+LFG_EXPORT void *lfg_context_get_stream(lfg_context *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+LFG_EXPORT int lfg_context_device(const lfg_context *ctx) { return ctx ? ctx->device : -1; }
+
+LFG_EXPORT int lfg_sync(lfg_context *ctx) {
+    if (!ctx) return LFG_ERR_INVALID;
+    LFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LFG_OK;
+}
+
+LFG_EXPORT const char *lfg_last_error(const lfg_context *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+// ================================================================== frames
+
+LFG_EXPORT int lfg_frame_create(lfg_context *ctx, uint32_t width, uint32_t height, uint32_t format, lfg_frame *out) {
+    if (!ctx || !out) return fail(ctx, LFG_ERR_INVALID, "lfg_frame_create: NULL argument");
+    const uint32_t bpp = bytes_per_pixel(format);
+    if (!bpp || width == 0 || height == 0 || width > 32768u || height > 32768u)
+        return fail(ctx, LFG_ERR_INVALID, "lfg_frame_create: bad size or format");
+    LFG_HIP(ctx, hipSetDevice(ctx->device));
+    void *p = nullptr;
+    const size_t bytes = (size_t)width * (size_t)height * (size_t)bpp;
+    LFG_HIP(ctx, hipMalloc(&p, bytes));
+    out->data = p; out->width = width; out->height = height; out->pitch = width * bpp;
+    out->format = format; out->owned = 1; out->reserved = 0;
+    return LFG_OK;
+}
+
+LFG_EXPORT void lfg_frame_destroy(lfg_context *ctx, lfg_frame *frame) {
+    if (!frame) return;
+    if (frame->data && frame->owned) {
+        if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+        (void)hipFree(frame->data);
+    }
+    frame->data = nullptr; frame->width = frame->height = frame->pitch = 0; frame->owned = 0;
+}
+
+LFG_EXPORT int lfg_frame_wrap(void *device_ptr, uint32_t width, uint32_t height, uint32_t pitch, uint32_t format,
+                              lfg_frame *out) {
+    const uint32_t bpp = bytes_per_pixel(format);
+    if (!out || !device_ptr || !bpp || width == 0 || height == 0 || pitch < width * bpp) return LFG_ERR_INVALID;
+    out->data = device_ptr; out->width = width; out->height = height; out->pitch = pitch;
+    out->format = format; out->owned = 0; out->reserved = 0;
+    return LFG_OK;
+}
+
+LFG_EXPORT int lfg_frame_copy(lfg_context *ctx, const lfg_frame *src, lfg_frame *dst) {
+    if (!ctx || !src || !dst || !src->data || !dst->data) return fail(ctx, LFG_ERR_INVALID, "lfg_frame_copy: NULL frame");
+    if (!same_size(src, dst) || src->format != dst->format)                  // frame_manager.cpp:84-87
+        return fail(ctx, LFG_ERR_INVALID, "Source and destination frame dimensions do not match");
+    const size_t row = (size_t)src->width * bytes_per_pixel(src->format);
+    LFG_HIP(ctx, hipMemcpy2DAsync(dst->data, dst->pitch, src->data, src->pitch, row, src->height,
+                                  hipMemcpyDeviceToDevice, ctx->stream));
+    return LFG_OK;
+}
+
+LFG_EXPORT int lfg_staging_create(lfg_context *ctx, size_t bytes, void **out_host_ptr) {
+    if (!ctx || !out_host_ptr || bytes == 0) return fail(ctx, LFG_ERR_INVALID, "lfg_staging_create: bad argument");
+    LFG_HIP(ctx, hipSetDevice(ctx->device));
+    LFG_HIP(ctx, hipHostMalloc(out_host_ptr, bytes, hipHostMallocDefault));
+    return LFG_OK;
+}
+
+LFG_EXPORT void lfg_staging_destroy(lfg_context *ctx, void *host_ptr) {
+    if (!host_ptr) return;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipHostFree(host_ptr);
+}
+
+LFG_EXPORT int lfg_frame_upload(lfg_context *ctx, lfg_frame *dst, const void *host, size_t bytes) {
+    if (!ctx || !dst || !dst->data || !host) return fail(ctx, LFG_ERR_INVALID, "lfg_frame_upload: NULL argument");
+    const size_t row = (size_t)dst->width * bytes_per_pixel(dst->format);
+    if (bytes < row * dst->height) {                                          // window_capture.cpp:478-481
+        char msg[160];
+        snprintf(msg, sizeof msg, "Captured image size (%zu) smaller than expected (%zu)", bytes, row * dst->height);
+        return fail(ctx, LFG_ERR_INVALID, msg);
+    }
+    LFG_HIP(ctx, hipMemcpy2DAsync(dst->data, dst->pitch, host, row, row, dst->height, hipMemcpyHostToDevice, ctx->stream));
+    return LFG_OK;
+}
+
+LFG_EXPORT int lfg_frame_download(lfg_context *ctx, const lfg_frame *src, void *host, size_t bytes) {
+    if (!ctx || !src || !src->data || !host) return fail(ctx, LFG_ERR_INVALID, "lfg_frame_download: NULL argument");
+    const size_t row = (size_t)src->width * bytes_per_pixel(src->format);
+    if (bytes < row * src->height) return fail(ctx, LFG_ERR_INVALID, "lfg_frame_download: host buffer too small");
+    LFG_HIP(ctx, hipMemcpy2DAsync(host, row, src->data, src->pitch, row, src->height, hipMemcpyDeviceToHost, ctx->stream));
+    return LFG_OK;
+}
+
+// ================================================================== pinned-host frame ring
+
+LFG_EXPORT int lfg_ring_create(lfg_context *ctx, uint32_t slots, size_t slot_bytes, lfg_ring **out_ring) {
+    if (!ctx || !out_ring || slots == 0 || slots > 64 || slot_bytes == 0)
+        return fail(ctx, LFG_ERR_INVALID, "lfg_ring_create: bad argument");
+    lfg_ring *r = new (std::nothrow) lfg_ring();
+    if (!r) return fail(ctx, LFG_ERR_NOMEM, "lfg_ring_create: out of host memory");
+    r->ctx = ctx; r->slots = slots; r->slot_bytes = (slot_bytes + 4095u) & ~(size_t)4095u;
+    hipError_t e = hipHostMalloc((void **)&r->base, r->slot_bytes * slots, hipHostMallocDefault);
+    if (e != hipSuccess) { delete r; return fail_hip(ctx, e, "hipHostMalloc(ring)"); }
+    r->done.resize(slots, nullptr); r->busy.assign(slots, 0);
+    for (uint32_t i = 0; i < slots; ++i) {
+        e = hipEventCreateWithFlags(&r->done[i], hipEventDisableTiming);
+        if (e != hipSuccess) { lfg_ring_destroy(r); return fail_hip(ctx, e, "hipEventCreate(ring)"); }
+    }
+    *out_ring = r;
+    return LFG_OK;
+}
+
+LFG_EXPORT void lfg_ring_destroy(lfg_ring *ring) {
+    if (!ring) return;
+    for (uint32_t i = 0; i < ring->slots; ++i)
+        if (ring->done[i]) { if (ring->busy[i]) (void)hipEventSynchronize(ring->done[i]); (void)hipEventDestroy(ring->done[i]); }
+    if (ring->base) (void)hipHostFree(ring->base);
+    delete ring;
+}
+
+LFG_EXPORT int lfg_ring_acquire(lfg_ring *ring, void **out_host_ptr, uint32_t *out_slot) {
+    if (!ring || !out_host_ptr || !out_slot) return LFG_ERR_INVALID;
+    const uint32_t s = ring->next;
+    ring->next = (ring->next + 1) % ring->slots;
+    if (ring->busy[s]) { LFG_HIP(ring->ctx, hipEventSynchronize(ring->done[s])); ring->busy[s] = 0; }
+    *out_host_ptr = ring->base + (size_t)s * ring->slot_bytes;
+    *out_slot = s;
+    return LFG_OK;
+}
+
+LFG_EXPORT int lfg_ring_upload(lfg_ring *ring, uint32_t slot, lfg_frame *dst) {
+    if (!ring || slot >= ring->slots) return LFG_ERR_INVALID;
+    int rc = lfg_frame_upload(ring->ctx, dst, ring->base + (size_t)slot * ring->slot_bytes, ring->slot_bytes);
+    if (rc != LFG_OK) return rc;
+    LFG_HIP(ring->ctx, hipEventRecord(ring->done[slot], ring->ctx->stream));
+    ring->busy[slot] = 1;
+    return LFG_OK;
+}
+
+LFG_EXPORT int lfg_ring_download(lfg_ring *ring, uint32_t slot, const lfg_frame *src) {
+    if (!ring || slot >= ring->slots) return LFG_ERR_INVALID;
+    int rc = lfg_frame_download(ring->ctx, src, ring->base + (size_t)slot * ring->slot_bytes, ring->slot_bytes);
+    if (rc != LFG_OK) return rc;
+    LFG_HIP(ring->ctx, hipEventRecord(ring->done[slot], ring->ctx->stream));
+    ring->busy[slot] = 1;
+    return LFG_OK;
+}
+
+// ================================================================== stages
+
+LFG_EXPORT int lfg_scale(lfg_context *ctx, const lfg_frame *in, lfg_frame *out) {
+    if (!ctx) return LFG_ERR_INVALID;
+    if (!frame_ok(in, LFG_FORMAT_RGBA8_UNORM) || !frame_ok(out, LFG_FORMAT_RGBA8_UNORM))
+        return fail(ctx, LFG_ERR_INVALID, "lfg_scale: frames must be non-empty RGBA8");
+    if (in->data == out->data) return fail(ctx, LFG_ERR_INVALID, "lfg_scale: in-place scaling is not supported");
+    trim_axis_tables(ctx);
+    lfg::AxisTable *tx = nullptr, *ty = nullptr;               // vector capacity is reserved: pointers stay valid
+    int rc = build_axis_table(ctx, (int)in->width, (int)out->width, &tx);
+    if (rc != LFG_OK) return rc;
+    rc = build_axis_table(ctx, (int)in->height, (int)out->height, &ty);
+    if (rc != LFG_OK) return rc;
+    const bool fast = tx->pattern_2x && ty->pattern_2x && (in->pitch % 4u == 0) && (out->pitch % 8u == 0) &&
+                      ((uintptr_t)out->data % 8u == 0) && ((uintptr_t)in->data % 4u == 0);
+    StageTimer timer(ctx, LFG_STAGE_SCALE);
+    hipError_t e = fast ? lfg::launch_scale_2x(ctx->stream, *in, *out, *tx, *ty)
+                        : lfg::launch_scale_generic(ctx->stream, *in, *out, *tx, *ty);
+    if (e != hipSuccess) return fail_hip(ctx, e, "scale kernel launch");
+    return LFG_OK;
+}
+
+LFG_EXPORT int lfg_motion(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *curr, lfg_frame *mv,
+                          int block_size, float search_radius) {
+    if (!ctx) return LFG_ERR_INVALID;
+    if (!frame_ok(prev, LFG_FORMAT_RGBA8_UNORM) || !frame_ok(curr, LFG_FORMAT_RGBA8_UNORM) ||
+        !frame_ok(mv, LFG_FORMAT_MV_S8X2))
+        return fail(ctx, LFG_ERR_INVALID, "lfg_motion: prev/curr must be RGBA8 and mv MV_S8X2, all non-empty");
+    if (!same_size(prev, curr) || !same_size(curr, mv))
+        return fail(ctx, LFG_ERR_INVALID, "lfg_motion: prev, curr and mv differ in size");
+    if (block_size < 1 || block_size > 64) return fail(ctx, LFG_ERR_UNSUPPORTED, "lfg_motion: blockSize must be in [1,64]");
+    if (!(search_radius >= 0.0f) || search_radius > 127.0f || search_radius != std::floor(search_radius))
+        return fail(ctx, LFG_ERR_UNSUPPORTED, "lfg_motion: searchRadius must be a whole number in [0,127]");
+    if ((prev->pitch | curr->pitch) % 4u || ((uintptr_t)prev->data | (uintptr_t)curr->data) % 4u)
+        return fail(ctx, LFG_ERR_INVALID, "lfg_motion: RGBA8 frames must be 4-byte aligned");
+    const int R = (int)search_radius;
+    StageTimer timer(ctx, LFG_STAGE_MOTION);
+    hipError_t e;
+    if (block_size == 8 && R == 16) e = lfg::launch_motion_tiled_8_16(ctx->stream, *prev, *curr, *mv);
+    else e = lfg::launch_motion_generic(ctx->stream, *prev, *curr, *mv, block_size, R);
+    if (e != hipSuccess) return fail_hip(ctx, e, "motion kernel launch");
+    return LFG_OK;
+}
+
+LFG_EXPORT int lfg_interpolate(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *curr, const lfg_frame *mv,
+                               lfg_frame *out, float factor) {
+    if (!ctx) return LFG_ERR_INVALID;
+    if (!frame_ok(prev, LFG_FORMAT_RGBA8_UNORM) || !frame_ok(curr, LFG_FORMAT_RGBA8_UNORM) ||
+        !frame_ok(mv, LFG_FORMAT_MV_S8X2) || !frame_ok(out, LFG_FORMAT_RGBA8_UNORM))
+        return fail(ctx, LFG_ERR_INVALID, "lfg_interpolate: bad frame (NULL, empty or wrong format)");
+    if (!same_size(prev, curr) || !same_size(curr, mv) || !same_size(curr, out))
+        return fail(ctx, LFG_ERR_INVALID, "lfg_interpolate: frames differ in size");
+    if ((prev->pitch | curr->pitch | out->pitch) % 4u || mv->pitch % 2u)
+        return fail(ctx, LFG_ERR_INVALID, "lfg_interpolate: row pitch not a multiple of the pixel size");
+    if (out->data == prev->data || out->data == curr->data)
+        return fail(ctx, LFG_ERR_INVALID, "lfg_interpolate: output aliases an input");
+    StageTimer timer(ctx, LFG_STAGE_INTERPOLATE);
+    hipError_t e = lfg::launch_interpolate(ctx->stream, *prev, *curr, *mv, *out, factor);
+    if (e != hipSuccess) return fail_hip(ctx, e, "interpolate kernel launch");
+    return LFG_OK;
+}
+
+LFG_EXPORT int lfg_interpolate_frames(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *curr,
+                                      lfg_frame *out, float factor) {
+    if (!ctx || !curr) return fail(ctx, LFG_ERR_INVALID, "lfg_interpolate_frames: NULL argument");
+    lfg_frame &mv = ctx->mv_tmp;
+    if (!mv.data || mv.width != curr->width || mv.height != curr->height) {   // frame_manager.cpp:226-230
+        lfg_frame_destroy(ctx, &mv);
+        int rc = lfg_frame_create(ctx, curr->width, curr->height, LFG_FORMAT_MV_S8X2, &mv);
+        if (rc != LFG_OK) return fail(ctx, rc, "Failed to create motion vectors frame");
+    }
+    int rc = lfg_motion(ctx, prev, curr, &mv, 8, 16.0f);                      // frame_manager.cpp:332-333
+    if (rc != LFG_OK) return rc;
+    return lfg_interpolate(ctx, prev, curr, &mv, out, factor);
+}
+
+LFG_EXPORT int lfg_mv_export_rgba32f(lfg_context *ctx, const lfg_frame *mv, void *device_rgba32f) {
+    if (!ctx || !frame_ok(mv, LFG_FORMAT_MV_S8X2) || !device_rgba32f || (uintptr_t)device_rgba32f % 16u)
+        return fail(ctx, LFG_ERR_INVALID, "lfg_mv_export_rgba32f: bad argument");
+    hipError_t e = lfg::launch_mv_export(ctx->stream, *mv, (float *)device_rgba32f);
+    if (e != hipSuccess) return fail_hip(ctx, e, "mv export kernel launch");
+    return LFG_OK;
+}
+
+// ================================================================== measurement
+
+LFG_EXPORT int lfg_profile_enable(lfg_context *ctx, int enabled) {
+    if (!ctx) return LFG_ERR_INVALID;
+    int rc = drain_profile(ctx);
+    ctx->profile = enabled != 0;
+    return rc;
+}
+
+LFG_EXPORT int lfg_profile_reset(lfg_context *ctx) {
+    if (!ctx) return LFG_ERR_INVALID;
+    int rc = drain_profile(ctx);
+    for (int i = 0; i < LFG_STAGE_COUNT; ++i) { ctx->prof_ms[i] = 0.0; ctx->prof_n[i] = 0; }
+    return rc;
+}
+
+LFG_EXPORT int lfg_profile_get(lfg_context *ctx, int stage, double *out_total_ms, uint64_t *out_launches) {
+    if (!ctx || stage < 0 || stage >= LFG_STAGE_COUNT) return LFG_ERR_INVALID;
+    int rc = drain_profile(ctx);
+    if (out_total_ms) *out_total_ms = ctx->prof_ms[stage];
+    if (out_launches) *out_launches = ctx->prof_n[stage];
+    return rc;
+}

@@ -1,0 +1,65 @@
+// Internal declarations shared by the C-ABI implementation and the kernel launchers.
+// Not part of the public boundary (that is include/linuxfg_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "linuxfg_hip.h"
+
+namespace lfg {
+
+// Per-axis Lanczos tables for one (inSize -> outSize) resample, as shaders/scale.comp:24-41
+// computes them per output coordinate: first tap index (floor(pixelPos) - 2, unclamped) and six
+// weights, pre-normalised by the sum of the in-range weights (the shader divides by totalWeight,
+// scale.comp:48; the filter is exactly separable) and zeroed for taps
+// the shader skips (scale.comp:34-37).
+struct AxisTable {
+    int in_size = 0, out_size = 0;
+    bool pattern_2x = false;      // start[2k] == k-3 and start[2k+1] == k-2 for every k
+    int *d_start = nullptr;       // [out_size]
+    float *d_weight = nullptr;    // [out_size][6]
+};
+
+struct ProfileSlot {
+    hipEvent_t begin = nullptr, end = nullptr;
+    int stage = 0;
+};
+
+}  // namespace lfg
+
+struct lfg_context {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string error;
+    std::vector<lfg::AxisTable> tables;       // small cache, linear search
+    lfg_frame mv_tmp{};                        // temporary of lfg_interpolate_frames
+    // profiling
+    bool profile = false;
+    std::vector<lfg::ProfileSlot> prof_pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_free;
+    double prof_ms[LFG_STAGE_COUNT] = {0, 0, 0};
+    uint64_t prof_n[LFG_STAGE_COUNT] = {0, 0, 0};
+};
+
+namespace lfg {
+
+// Kernel launchers (scale.hip, motion.hip, interpolate.hip).  All enqueue on `s` and return the
+// launch status; arguments have been validated by the caller.
+hipError_t launch_scale_generic(hipStream_t s, const lfg_frame &in, const lfg_frame &out,
+                                const AxisTable &tx, const AxisTable &ty);
+hipError_t launch_scale_2x(hipStream_t s, const lfg_frame &in, const lfg_frame &out,
+                           const AxisTable &tx, const AxisTable &ty);
+hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
+                                    const lfg_frame &mv);
+hipError_t launch_motion_generic(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
+                                 const lfg_frame &mv, int block_size, int radius);
+hipError_t launch_interpolate(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
+                              const lfg_frame &mv, const lfg_frame &out, float factor);
+hipError_t launch_mv_export(hipStream_t s, const lfg_frame &mv, float *rgba32f);
+
+}  // namespace lfg
