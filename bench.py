@@ -89,7 +89,7 @@ def cpu_baseline(w_in, h_in, w, h, factors, workload):
                           f"extrapolated by rows; {threads} threads"}
     # motion + interpolate at output resolution on synthetic frames of that size
     prev, curr = synth.make_pair(w, h, stream=0)
-    mw, mh = 128, max(4, threads)                                    # crop away from the borders
+    mw, mh = 128, 2 * threads                                        # crop away from the borders
     x0, y0 = w // 2, h // 2
     t0 = time.perf_counter()
     mv_roi = oracle.motion(prev, curr, roi=(x0, y0, x0 + mw, y0 + mh), threads=threads)

@@ -173,6 +173,13 @@ int  lfg_interpolate_frames(lfg_context *ctx, const lfg_frame *prev, const lfg_f
  * (shaders/motion.comp:56) into `device_rgba32f` (width*height*16 bytes, device memory). */
 int  lfg_mv_export_rgba32f(lfg_context *ctx, const lfg_frame *mv, void *device_rgba32f);
 
+/* ---------------------------------------------------------------- diagnostics */
+
+/* The motion kernel uses a hand-written correctly rounded sqrt (csrc/motion.hip: exact_sqrt).  This
+ * compares it on the device with the compiler's IEEE sqrtf for every float whose bit pattern lies
+ * in [lo_bits, hi_bits] and returns the number of mismatches (expected 0).  Test-suite use only. */
+int  lfg_selftest_sqrt(lfg_context *ctx, uint32_t lo_bits, uint32_t hi_bits, uint64_t *out_mismatches);
+
 /* ---------------------------------------------------------------- measurement */
 
 /* When enabled, every stage launch is bracketed by HIP events on the context's stream; the

@@ -63,6 +63,7 @@ SIGNATURES = {
     "lfg_interpolate": (_i, [_vp, _FP, _FP, _FP, _FP, ctypes.c_float]),
     "lfg_interpolate_frames": (_i, [_vp, _FP, _FP, _FP, ctypes.c_float]),
     "lfg_mv_export_rgba32f": (_i, [_vp, _FP, _vp]),
+    "lfg_selftest_sqrt": (_i, [_vp, _u32, _u32, ctypes.POINTER(ctypes.c_uint64)]),
     "lfg_profile_enable": (_i, [_vp, _i]),
     "lfg_profile_reset": (_i, [_vp]),
     "lfg_profile_get": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]),
@@ -187,6 +188,11 @@ class Context:
     def interpolate_frames(self, prev: Frame, curr: Frame, out: Frame, factor: float = 0.5):
         self._check(self.lib.lfg_interpolate_frames(self.h, ctypes.byref(prev), ctypes.byref(curr),
                                                     ctypes.byref(out), factor), "lfg_interpolate_frames")
+
+    def selftest_sqrt(self, lo_bits: int, hi_bits: int) -> int:
+        n = ctypes.c_uint64()
+        self._check(self.lib.lfg_selftest_sqrt(self.h, lo_bits, hi_bits, ctypes.byref(n)), "lfg_selftest_sqrt")
+        return n.value
 
     # -- measurement
     def profile_enable(self, on: bool = True):

@@ -99,8 +99,7 @@ __global__ __launch_bounds__(256) void interpolate_kernel(
         const float mx = (float)m[2 * i], my = (float)m[2 * i + 1];
         const V4 p = sample_with_motion(prev, W, H, prevPitch, uvx, uvy, mx, my, -t);
         const V4 c = sample_with_motion(curr, W, H, currPitch, uvx, uvy, mx, my, 1.0f - t);
-        o[i] = to_unorm8(mixf(p.x, c.x, t)) | (to_unorm8(mixf(p.y, c.y, t)) << 8) |
-               (to_unorm8(mixf(p.z, c.z, t)) << 16) | (to_unorm8(mixf(p.w, c.w, t)) << 24);
+        o[i] = pack_rgba8_unorm(mixf(p.x, c.x, t), mixf(p.y, c.y, t), mixf(p.z, c.z, t), mixf(p.w, c.w, t));
     }
     if (full) {
         *reinterpret_cast<uint4 *>(orow + (size_t)px0 * 4u) = uint4{o[0], o[1], o[2], o[3]};

@@ -433,6 +433,23 @@ LFG_EXPORT int lfg_mv_export_rgba32f(lfg_context *ctx, const lfg_frame *mv, void
     return LFG_OK;
 }
 
+// ================================================================== diagnostics
+
+LFG_EXPORT int lfg_selftest_sqrt(lfg_context *ctx, uint32_t lo_bits, uint32_t hi_bits, uint64_t *out_mismatches) {
+    if (!ctx || !out_mismatches || lo_bits > hi_bits) return fail(ctx, LFG_ERR_INVALID, "lfg_selftest_sqrt: bad argument");
+    unsigned long long *d = nullptr;
+    LFG_HIP(ctx, hipMalloc((void **)&d, sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess) e = lfg::launch_sqrt_selftest(ctx->stream, lo_bits, hi_bits, d);
+    unsigned long long h = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail_hip(ctx, e, "sqrt selftest");
+    *out_mismatches = (uint64_t)h;
+    return LFG_OK;
+}
+
 // ================================================================== measurement
 
 LFG_EXPORT int lfg_profile_enable(lfg_context *ctx, int enabled) {

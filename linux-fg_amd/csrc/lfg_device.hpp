@@ -28,21 +28,67 @@ __device__ __forceinline__ float byte1(uint32_t p) { return (float)((p >> 8) & 0
 __device__ __forceinline__ float byte2(uint32_t p) { return (float)((p >> 16) & 0xffu); }
 __device__ __forceinline__ float byte3(uint32_t p) { return (float)(p >> 24); }
 
-// A value already in 0..255 scale -> byte: clamp, round half to even (v_rndne_f32).
-__device__ __forceinline__ uint32_t to_byte_255(float v) {
-    v = __builtin_fminf(__builtin_fmaxf(v, 0.0f), 255.0f);       // fmax(NaN, 0) = 0
-    return (uint32_t)__builtin_rintf(v);
-}
-
+// v_cvt_pk_u8_f32 converts with round-half-to-even and saturates to [0,255] (NaN -> 0); measured on
+// gfx950 by tools/microbench.hip: 0.5->0, 1.5->2, 2.5->2, 254.5->254, 300->255, -3->0.  One VALU op
+// per channel replaces clamp + rndne + cvt + shift/or.
 __device__ __forceinline__ uint32_t pack_rgba8_255(float r, float g, float b, float a) {
-    return to_byte_255(r) | (to_byte_255(g) << 8) | (to_byte_255(b) << 16) | (to_byte_255(a) << 24);
+    uint32_t p = __builtin_amdgcn_cvt_pk_u8_f32(r, 0u, 0u);
+    p = __builtin_amdgcn_cvt_pk_u8_f32(g, 1u, p);
+    p = __builtin_amdgcn_cvt_pk_u8_f32(b, 2u, p);
+    return __builtin_amdgcn_cvt_pk_u8_f32(a, 3u, p);
 }
 
-// A value in 0..1 scale -> UNORM8 exactly as the oracle stores it: clamp to [0,1], * 255, RNE.
-__device__ __forceinline__ uint32_t to_unorm8(float v) {
-    v = __builtin_fminf(__builtin_fmaxf(v, 0.0f), 1.0f);
-    return (uint32_t)__builtin_rintf(v * 255.0f);
+// Values in 0..1 scale -> packed UNORM8 exactly as the oracle stores them: clamp to [0,1], * 255,
+// round half to even.  Scaling first and saturating in the conversion gives the same byte.
+__device__ __forceinline__ uint32_t pack_rgba8_unorm(float r, float g, float b, float a) {
+    return pack_rgba8_255(r * 255.0f, g * 255.0f, b * 255.0f, a * 255.0f);
 }
+
+// ---- typed buffer loads: the texture-address unit converts RGBA8 UNORM to four floats on the way in.
+// Measured on gfx950 (tools/probe_unorm.hip): the conversion is bit-exact (float)k / 255.0f for all
+// 256 byte values, i.e. oracle choice (1), at zero VALU cost.  hipcc exposes no builtin for the format
+// loads, so they are issued from inline asm; the compiler does not track them, hence the explicit
+// s_waitcnt that takes every loaded register as an in/out operand (uses cannot be scheduled above it).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// Buffer resource (V#) over `bytes` bytes at `base`: raw (stride 0), DST_SEL = R,G,B,A,
+// NUM_FORMAT = UNORM (0), DATA_FORMAT = 8_8_8_8 (10).  Offsets >= bytes (so also "negative" offsets,
+// which wrap to >= 2^31) are out of range and load (0,0,0,0): oracle choice (5) for rows above/below
+// the image.  The four dwords are made wave-uniform for the SGPR operand.
+__device__ __forceinline__ i32x4 make_rgba8_rsrc(const void *base, uint32_t bytes) {
+    const uint64_t b = (uint64_t)base;
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+    r.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(b >> 32) & 0xffffu));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = __builtin_amdgcn_readfirstlane((int)(4u | (5u << 3) | (6u << 6) | (7u << 9) | (0u << 12) | (10u << 15)));
+    return r;
+}
+
+// Load RGBA8 texels at byte offsets `o*` as float4 each.  Issue and wait live in ONE asm statement:
+// the outputs are only defined once the statement ends, so the compiler can never copy or spill a
+// register that a load is still writing (it does not track these loads).
+#define LFG_TBUF "tbuffer_load_format_xyzw %0, %1, %2, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen"
+__device__ __forceinline__ void load_rgba8_unorm_x3(f32x4 &a, f32x4 &b, f32x4 &c, int oa, int ob, int oc, i32x4 rsrc) {
+    asm volatile(
+        "tbuffer_load_format_xyzw %0, %3, %6, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
+        "tbuffer_load_format_xyzw %1, %4, %6, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
+        "tbuffer_load_format_xyzw %2, %5, %6, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(oa), "v"(ob), "v"(oc), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ void load_rgba8_unorm_x4(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d,
+                                                    int oa, int ob, int oc, int od, i32x4 rsrc) {
+    asm volatile(
+        "tbuffer_load_format_xyzw %0, %4, %8, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
+        "tbuffer_load_format_xyzw %1, %5, %8, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
+        "tbuffer_load_format_xyzw %2, %6, %8, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
+        "tbuffer_load_format_xyzw %3, %7, %8, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(oa), "v"(ob), "v"(oc), "v"(od), "s"(rsrc) : "memory");
+}
+#undef LFG_TBUF
 
 // Orders this wave's LDS traffic for cross-lane exchange inside ONE wave: a wavefront-scope fence
 // keeps the compiler from moving a lane's LDS reads above its own LDS write (they never alias for

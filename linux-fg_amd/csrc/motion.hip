@@ -15,10 +15,14 @@
 // Roofline: fp32 VALU, not HBM: 64 dependent-order adds per (pixel, candidate) plus one
 // correctly rounded distance per (position, candidate); HBM traffic is 10 B/pixel.
 //
-// motion_tiled_8_16_kernel (B = 8, R = 16): a 256-thread workgroup owns a 64x32 pixel tile.
-//   LDS: prev tile with halo as packed RGBA8 (103 x 71 px), and a double-buffered plane
-//   D[39][72] of distances for ONE candidate over the tile plus its block halo.
-//   Per candidate k:   phase A  every thread computes ~11 entries of D_{k+1} (its curr texels stay in
+// motion_tiled_8_16_kernel (B = 8, R = 16): a 512-thread workgroup owns a 64x64 pixel tile.
+//   Texels come in through TYPED buffer loads (tbuffer_load_format_xyzw, RGBA8 UNORM): the
+//   texture-address unit returns four floats that are bit-exact byte/255.0f (tools/probe_unorm.hip),
+//   so UNORM conversion costs no VALU work, and rows outside the image load zeros by the buffer's own
+//   range check.  prev is read straight from L1/L2 (the tile's search window is ~42 KB, re-read by
+//   every candidate); LDS holds only a double-buffered plane D[71][72] of distances for ONE candidate
+//   over the tile plus its block halo (41 KB: two workgroups per CU, 4 waves/SIMD).
+//   Per candidate k:   phase A  every thread computes ~10 entries of D_{k+1} (its curr texels stay in
 //                               registers as floats for the whole kernel)
 //                      phase B  every thread owns 8 horizontally adjacent pixels of one row and runs
 //                               their 8 chains over D_k: 8 rows x 15 floats from LDS, 512 adds
@@ -30,79 +34,115 @@
 
 namespace lfg {
 
-// distance() of two texels given as packed RGBA8, oracle choices (1) and (7):
-// sqrt(((dx*dx + dy*dy) + dz*dz) + dw*dw) with dx = a.x/255 - b.x/255, correctly rounded sqrt.
-__device__ __forceinline__ float dist_f(float cx, float cy, float cz, float cw, uint32_t p) {
-    const float dx = cx - unorm8_to_float(byte0(p));
-    const float dy = cy - unorm8_to_float(byte1(p));
-    const float dz = cz - unorm8_to_float(byte2(p));
-    const float dw = cw - unorm8_to_float(byte3(p));
-    return __builtin_sqrtf(((dx * dx + dy * dy) + dz * dz) + dw * dw);
+// Correctly rounded sqrtf for x = 0 or normal x (here x is a sum of four squares in [0, 4]).
+// v_sqrt_f32 is within 1 ulp; the two FMA residuals against the neighbouring floats decide whether
+// to step down or up (the same fix-up LLVM emits for IEEE sqrt, minus its denormal scaling, which
+// this input range never needs).  ~12 VALU-op equivalents instead of ~23 for __builtin_sqrtf
+// (tools/microbench.hip).  Checked against __builtin_sqrtf for every float in [2^-20, 8] and 0 by
+// lfg_selftest_sqrt (tests/test_gpu_parity.py::test_exact_sqrt_exhaustive).
+__device__ __forceinline__ float exact_sqrt(float x) {
+    float y = __builtin_amdgcn_sqrtf(x);
+    const float ydn = __builtin_bit_cast(float, __builtin_bit_cast(int, y) - 1);
+    const float yup = __builtin_bit_cast(float, __builtin_bit_cast(int, y) + 1);
+    const float rdn = __builtin_fmaf(-ydn, y, x);
+    const float rup = __builtin_fmaf(-yup, y, x);
+    y = (rdn <= 0.0f) ? ydn : y;
+    y = (rup > 0.0f) ? yup : y;
+    return y;
+}
+
+// distance() of two texels already converted to float, oracle choice (7):
+// sqrt(((dx*dx + dy*dy) + dz*dz) + dw*dw), correctly rounded sqrt.
+template <bool FAST_SQRT>
+__device__ __forceinline__ float dist4(const float (&c)[4], f32x4 p) {
+    const float dx = c[0] - p.x, dy = c[1] - p.y, dz = c[2] - p.z, dw = c[3] - p.w;
+    const float s = ((dx * dx + dy * dy) + dz * dz) + dw * dw;
+    return FAST_SQRT ? exact_sqrt(s) : __builtin_sqrtf(s);
 }
 
 // ------------------------------------------------------------------------------ tiled, B = 8, R = 16
 
 constexpr int kB = 8, kR = 16;
-constexpr int kTW = 64, kTH = 32;                 // pixel tile
+constexpr int kTW = 64, kTH = 64;                 // pixel tile
+constexpr int kNT = 512;                          // threads per workgroup: one per 8x1 pixel patch
 constexpr int kDW = kTW + kB - 1;                 // 71 block positions across
-constexpr int kDH = kTH + kB - 1;                 // 39 down
+constexpr int kDH = kTH + kB - 1;                 // 71 down
 constexpr int kDP = 72;                           // D row pitch (floats)
-constexpr int kPW = kDW + 2 * kR;                 // 103 prev columns
-constexpr int kPH = kDH + 2 * kR;                 // 71 prev rows
-constexpr int kPP = 104;                          // prev row pitch (pixels)
-constexpr int kPos = (kDP * kDH + 255) / 256;     // D entries per thread (11)
-constexpr int kCand = (2 * kR + 1) * (2 * kR + 1);
+constexpr int kPos = (kDP * kDH + kNT - 1) / kNT; // D entries per thread (10)
+constexpr int kSide = 2 * kR + 1;
+constexpr int kCand = kSide * kSide;
+static_assert(kTW / 8 * kTH == kNT, "one thread per 8x1 pixel patch");
+static_assert(kPos == 10, "wait_loads() lists ten registers");
 
-__global__ __launch_bounds__(256) void motion_tiled_8_16_kernel(
+__global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int8_t *__restrict__ mv, int mvPitch, int W, int H) {
-    __shared__ uint32_t sPrev[kPH * kPP];                              // 29.5 KB
-    __shared__ __attribute__((aligned(16))) float sD[2][kDH * kDP];    // 22.5 KB
+    __shared__ __attribute__((aligned(16))) float sD[2][kDH * kDP];    // 2 x 20.4 KB
 
     const int tid = threadIdx.x;
     const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * kTH;         // tile origin (pixels)
     const int bx0 = tx0 - kB / 2, by0 = ty0 - kB / 2;                 // image coords of D(0,0)
+    const i32x4 rPrev = make_rgba8_rsrc(prev, (uint32_t)H * (uint32_t)prevPitch);
+    const i32x4 rCurr = make_rgba8_rsrc(curr, (uint32_t)H * (uint32_t)currPitch);
+    // Tiles whose search window can leave the image sideways need an explicit column test; rows
+    // above/below the image fall out of the buffer range and load zeros by themselves.
+    const bool borderX = __builtin_amdgcn_readfirstlane((bx0 - kR < 0) || (bx0 + kDW - 1 + kR >= W));
 
-    // prev tile: LDS (row j, col i) = prev(bx0 - R + i, by0 - R + j), zero outside the image (choice 5).
-    for (int i = tid; i < kPH * kPP; i += 256) {
-        const int j = i / kPP, c = i - j * kPP;
-        const int gx = bx0 - kR + c, gy = by0 - kR + j;
-        uint32_t v = 0u;
-        if (c < kPW && gx >= 0 && gy >= 0 && gx < W && gy < H)
-            v = *reinterpret_cast<const uint32_t *>(prev + (size_t)gy * (size_t)prevPitch + (size_t)gx * 4u);
-        sPrev[i] = v;
-    }
-
-    // This thread's D entries: linear index e = tid + 256 n  ->  (cy, cx) = (e / 72, e % 72).
+    // This thread's D entries: linear index e = tid + kNT n  ->  (cy, cx) = (e / 72, e % 72).
+    // Entries that are padding or lie outside the image get curr = 0 (out-of-range load) and a prev
+    // offset that stays out of range for every candidate, so their distance is sqrt(0) = 0 with no
+    // per-candidate select.
+    constexpr int kOob = (int)0x80000000;
     float cf[kPos][4];
-    int pbase[kPos];             // LDS index of prev(c + (-R,-R)) for the entry's position c
-    uint32_t valid = 0u;         // bit n: entry n is a real position inside the image
-#pragma unroll
-    for (int n = 0; n < kPos; ++n) {
-        const int e = tid + 256 * n;
-        const int cy = e / kDP, cx = e - cy * kDP;
-        const int gx = bx0 + cx, gy = by0 + cy;
-        const bool ok = (e < kDP * kDH) && (cx < kDW) && gx >= 0 && gy >= 0 && gx < W && gy < H;
-        uint32_t p = 0u;
-        if (ok) p = *reinterpret_cast<const uint32_t *>(curr + (size_t)gy * (size_t)currPitch + (size_t)gx * 4u);
-        cf[n][0] = unorm8_to_float(byte0(p)); cf[n][1] = unorm8_to_float(byte1(p));
-        cf[n][2] = unorm8_to_float(byte2(p)); cf[n][3] = unorm8_to_float(byte3(p));
-        pbase[n] = ok ? (cy * kPP + cx) : 0;
-        if (ok) valid |= (1u << n);
-    }
-    __syncthreads();
-
-    auto phaseA = [&](int cand, float *__restrict__ D) {
-        const int dyi = cand / (2 * kR + 1), dxi = cand - dyi * (2 * kR + 1);
-        const int off = dyi * kPP + dxi;          // (dy + R) rows, (dx + R) columns
+    int pbyte[kPos];             // byte offset of prev(c + (-R,-R)) in the prev frame (may be negative)
+    const int cx0 = tid % kDP;   // cx of entry n is (cx0 + 8 n) mod 72, since kNT mod 72 == 8
+    static_assert(kNT % kDP == 8, "cx recurrence below");
+    {
+        int co[kPos];
 #pragma unroll
         for (int n = 0; n < kPos; ++n) {
-            const int e = tid + 256 * n;
-            if (e < kDP * kDH) {
-                const uint32_t p = sPrev[pbase[n] + off];
-                const float d = dist_f(cf[n][0], cf[n][1], cf[n][2], cf[n][3], p);
-                D[e] = ((valid >> n) & 1u) ? d : 0.0f;
-            }
+            const int e = tid + kNT * n;
+            const int cy = e / kDP, cx = e - cy * kDP;
+            const int gx = bx0 + cx, gy = by0 + cy;
+            const bool ok = (e < kDP * kDH) && (cx < kDW) && gx >= 0 && gy >= 0 && gx < W && gy < H;
+            co[n] = ok ? gy * currPitch + gx * 4 : kOob;
+            pbyte[n] = ok ? (gy - kR) * prevPitch + (gx - kR) * 4 : kOob;
+        }
+        f32x4 c4[kPos];
+        load_rgba8_unorm_x4(c4[0], c4[1], c4[2], c4[3], co[0], co[1], co[2], co[3], rCurr);
+        load_rgba8_unorm_x3(c4[4], c4[5], c4[6], co[4], co[5], co[6], rCurr);
+        load_rgba8_unorm_x3(c4[7], c4[8], c4[9], co[7], co[8], co[9], rCurr);
+#pragma unroll
+        for (int n = 0; n < kPos; ++n) { cf[n][0] = c4[n].x; cf[n][1] = c4[n].y; cf[n][2] = c4[n].z; cf[n][3] = c4[n].w; }
+    }
+
+    // ---- phase A: D(c) = distance(curr(c), prev(c + m)) for one candidate, 0 outside the image.
+    //      Loads go out in batches of 4 + 3 + 3 so that at most 16 registers are in flight.
+    auto phaseA = [&](int cand, float *__restrict__ D) {
+        const int dyi = cand / kSide, dxi = cand - dyi * kSide;       // dy + R, dx + R (wave-uniform)
+        const int candOff = dyi * prevPitch + dxi * 4;
+        auto offset = [&](int n) -> int {
+            if (!borderX) return pbyte[n] + candOff;
+            int cx = cx0 + 8 * n;                                       // < 72 + 72
+            cx = cx >= kDP ? cx - kDP : cx;
+            const bool xin = (unsigned)(bx0 + cx - kR + dxi) < (unsigned)W;
+            return xin ? pbyte[n] + candOff : kOob;
+        };
+        auto store = [&](int n, f32x4 p) {
+            const int e = tid + kNT * n;
+            if (e < kDP * kDH) D[e] = dist4<true>(cf[n], p);
+        };
+        {
+            f32x4 p0, p1, p2, p3;
+            load_rgba8_unorm_x4(p0, p1, p2, p3, offset(0), offset(1), offset(2), offset(3), rPrev);
+            store(0, p0); store(1, p1); store(2, p2); store(3, p3);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int n0 = 4 + 3 * h;
+            f32x4 p0, p1, p2;
+            load_rgba8_unorm_x3(p0, p1, p2, offset(n0), offset(n0 + 1), offset(n0 + 2), rPrev);
+            store(n0, p0); store(n0 + 1, p1); store(n0 + 2, p2);
         }
     };
 
@@ -117,16 +157,23 @@ __global__ __launch_bounds__(256) void motion_tiled_8_16_kernel(
     __syncthreads();
 
     for (int cand = 0; cand < kCand; ++cand) {
-        if (cand + 1 < kCand) phaseA(cand + 1, sD[(cand + 1) & 1]);
+        phaseA(cand + 1, sD[(cand + 1) & 1]);   // cand + 1 == kCand reads past the last row: zeros, never used
+        __builtin_amdgcn_sched_barrier(0);       // keep phase A's loaded texels out of phase B's live range
 
-        const float *__restrict__ D = sD[cand & 1];
+        // ---- phase B: the 8 sequential chains of this thread's pixels, block rows top to bottom,
+        //      block columns left to right -- the literal order of motion.comp:33-47.
+        const f32x4 *rowp = reinterpret_cast<const f32x4 *>(sD[cand & 1] + ry * kDP + rxq * 8);
         float acc[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
+        // One block row per step: four 16-byte LDS reads (15 of the 16 floats are used), then its 64
+        // adds.  The scheduling barrier keeps the compiler from hoisting all eight rows' reads
+        // (register pressure: 3 instead of 4 waves/SIMD) or splitting them into dword reads; the other
+        // waves on the SIMD cover the LDS latency.
 #pragma unroll
         for (int y = 0; y < kB; ++y) {
-            const float4 *row = reinterpret_cast<const float4 *>(D + (ry + y) * kDP + rxq * 8);
-            const float4 q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3];
+            const f32x4 *r = rowp + y * (kDP / 4);
+            const f32x4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
             const float e[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
                                  q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
 #pragma unroll
@@ -134,6 +181,7 @@ __global__ __launch_bounds__(256) void motion_tiled_8_16_kernel(
 #pragma unroll
                 for (int i = 0; i < 8; ++i) acc[i] += e[i + x];       // pixel i, block column x
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -147,7 +195,7 @@ __global__ __launch_bounds__(256) void motion_tiled_8_16_kernel(
         int8_t o[16];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int dyi = bestCand[i] / (2 * kR + 1), dxi = bestCand[i] - dyi * (2 * kR + 1);
+            const int dyi = bestCand[i] / kSide, dxi = bestCand[i] - dyi * kSide;
             o[2 * i] = (int8_t)(dxi - kR);
             o[2 * i + 1] = (int8_t)(dyi - kR);
         }
@@ -168,9 +216,27 @@ __global__ __launch_bounds__(256) void motion_tiled_8_16_kernel(
 hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                     const lfg_frame &mv) {
     dim3 grid((curr.width + kTW - 1) / kTW, (curr.height + kTH - 1) / kTH);
-    hipLaunchKernelGGL(motion_tiled_8_16_kernel, grid, dim3(256), 0, s,
+    hipLaunchKernelGGL(motion_tiled_8_16_kernel, grid, dim3(kNT), 0, s,
                        (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
                        (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height);
+    return hipGetLastError();
+}
+
+// Diagnostic: compares exact_sqrt with __builtin_sqrtf for every float whose bit pattern lies in
+// [lo_bits, hi_bits]; counts mismatches.  Used only by the test-suite (lfg_selftest_sqrt).
+__global__ __launch_bounds__(256) void sqrt_selftest_kernel(uint32_t lo, uint32_t hi, unsigned long long *mismatch) {
+    const unsigned long long span = (unsigned long long)hi - lo + 1ull;
+    unsigned long long bad = 0;
+    for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < span; i += (unsigned long long)gridDim.x * 256ull) {
+        const float x = __builtin_bit_cast(float, (uint32_t)(lo + i));
+        const float a = exact_sqrt(x), b = __builtin_sqrtf(x);
+        if (__builtin_bit_cast(uint32_t, a) != __builtin_bit_cast(uint32_t, b)) ++bad;
+    }
+    if (bad) atomicAdd(mismatch, bad);
+}
+
+hipError_t launch_sqrt_selftest(hipStream_t s, uint32_t lo, uint32_t hi, unsigned long long *d_mismatch) {
+    hipLaunchKernelGGL(sqrt_selftest_kernel, dim3(4096), dim3(256), 0, s, lo, hi, d_mismatch);
     return hipGetLastError();
 }
 
@@ -199,8 +265,11 @@ __global__ __launch_bounds__(256) void motion_generic_kernel(
                     uint32_t p = 0u;
                     if (qx >= 0 && qy >= 0 && qx < W && qy < H)
                         p = *reinterpret_cast<const uint32_t *>(prev + (size_t)qy * (size_t)prevPitch + (size_t)qx * 4u);
-                    diff += dist_f(unorm8_to_float(byte0(c)), unorm8_to_float(byte1(c)),
-                                   unorm8_to_float(byte2(c)), unorm8_to_float(byte3(c)), p);
+                    const float cc[4] = {unorm8_to_float(byte0(c)), unorm8_to_float(byte1(c)),
+                                         unorm8_to_float(byte2(c)), unorm8_to_float(byte3(c))};
+                    const f32x4 pp = {unorm8_to_float(byte0(p)), unorm8_to_float(byte1(p)),
+                                      unorm8_to_float(byte2(p)), unorm8_to_float(byte3(p))};
+                    diff += dist4<false>(cc, pp);
                 }
             }
             if (diff < minDiff) { minDiff = diff; bx = dx; by = dy; }

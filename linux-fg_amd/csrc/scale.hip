@@ -21,6 +21,8 @@
 //                        independent, LDS is only the cross-lane exchange for the horizontal taps.
 //   scale_generic_kernel any sizes (down-scaling included): one thread per output pixel, 36
 //                        table-weighted texel reads through L1/L2.
+#include <cstdlib>
+
 #include "lfg_device.hpp"
 #include "lfg_internal.hpp"
 
@@ -131,19 +133,23 @@ __global__ __launch_bounds__(256) void scale_2x_kernel(
 #pragma unroll
     for (int u = 0; u < 6; ++u) { win[u][0] = F4{0, 0, 0, 0}; win[u][1] = F4{0, 0, 0, 0}; }
 
-    uint32_t pa, pb;
+    // Software pipeline over rows: six row loads are always in flight per wave (the row for step r+6
+    // is requested as soon as step r has consumed its registers), so HBM/L2 latency is paid once per
+    // wave instead of once per row.
     const int rFirst = rBegin - 5;
-    load_row(rFirst, pa, pb);
+    uint32_t pa[6], pb[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) load_row(rFirst + u, pa[u], pb[u]);
 
     for (int rb = rFirst; rb < rEnd; rb += 6) {
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
             const int r = rb + u;
             if (r < rEnd) {
-                // 1. this row's pixels -> LDS as floats (0..255 scale); prefetch the next row.
-                buf[lane] = unpack255(pa);
-                if (lane < kRowBuf - 64) buf[64 + lane] = unpack255(pb);
-                load_row(r + 1, pa, pb);
+                // 1. this row's pixels -> LDS as floats (0..255 scale).
+                buf[lane] = unpack255(pa[u]);
+                if (lane < kRowBuf - 64) buf[64 + lane] = unpack255(pb[u]);
+                load_row(r + 6, pa[u], pb[u]);
                 wave_lds_sync();
                 // 2. the lane's 7 horizontal neighbours (input columns k-3 .. k+3).
                 F4 t[7];
@@ -191,11 +197,20 @@ __global__ __launch_bounds__(256) void scale_2x_kernel(
     }
 }
 
+static int scale2x_steps_per_strip() {
+    static int v = [] {
+        const char *e = getenv("LFG_SCALE_STEPS");       // tuning knob for experiments only
+        int n = e ? atoi(e) : 0;
+        return (n >= 1 && n <= 4096) ? n : 8;
+    }();
+    return v;
+}
+
 hipError_t launch_scale_2x(hipStream_t s, const lfg_frame &in, const lfg_frame &out,
                            const AxisTable &tx, const AxisTable &ty) {
     const int colGroups = ((int)in.width + kStripCols - 1) / kStripCols;
     const int totalSteps = (int)in.height + 1;            // steps r = 2 .. inH + 2
-    const int stepsPerStrip = 24;
+    const int stepsPerStrip = scale2x_steps_per_strip();
     const int strips = (totalSteps + stepsPerStrip - 1) / stepsPerStrip;
     const int waves = colGroups * strips;
     dim3 grid((waves + 3) / 4);

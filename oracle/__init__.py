@@ -51,7 +51,9 @@ def lib() -> ctypes.CDLL:
 
 
 def default_threads() -> int:
-    return max(1, len(os.sched_getaffinity(0)))
+    """Host threads for the oracle: the affinity mask, capped at 16 (a one-GPU box's CPU share)."""
+    cap = int(os.environ.get("LFG_ORACLE_THREADS", "16"))
+    return max(1, min(cap, len(os.sched_getaffinity(0))))
 
 
 def _frame(a: np.ndarray, name: str) -> np.ndarray:

@@ -179,6 +179,32 @@ def test_motion_4k_translation_property(ctx, oracle):
         assert (got[y0:y1, x0:x1] == want[y0:y1, x0:x1]).all(), roi
 
 
+def test_exact_sqrt_exhaustive(ctx):
+    """csrc/motion.hip: exact_sqrt (v_sqrt_f32 + two-FMA fix-up) against the compiler's IEEE sqrtf for
+    every float from 2^-21 to 8 (the motion kernel feeds it sums of four squares in [0, 4], the
+    smallest non-zero one being (1/255)^2 ~ 1.5e-5) and for 0."""
+    lo = int(np.float32(2.0 ** -21).view(np.uint32))
+    hi = int(np.float32(8.0).view(np.uint32))
+    assert ctx.selftest_sqrt(lo, hi) == 0
+    assert ctx.selftest_sqrt(0, 0) == 0
+
+
+def test_device_sqrt_and_unorm_match_host(ctx, oracle):
+    """The compiler's device sqrtf / the 1/255 form against the host's: a frame pair whose distances
+    cover many distinct sums of squares, through the generic (literal) kernel with a 1x1 block and
+    zero radius -- the cost is a single distance, so equal MVs say nothing; instead use two
+    candidates' ordering: covered by the full parity tests above.  Here: every byte pair once."""
+    a = np.arange(256, dtype=np.uint8)
+    prev = np.zeros((16, 256, 4), np.uint8)
+    curr = np.zeros((16, 256, 4), np.uint8)
+    for r in range(16):
+        prev[r, :, 0] = a; prev[r, :, 1] = np.roll(a, 17 * r); prev[r, :, 2] = a[::-1]; prev[r, :, 3] = np.roll(a, 5 * r + 1)
+        curr[r, :, 0] = np.roll(a, 3 * r + 1); curr[r, :, 1] = a; curr[r, :, 2] = np.roll(a, 7 * r); curr[r, :, 3] = a[::-1]
+    got = run_motion(ctx, prev, curr, 3, 5.0)
+    want = as_int(oracle.motion(prev, curr, 3, 5.0))
+    assert (got == want).all()
+
+
 # ------------------------------------------------------------------------------ interpolate
 
 @pytest.mark.parametrize("t", [0.25, 0.5, 0.75, 0.3])

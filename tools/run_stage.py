@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Run one stage of the hot path a few times on cuda:0 (for rocprofv3 --pmc / --kernel-trace runs).
+usage: run_stage.py {scale|motion|interpolate|pipeline} [reps] [content]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+from linux_fg_amd import capi, synth  # noqa: E402
+
+stage = sys.argv[1] if len(sys.argv) > 1 else "pipeline"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+content = sys.argv[3] if len(sys.argv) > 3 else "translated"
+w, h = 1920, 1080
+W, H = 2 * w, 2 * h
+ctx = capi.Context(0)
+prev_in = synth.make_prev(w, h, synth.BASE_SEED)
+curr_in = synth.translate(prev_in, (3, -2), synth.BASE_SEED) if content == "translated" else synth.noise_bytes(w, h, 12345)
+p_in, c_in = ctx.frame_from(prev_in), ctx.frame_from(curr_in)
+P, C, O = ctx.create_frame(W, H), ctx.create_frame(W, H), ctx.create_frame(W, H)
+M = ctx.create_frame(W, H, capi.FORMAT_MV_S8X2)
+ctx.scale(p_in, P)
+ctx.scale(c_in, C)
+ctx.motion(P, C, M) if stage in ("interpolate",) else None
+ctx.sync()
+for _ in range(reps):
+    if stage in ("scale", "pipeline"):
+        ctx.scale(c_in, C)
+    if stage in ("motion", "pipeline"):
+        ctx.motion(P, C, M)
+    if stage in ("interpolate", "pipeline"):
+        ctx.interpolate(P, C, M, O, 0.5)
+ctx.sync()
+print("done", stage, reps)
