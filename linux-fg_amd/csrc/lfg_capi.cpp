@@ -362,7 +362,7 @@ LFG_EXPORT int lfg_scale(lfg_context *ctx, const lfg_frame *in, lfg_frame *out) 
     if (rc != LFG_OK) return rc;
     rc = build_axis_table(ctx, (int)in->height, (int)out->height, &ty);
     if (rc != LFG_OK) return rc;
-    const bool fast = tx->pattern_2x && ty->pattern_2x && (in->pitch % 4u == 0) && (out->pitch % 8u == 0) &&
+    const bool fast = tx->pattern_2x && ty->pattern_2x && lfg::scale_2x_supported(*in, *out) && (in->pitch % 4u == 0) && (out->pitch % 8u == 0) &&
                       ((uintptr_t)out->data % 8u == 0) && ((uintptr_t)in->data % 4u == 0);
     StageTimer timer(ctx, LFG_STAGE_SCALE);
     hipError_t e = fast ? lfg::launch_scale_2x(ctx->stream, *in, *out, *tx, *ty)

@@ -54,6 +54,7 @@ hipError_t launch_scale_generic(hipStream_t s, const lfg_frame &in, const lfg_fr
                                 const AxisTable &tx, const AxisTable &ty);
 hipError_t launch_scale_2x(hipStream_t s, const lfg_frame &in, const lfg_frame &out,
                            const AxisTable &tx, const AxisTable &ty);
+bool scale_2x_supported(const lfg_frame &in, const lfg_frame &out);
 hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                     const lfg_frame &mv);
 hipError_t launch_motion_generic(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,

@@ -21,7 +21,7 @@
 //                        independent, LDS is only the cross-lane exchange for the horizontal taps.
 //   scale_generic_kernel any sizes (down-scaling included): one thread per output pixel, 36
 //                        table-weighted texel reads through L1/L2.
-#include <cstdlib>
+#include <cstdio>
 
 #include "lfg_device.hpp"
 #include "lfg_internal.hpp"
@@ -80,22 +80,45 @@ hipError_t launch_scale_generic(hipStream_t s, const lfg_frame &in, const lfg_fr
 
 constexpr int kStripCols = 64;      // input columns per wave (one per lane)
 constexpr int kRowBuf = 72;         // 64 + 3 left + 3 right halo, rounded up to 72 float4
+constexpr int kOobOffset = (int)0x80000000;   // buffer offset that always fails the range check
+#ifndef LFG_STORE_AUX
+#define LFG_STORE_AUX 2
+#endif
+constexpr int kStoreAux = LFG_STORE_AUX;      // gfx940+ cache policy bits: 1 = sc0, 2 = nt, 16 = sc1
 
 struct F4 { float x, y, z, w; };
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ F4 unpack255(uint32_t p) { return F4{byte0(p), byte1(p), byte2(p), byte3(p)}; }
 
 // At exact 2x, output columns 2k and 2k+1 (lane = input column k) read input columns k-3..k+2 and
 // k-2..k+3; output rows 2r-5 and 2r-4 both read input rows r-5..r (host-verified: AxisTable::pattern_2x).
 // Step r therefore loads input row r, forms the two horizontal sums, and emits those two output rows
-// from the six most recent horizontal rows.  Strip `st` runs steps [2 + st*stepsPerStrip, ...), after
-// five warm-up steps that refill the window.
-__global__ __launch_bounds__(256) void scale_2x_kernel(
+// from the six most recent horizontal rows.  A wave runs STEPS emitting steps after five warm-up
+// steps that fill the window.
+//
+// The whole strip is unrolled and BRANCH-FREE: every load and store is a raw buffer access whose
+// offset is pushed out of range when it must not happen (lanes past the right edge, rows outside
+// the image; the hardware drops out-of-range stores and returns 0 for loads).  Straight-line code
+// lets the compiler count outstanding memory operations exactly, so each step waits only for the
+// row it consumes (prefetched six steps earlier) instead of draining loads AND stores at every loop
+// back-edge, which is what made the looped version latency-bound.
+template <int STEPS>
+__global__ __launch_bounds__(256, 3) void scale_2x_kernel(
     const uint8_t *__restrict__ in, int inW, int inH, int inPitch,
     uint8_t *__restrict__ out, int outW, int outH, int outPitch,
     const float *__restrict__ weightX, const float *__restrict__ weightY,
-    int colGroups, int strips, int stepsPerStrip) {
+    int colGroups, int strips
+#ifdef LFG_DIAG_STAMPS
+    , unsigned long long *stamps     // diagnostic build only: per-wave {start, after prologue, end} s_memrealtime
+#endif
+    ) {
+    constexpr int T = STEPS + 5;
+#ifdef LFG_DIAG_STAMPS
+    const unsigned long long tStart = __builtin_amdgcn_s_memrealtime();
+#endif
     __shared__ __attribute__((aligned(16))) F4 rowbuf[4][kRowBuf];
+    __shared__ __attribute__((aligned(16))) float wyS[4][STEPS * 2 * 6];
 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -104,120 +127,187 @@ __global__ __launch_bounds__(256) void scale_2x_kernel(
     const int cg = gw % colGroups, st = gw / colGroups;
     const int icx0 = cg * kStripCols;
     const int k = icx0 + lane;                            // this lane's input column
-    const int rEnd = min(2 + (st + 1) * stepsPerStrip, inH + 3);
-    const int rBegin = 2 + st * stepsPerStrip;            // first emitting step
-    F4 *buf = rowbuf[wv];
-
-    // Horizontal weights of the lane's two output columns (clamped for lanes past the right edge;
-    // those lanes never store).
-    const int kc = min(k, inW - 1);
-    float wa[6], wb[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        wa[j] = weightX[(2 * kc) * 6 + j];
-        wb[j] = weightX[(2 * kc + 1) * 6 + j];
-    }
-
-    // Column this lane loads into the row buffer: buffer slot i holds input column icx0 - 3 + i.
-    const int colA = clampi(icx0 - 3 + lane, 0, inW - 1);
-    const int colB = clampi(icx0 - 3 + 64 + lane, 0, inW - 1);    // lanes 0..7 only
-    auto load_row = [&](int r, uint32_t &pa, uint32_t &pb) {
-        const int rr = clampi(r, 0, inH - 1);
-        const uint8_t *row = in + (size_t)rr * (size_t)inPitch;
-        pa = *reinterpret_cast<const uint32_t *>(row + (size_t)colA * 4u);
-        pb = 0u;
-        if (lane < kRowBuf - 64) pb = *reinterpret_cast<const uint32_t *>(row + (size_t)colB * 4u);
-    };
-
-    F4 win[6][2];
-#pragma unroll
-    for (int u = 0; u < 6; ++u) { win[u][0] = F4{0, 0, 0, 0}; win[u][1] = F4{0, 0, 0, 0}; }
-
-    // Software pipeline over rows: six row loads are always in flight per wave (the row for step r+6
-    // is requested as soon as step r has consumed its registers), so HBM/L2 latency is paid once per
-    // wave instead of once per row.
+    // Emitting steps r = rBegin .. rBegin+STEPS-1 out of 2 .. inH+2; the last strip is shifted up
+    // to full length (it re-emits a few rows of its neighbour with identical values).
+    const int rBegin = min(2 + st * STEPS, inH + 3 - STEPS);
     const int rFirst = rBegin - 5;
-    uint32_t pa[6], pb[6];
-#pragma unroll
-    for (int u = 0; u < 6; ++u) load_row(rFirst + u, pa[u], pb[u]);
+    F4 *buf = rowbuf[wv];
+    float *wys = wyS[wv];
 
-    for (int rb = rFirst; rb < rEnd; rb += 6) {
+    const __amdgpu_buffer_rsrc_t rIn = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(in), 0, inH * inPitch, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rOut = __builtin_amdgcn_make_buffer_rsrc(out, 0, outH * outPitch, 0x00020000);
+
+    // Vertical weights of the strip's 2*STEPS output rows -> wave-private LDS once; the steps read them
+    // with broadcast LDS reads (a scalar load per output row would sit on the critical path).
+    {
+        const int oyFirst = 2 * rBegin - 5;
 #pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            const int r = rb + u;
-            if (r < rEnd) {
-                // 1. this row's pixels -> LDS as floats (0..255 scale).
-                buf[lane] = unpack255(pa[u]);
-                if (lane < kRowBuf - 64) buf[64 + lane] = unpack255(pb[u]);
-                load_row(r + 6, pa[u], pb[u]);
-                wave_lds_sync();
-                // 2. the lane's 7 horizontal neighbours (input columns k-3 .. k+3).
-                F4 t[7];
-#pragma unroll
-                for (int j = 0; j < 7; ++j) t[j] = buf[lane + j];
-                wave_lds_sync();
-                F4 h0{0, 0, 0, 0}, h1{0, 0, 0, 0};
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    h0.x = __builtin_fmaf(wa[j], t[j].x, h0.x); h0.y = __builtin_fmaf(wa[j], t[j].y, h0.y);
-                    h0.z = __builtin_fmaf(wa[j], t[j].z, h0.z); h0.w = __builtin_fmaf(wa[j], t[j].w, h0.w);
-                    h1.x = __builtin_fmaf(wb[j], t[j + 1].x, h1.x); h1.y = __builtin_fmaf(wb[j], t[j + 1].y, h1.y);
-                    h1.z = __builtin_fmaf(wb[j], t[j + 1].z, h1.z); h1.w = __builtin_fmaf(wb[j], t[j + 1].w, h1.w);
-                }
-                win[u][0] = h0; win[u][1] = h1;
-                // 3. emit output rows 2r-5 and 2r-4 from window rows r-5..r = slots (u+1+j)%6.
-                if (r >= rBegin) {
-#pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        const int oy = 2 * r - 5 + half;              // wave-uniform
-                        if (oy >= 0 && oy < outH) {
-                            const float *wy = weightY + (size_t)oy * 6u;
-                            F4 o0{0, 0, 0, 0}, o1{0, 0, 0, 0};
-#pragma unroll
-                            for (int j = 0; j < 6; ++j) {
-                                const float w = wy[j];
-                                const F4 &a = win[(u + 1 + j) % 6][0];
-                                const F4 &b = win[(u + 1 + j) % 6][1];
-                                o0.x = __builtin_fmaf(w, a.x, o0.x); o0.y = __builtin_fmaf(w, a.y, o0.y);
-                                o0.z = __builtin_fmaf(w, a.z, o0.z); o0.w = __builtin_fmaf(w, a.w, o0.w);
-                                o1.x = __builtin_fmaf(w, b.x, o1.x); o1.y = __builtin_fmaf(w, b.y, o1.y);
-                                o1.z = __builtin_fmaf(w, b.z, o1.z); o1.w = __builtin_fmaf(w, b.w, o1.w);
-                            }
-                            if (k < inW) {
-                                uint2 px;
-                                px.x = pack_rgba8_255(o0.x, o0.y, o0.z, o0.w);
-                                px.y = pack_rgba8_255(o1.x, o1.y, o1.z, o1.w);
-                                *reinterpret_cast<uint2 *>(out + (size_t)oy * (size_t)outPitch + (size_t)k * 8u) = px;
-                            }
-                        }
-                    }
-                }
-            }
+        for (int i0 = 0; i0 < STEPS * 12; i0 += 64) {
+            const int i = i0 + lane;
+            const int oy = oyFirst + i / 6;
+            if (i < STEPS * 12)
+                wys[i] = (oy >= 0 && oy < outH) ? weightY[(size_t)oy * 6u + (size_t)(i % 6)] : 0.0f;
         }
     }
+
+    // Horizontal weights of the lane's two output columns: 12 consecutive floats, three 16-byte loads
+    // (clamped for lanes past the right edge; those lanes never store).
+    const int kc = min(k, inW - 1);
+    float wa[6], wb[6];
+    {
+        const float4 *wp = reinterpret_cast<const float4 *>(weightX + (size_t)(2 * kc) * 6u);
+        const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2];
+        wa[0] = w0.x; wa[1] = w0.y; wa[2] = w0.z; wa[3] = w0.w; wa[4] = w1.x; wa[5] = w1.y;
+        wb[0] = w1.z; wb[1] = w1.w; wb[2] = w2.x; wb[3] = w2.y; wb[4] = w2.z; wb[5] = w2.w;
+    }
+
+    // Row-buffer slot i holds input column icx0 - 3 + i: every lane loads slot `lane`, lanes 0..7 also
+    // slot 64 + lane (the other lanes' second load is out of range and returns 0).
+    const int offA = clampi(icx0 - 3 + lane, 0, inW - 1) * 4;
+    const int offB = lane < kRowBuf - 64 ? clampi(icx0 - 3 + 64 + lane, 0, inW - 1) * 4 : kOobOffset;
+    // Store offsets of the lane pair (2j, 2j+1): the even lane writes 16 bytes of the upper output row
+    // of a step at column 4j, the odd lane 16 bytes of the lower row at the same column.  The scalar
+    // part of the address is the upper row's offset.
+    const bool odd = (lane & 1) != 0;
+    const int offLane = k < inW ? (odd ? (k - 1) * 8 + outPitch : k * 8) : kOobOffset;
+    auto load_row = [&](int r, uint32_t &pa, uint32_t &pb) {
+        const int rowOff = clampi(r, 0, inH - 1) * inPitch;              // wave-uniform
+        pa = __builtin_amdgcn_raw_buffer_load_b32(rIn, offA, rowOff, 0);
+        pb = __builtin_amdgcn_raw_buffer_load_b32(rIn, offB, rowOff, 0);
+    };
+
+    constexpr int kAhead = 3;                              // rows in flight per wave
+#ifdef LFG_DIAG_STAMPS
+    const unsigned long long tPro = __builtin_amdgcn_s_memrealtime();
+#endif
+    F4 win[6][2];
+    uint32_t pa[kAhead], pb[kAhead];
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) load_row(rFirst + u, pa[u], pb[u]);
+
+#pragma unroll
+    for (int s = 0; s < T; ++s) {
+        const int r = rFirst + s;
+        const int u = s % 6;                               // window slot of this step
+        // 1. this row's pixels -> LDS as floats (0..255 scale); request the row kAhead steps ahead.
+        const int v = s % kAhead;
+        buf[lane] = unpack255(pa[v]);
+        if (lane < kRowBuf - 64) buf[64 + lane] = unpack255(pb[v]);
+        if (s + kAhead < T) load_row(r + kAhead, pa[v], pb[v]);
+        wave_lds_sync();
+        // 2. the lane's 7 horizontal neighbours (input columns k-3 .. k+3).
+        F4 t[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) t[j] = buf[lane + j];
+        wave_lds_sync();
+        F4 h0{0, 0, 0, 0}, h1{0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            h0.x = __builtin_fmaf(wa[j], t[j].x, h0.x); h0.y = __builtin_fmaf(wa[j], t[j].y, h0.y);
+            h0.z = __builtin_fmaf(wa[j], t[j].z, h0.z); h0.w = __builtin_fmaf(wa[j], t[j].w, h0.w);
+            h1.x = __builtin_fmaf(wb[j], t[j + 1].x, h1.x); h1.y = __builtin_fmaf(wb[j], t[j + 1].y, h1.y);
+            h1.z = __builtin_fmaf(wb[j], t[j + 1].z, h1.z); h1.w = __builtin_fmaf(wb[j], t[j + 1].w, h1.w);
+        }
+        win[u][0] = h0; win[u][1] = h1;
+        // 3. emit output rows 2r-5 and 2r-4 from window rows r-5..r = slots (u+1+j)%6.
+        if (s >= 5) {
+            uint32_t px[2][2];                                         // [output row half][column]
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const float2 *wyp = reinterpret_cast<const float2 *>(wys + (2 * (s - 5) + half) * 6);
+                const float2 wy01 = wyp[0], wy23 = wyp[1], wy45 = wyp[2];
+                const float wy[6] = {wy01.x, wy01.y, wy23.x, wy23.y, wy45.x, wy45.y};
+                F4 o0{0, 0, 0, 0}, o1{0, 0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const float w = wy[j];
+                    const F4 &a = win[(u + 1 + j) % 6][0];
+                    const F4 &b = win[(u + 1 + j) % 6][1];
+                    o0.x = __builtin_fmaf(w, a.x, o0.x); o0.y = __builtin_fmaf(w, a.y, o0.y);
+                    o0.z = __builtin_fmaf(w, a.z, o0.z); o0.w = __builtin_fmaf(w, a.w, o0.w);
+                    o1.x = __builtin_fmaf(w, b.x, o1.x); o1.y = __builtin_fmaf(w, b.y, o1.y);
+                    o1.z = __builtin_fmaf(w, b.z, o1.z); o1.w = __builtin_fmaf(w, b.w, o1.w);
+                }
+                px[half][0] = pack_rgba8_255(o0.x, o0.y, o0.z, o0.w);
+                px[half][1] = pack_rgba8_255(o1.x, o1.y, o1.z, o1.w);
+            }
+            // One 16-byte store per lane instead of two 8-byte ones (8-byte-per-lane stores are
+            // issue-bound at ~7 B/clk/CU on gfx950, which capped this kernel at ~7.5 us).  Lanes pair up:
+            // the even lane takes both lanes' pixels of the upper row (4 adjacent columns), the odd
+            // lane both lanes' pixels of the lower row.  The exchange is one DPP quad_perm [1,0,3,2]
+            // (swap neighbours) per dword of the pair each lane gives away.
+            const uint32_t g0 = odd ? px[0][0] : px[1][0], g1 = odd ? px[0][1] : px[1][1];
+            const uint32_t x0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)g0, 0xB1, 0xF, 0xF, false);
+            const uint32_t x1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)g1, 0xB1, 0xF, 0xF, false);
+            u32x4 q;
+            q.x = odd ? x0 : px[0][0]; q.y = odd ? x1 : px[0][1];
+            q.z = odd ? px[1][0] : x0; q.w = odd ? px[1][1] : x1;
+            const int oy0 = 2 * r - 5;                                 // upper row (wave-uniform), >= -1
+            // Only two steps of a frame are special: oy0 == -1 (no upper row; the lower row is row 0, so
+            // the odd lanes drop the extra pitch) and oy0 + 1 == outH (no lower row).
+            const int sub = oy0 < 0 ? outPitch : 0;                    // scalar
+            const bool ok = odd ? (oy0 + 1 < outH) : (oy0 >= 0);
+            const int voff = ok ? offLane - sub : kOobOffset;
+            __builtin_amdgcn_raw_buffer_store_b128(q, rOut, voff, max(oy0, 0) * outPitch, kStoreAux);
+        }
+        __builtin_amdgcn_sched_barrier(0);     // keep each step's registers local
+    }
+#ifdef LFG_DIAG_STAMPS
+    if (stamps && lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamps[(size_t)gw * 4 + 0] = tStart; stamps[(size_t)gw * 4 + 1] = tPro;
+        stamps[(size_t)gw * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+        stamps[(size_t)gw * 4 + 3] = 0;
+    }
+#endif
 }
 
-static int scale2x_steps_per_strip() {
-    static int v = [] {
-        const char *e = getenv("LFG_SCALE_STEPS");       // tuning knob for experiments only
-        int n = e ? atoi(e) : 0;
-        return (n >= 1 && n <= 4096) ? n : 8;
-    }();
-    return v;
+constexpr int kScaleSteps = 11;
+
+#ifdef LFG_DIAG_STAMPS
+// Diagnostic build only (-DLFG_DIAG_STAMPS, never the shipped library): a device buffer for the
+// per-wave time stamps, dumped to $LFG_STAMPS_FILE by lfg_diag_dump_stamps().
+static unsigned long long *g_stamps = nullptr;
+static size_t g_stampWaves = 0;
+static unsigned long long *diag_stamp_buffer(size_t waves) {
+    if (!g_stamps) { (void)hipMalloc((void **)&g_stamps, waves * 4 * sizeof(unsigned long long)); g_stampWaves = waves; }
+    return g_stamps;
+}
+extern "C" __attribute__((visibility("default"))) int lfg_diag_dump_stamps(const char *path) {
+    if (!g_stamps) return -1;
+    std::vector<unsigned long long> h(g_stampWaves * 4);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(h.data(), g_stamps, h.size() * 8, hipMemcpyDeviceToHost);
+    FILE *f = fopen(path, "w");
+    if (!f) return -2;
+    for (size_t i = 0; i < g_stampWaves; ++i) fprintf(f, "%zu %llu %llu %llu\n", i, h[4 * i], h[4 * i + 1], h[4 * i + 2]);
+    fclose(f);
+    return 0;
+}
+#endif
+
+bool scale_2x_supported(const lfg_frame &in, const lfg_frame &out) {
+    return (int)in.height + 1 >= kScaleSteps && in.width % 2u == 0 && out.pitch % 16u == 0 &&
+           (uintptr_t)out.data % 16u == 0 && (uint64_t)in.height * in.pitch < 0x7fffffffull &&
+           (uint64_t)out.height * out.pitch < 0x7fffffffull;
 }
 
 hipError_t launch_scale_2x(hipStream_t s, const lfg_frame &in, const lfg_frame &out,
                            const AxisTable &tx, const AxisTable &ty) {
     const int colGroups = ((int)in.width + kStripCols - 1) / kStripCols;
     const int totalSteps = (int)in.height + 1;            // steps r = 2 .. inH + 2
-    const int stepsPerStrip = scale2x_steps_per_strip();
-    const int strips = (totalSteps + stepsPerStrip - 1) / stepsPerStrip;
+    const int strips = (totalSteps + kScaleSteps - 1) / kScaleSteps;
     const int waves = colGroups * strips;
     dim3 grid((waves + 3) / 4);
-    hipLaunchKernelGGL(scale_2x_kernel, grid, dim3(256), 0, s,
+    hipLaunchKernelGGL(scale_2x_kernel<kScaleSteps>, grid, dim3(256), 0, s,
                        (const uint8_t *)in.data, (int)in.width, (int)in.height, (int)in.pitch,
                        (uint8_t *)out.data, (int)out.width, (int)out.height, (int)out.pitch,
-                       tx.d_weight, ty.d_weight, colGroups, strips, stepsPerStrip);
+                       tx.d_weight, ty.d_weight, colGroups, strips
+#ifdef LFG_DIAG_STAMPS
+                       , diag_stamp_buffer((size_t)waves)
+#endif
+                       );
     return hipGetLastError();
 }
 
