@@ -90,6 +90,28 @@ __device__ __forceinline__ void load_rgba8_unorm_x4(f32x4 &a, f32x4 &b, f32x4 &c
 }
 #undef LFG_TBUF
 
+// Sixteen consecutive floats from LDS as eight ds_read_b64 (never merged into ds_read2_b64 / split into
+// dword reads by the compiler, whose banking differs), issue and wait in one statement.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lds_read_16f_b64(float (&e)[16], const float *lds_ptr) {
+    const uint32_t a = (uint32_t)(uintptr_t)lds_ptr;     // LDS byte address (low 32 bits of the generic pointer)
+    f32x2 q0, q1, q2, q3, q4, q5, q6, q7;
+    asm volatile(
+        "ds_read_b64 %0, %8\n\t"
+        "ds_read_b64 %1, %8 offset:8\n\t"
+        "ds_read_b64 %2, %8 offset:16\n\t"
+        "ds_read_b64 %3, %8 offset:24\n\t"
+        "ds_read_b64 %4, %8 offset:32\n\t"
+        "ds_read_b64 %5, %8 offset:40\n\t"
+        "ds_read_b64 %6, %8 offset:48\n\t"
+        "ds_read_b64 %7, %8 offset:56\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5), "=&v"(q6), "=&v"(q7)
+        : "v"(a) : "memory");
+    e[0] = q0.x; e[1] = q0.y; e[2] = q1.x; e[3] = q1.y; e[4] = q2.x; e[5] = q2.y; e[6] = q3.x; e[7] = q3.y;
+    e[8] = q4.x; e[9] = q4.y; e[10] = q5.x; e[11] = q5.y; e[12] = q6.x; e[13] = q6.y; e[14] = q7.x; e[15] = q7.y;
+}
+
 // Orders this wave's LDS traffic for cross-lane exchange inside ONE wave: a wavefront-scope fence
 // keeps the compiler from moving a lane's LDS reads above its own LDS write (they never alias for
 // the same lane, but they do across lanes); the hardware executes one wave's LDS ops in order.

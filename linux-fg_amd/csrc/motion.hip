@@ -67,7 +67,9 @@ constexpr int kTW = 64, kTH = 64;                 // pixel tile
 constexpr int kNT = 512;                          // threads per workgroup: one per 8x1 pixel patch
 constexpr int kDW = kTW + kB - 1;                 // 71 block positions across
 constexpr int kDH = kTH + kB - 1;                 // 71 down
-constexpr int kDP = 72;                           // D row pitch (floats)
+constexpr int kDP = 72;                           // D entries per row in the thread->entry map
+constexpr int kDS = 74;                           // D row pitch in LDS (floats): 74/2 = 37 = 1 mod 4 makes the
+                                                  // chain phase's ds_read_b64 pattern conflict-free (see phase B)
 constexpr int kPos = (kDP * kDH + kNT - 1) / kNT; // D entries per thread (10)
 constexpr int kSide = 2 * kR + 1;
 constexpr int kCand = kSide * kSide;
@@ -77,7 +79,7 @@ static_assert(kPos == 10, "wait_loads() lists ten registers");
 __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int8_t *__restrict__ mv, int mvPitch, int W, int H) {
-    __shared__ __attribute__((aligned(16))) float sD[2][kDH * kDP];    // 2 x 20.4 KB
+    __shared__ __attribute__((aligned(16))) float sD[2][kDH * kDS];    // 2 x 21 KB
 
     const int tid = threadIdx.x;
     const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * kTH;         // tile origin (pixels)
@@ -95,6 +97,7 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
     constexpr int kOob = (int)0x80000000;
     float cf[kPos][4];
     int pbyte[kPos];             // byte offset of prev(c + (-R,-R)) in the prev frame (may be negative)
+    int daddr[kPos];             // LDS index of the entry: cy * kDS + cx
     const int cx0 = tid % kDP;   // cx of entry n is (cx0 + 8 n) mod 72, since kNT mod 72 == 8
     static_assert(kNT % kDP == 8, "cx recurrence below");
     {
@@ -107,6 +110,7 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
             const bool ok = (e < kDP * kDH) && (cx < kDW) && gx >= 0 && gy >= 0 && gx < W && gy < H;
             co[n] = ok ? gy * currPitch + gx * 4 : kOob;
             pbyte[n] = ok ? (gy - kR) * prevPitch + (gx - kR) * 4 : kOob;
+            daddr[n] = cy * kDS + cx;
         }
         f32x4 c4[kPos];
         load_rgba8_unorm_x4(c4[0], c4[1], c4[2], c4[3], co[0], co[1], co[2], co[3], rCurr);
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
         };
         auto store = [&](int n, f32x4 p) {
             const int e = tid + kNT * n;
-            if (e < kDP * kDH) D[e] = dist4<true>(cf[n], p);
+            if (e < kDP * kDH) D[daddr[n]] = dist4<true>(cf[n], p);
         };
         {
             f32x4 p0, p1, p2, p3;
@@ -162,20 +166,20 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
 
         // ---- phase B: the 8 sequential chains of this thread's pixels, block rows top to bottom,
         //      block columns left to right -- the literal order of motion.comp:33-47.
-        const f32x4 *rowp = reinterpret_cast<const f32x4 *>(sD[cand & 1] + ry * kDP + rxq * 8);
+        const float *rowp = sD[cand & 1] + ry * kDS + rxq * 8;
         float acc[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
-        // One block row per step: four 16-byte LDS reads (15 of the 16 floats are used), then its 64
-        // adds.  The scheduling barrier keeps the compiler from hoisting all eight rows' reads
-        // (register pressure: 3 instead of 4 waves/SIMD) or splitting them into dword reads; the other
-        // waves on the SIMD cover the LDS latency.
+        // One block row per step: eight 8-byte LDS reads (15 of the 16 floats are used), then its 64
+        // adds.  With a 74-float pitch the 32 lanes of a ds_read_b64 group (4 tile rows x 8 patches) hit
+        // 32 distinct 8-byte slots of the 256-byte bank row: (37*row + 4*patch + j) mod 32 is a
+        // bijection, so the reads are conflict-free (16-byte reads on a 72-float pitch were 3-way
+        // conflicted: SQ_LDS_BANK_CONFLICT was 63 % of the LDS cycles, and no pitch fixes that for
+        // ds_read_b128's lane groups).  The other waves on the SIMD cover the LDS latency.
 #pragma unroll
         for (int y = 0; y < kB; ++y) {
-            const f32x4 *r = rowp + y * (kDP / 4);
-            const f32x4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
-            const float e[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
-                                 q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+            float e[16];
+            lds_read_16f_b64(e, rowp + y * kDS);
 #pragma unroll
             for (int x = 0; x < kB; ++x) {
 #pragma unroll
