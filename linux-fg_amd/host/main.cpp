@@ -1,0 +1,117 @@
+// lfg_host -- headless counterpart of the reference's CLI (src/main.cpp:21-144): same option names
+// and the same derivation of the output size; the X11 window id is replaced by a synthetic stream
+// index and the paced SDL loop by a fixed number of frames run flat out.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "scaler.hpp"
+
+static void PrintUsage() {
+    std::cout << "Usage: lfg_host [options] [stream-index]\n"
+              << "Options:\n"
+              << "  --help                   Show this help message\n"
+              << "  --input-width WIDTH      Input width (default: 1920)\n"
+              << "  --input-height HEIGHT    Input height (default: 1080)\n"
+              << "  --output-width WIDTH     Output width\n"
+              << "  --output-height HEIGHT   Output height\n"
+              << "  --target-fps FPS         Accepted for compatibility; frames are not paced\n"
+              << "  --no-interpolation       Disable frame interpolation\n"
+              << "  --interpolation-factor F Interpolation blend factor (0.0-1.0, default: 0.5)\n"
+              << "  --frames N               Number of input frames to process (default: 10)\n"
+              << "  --device N               HIP device ordinal (default: 0)\n"
+              << "  --dump-dir DIR           Write every presented frame to DIR as raw RGBA8\n"
+              << "  --quiet                  Only warnings and errors\n";
+}
+
+int main(int argc, char* argv[]) {
+    ScalerConfig config;
+    config.enableInterpolation = true;
+    config.interpolationFactor = 0.5f;
+    config.targetFps = 60;
+    uint32_t stream = 0;
+    int frames = 10, device = 0;
+    std::string dumpDir;
+
+    for (int i = 1; i < argc; i++) {
+        if (strcmp(argv[i], "--help") == 0) { PrintUsage(); return 0; }
+        else if (strcmp(argv[i], "--input-width") == 0 && i + 1 < argc) config.inputWidth = std::atoi(argv[++i]);
+        else if (strcmp(argv[i], "--input-height") == 0 && i + 1 < argc) config.inputHeight = std::atoi(argv[++i]);
+        else if (strcmp(argv[i], "--output-width") == 0 && i + 1 < argc) config.outputWidth = std::atoi(argv[++i]);
+        else if (strcmp(argv[i], "--output-height") == 0 && i + 1 < argc) config.outputHeight = std::atoi(argv[++i]);
+        else if (strcmp(argv[i], "--target-fps") == 0 && i + 1 < argc) config.targetFps = std::atoi(argv[++i]);
+        else if (strcmp(argv[i], "--no-interpolation") == 0) config.enableInterpolation = false;
+        else if (strcmp(argv[i], "--interpolation-factor") == 0 && i + 1 < argc) config.interpolationFactor = (float)std::atof(argv[++i]);
+        else if (strcmp(argv[i], "--frames") == 0 && i + 1 < argc) frames = std::atoi(argv[++i]);
+        else if (strcmp(argv[i], "--device") == 0 && i + 1 < argc) device = std::atoi(argv[++i]);
+        else if (strcmp(argv[i], "--dump-dir") == 0 && i + 1 < argc) dumpDir = argv[++i];
+        else if (strcmp(argv[i], "--quiet") == 0) Logger::Get().SetMinLevel(Logger::Level::WARNING);
+        else {
+            char* endPtr;
+            stream = (uint32_t)std::strtoul(argv[i], &endPtr, 0);
+            if (*endPtr != '\0') { LOG_ERROR("Invalid stream index"); return 1; }
+        }
+    }
+    if (config.inputWidth == 0) config.inputWidth = 1920;
+    if (config.inputHeight == 0) config.inputHeight = 1080;
+    // Output size: as src/main.cpp:76-90 (keep the aspect ratio when only one side is given).
+    if (config.outputWidth == 0 || config.outputHeight == 0) {
+        if (config.outputHeight != 0) {
+            float scale = (float)config.outputHeight / config.inputHeight;
+            config.outputWidth = static_cast<uint32_t>(config.inputWidth * scale);
+        } else if (config.outputWidth != 0) {
+            float scale = (float)config.outputWidth / config.inputWidth;
+            config.outputHeight = static_cast<uint32_t>(config.inputHeight * scale);
+        } else {
+            config.outputWidth = config.inputWidth;
+            config.outputHeight = config.inputHeight;
+        }
+    }
+
+    if (!HipContext::Get().Initialize(device)) { LOG_ERROR("Failed to initialize HIP"); return 1; }
+    if (!FrameManager::Get().Initialize(config.outputWidth, config.outputHeight)) {
+        LOG_ERROR("Failed to initialize frame manager");
+        HipContext::Get().Cleanup();
+        return 1;
+    }
+    Scaler::Get().SetFrameSource(std::make_unique<SyntheticCapture>(stream));
+    uint64_t checksum = 0, presented = 0, generated = 0;
+    Scaler::Get().SetPresenter([&](const uint8_t* rgba, uint32_t w, uint32_t h, bool interpolated) {
+        const size_t n = (size_t)w * h * 4;
+        uint64_t s = 0;
+        for (size_t i = 0; i < n; i += 64) s += rgba[i];
+        checksum = checksum * 1315423911ull + s;
+        if (!dumpDir.empty()) {
+            char name[512];
+            snprintf(name, sizeof name, "%s/frame_%04llu_%s_%ux%u.rgba", dumpDir.c_str(), (unsigned long long)presented,
+                     interpolated ? "interp" : "real", w, h);
+            if (FILE* f = fopen(name, "wb")) { fwrite(rgba, 1, n, f); fclose(f); }
+        }
+        ++presented;
+        generated += interpolated ? 1 : 0;
+    });
+    if (!Scaler::Get().Initialize(config)) {
+        LOG_ERROR("Failed to initialize scaler");
+        FrameManager::Get().Cleanup();
+        HipContext::Get().Cleanup();
+        return 1;
+    }
+
+    const auto t0 = std::chrono::steady_clock::now();
+    bool ok = true;
+    for (int i = 0; i < frames && ok; ++i) ok = Scaler::Get().ProcessFrame();
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+
+    // Teardown order as src/main.cpp:138-141.
+    Scaler::Get().Cleanup();
+    FrameManager::Get().Cleanup();
+    HipContext::Get().Cleanup();
+    if (!ok) { LOG_ERROR("ProcessFrame failed: ", Logger::Get().GetLastError()); return 1; }
+    printf("{\"input_frames\": %d, \"presented\": %llu, \"interpolated\": %llu, \"seconds\": %.4f, "
+           "\"presented_fps\": %.2f, \"checksum\": %llu, \"note\": \"includes host frame synthesis, PCIe upload and readback\"}\n",
+           frames, (unsigned long long)presented, (unsigned long long)generated, sec, presented / sec,
+           (unsigned long long)checksum);
+    return 0;
+}

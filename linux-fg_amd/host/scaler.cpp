@@ -1,0 +1,168 @@
+#include "scaler.hpp"
+
+namespace {
+lfg_context* Ctx() { return HipContext::Get().GetDevice(); }
+}
+
+bool Scaler::Initialize(const ScalerConfig& config) {
+    if (m_initialized) return true;
+    m_config = config;
+    if (!Ctx()) {
+        LOG_ERROR("Scaler::Initialize: HipContext is not initialized");
+        return false;
+    }
+    if (config.inputWidth == 0 || config.inputHeight == 0 || config.outputWidth == 0 || config.outputHeight == 0) {
+        LOG_ERROR("Scaler::Initialize: input and output sizes must be non-zero");
+        return false;
+    }
+    if (!m_source) m_source = std::make_unique<SyntheticCapture>();
+    if (!m_source->Initialize(config.inputWidth, config.inputHeight)) {
+        LOG_ERROR("Failed to initialize frame source");
+        return false;
+    }
+    const size_t inBytes = (size_t)config.inputWidth * config.inputHeight * 4;
+    const size_t outBytes = (size_t)config.outputWidth * config.outputHeight * 4;
+    if (lfg_ring_create(Ctx(), 3, inBytes, &m_uploadRing) != LFG_OK ||
+        lfg_ring_create(Ctx(), 4, outBytes, &m_readbackRing) != LFG_OK) {
+        LOG_ERROR("Failed to create pinned frame rings: ", lfg_last_error(Ctx()));
+        Cleanup();
+        return false;
+    }
+    m_initialized = true;
+    return true;
+}
+
+bool Scaler::CreateFrameResources() {
+    auto& fm = FrameManager::Get();
+    if (!m_currentFrame.data) {
+        LOG_DEBUG("Creating current frame buffer");
+        if (!fm.CreateFrame(m_currentFrame, m_config.inputWidth, m_config.inputHeight)) {
+            LOG_ERROR("Failed to create current frame");
+            return false;
+        }
+    }
+    if (m_config.enableInterpolation && !m_previousFrame.data) {
+        LOG_DEBUG("Creating previous frame buffer");
+        if (!fm.CreateFrame(m_previousFrame, m_config.inputWidth, m_config.inputHeight)) {
+            LOG_ERROR("Failed to create previous frame");
+            return false;
+        }
+    }
+    if (!m_outputFrame.data) {
+        LOG_DEBUG("Creating output frame buffer");
+        if (!fm.CreateFrame(m_outputFrame, m_config.outputWidth, m_config.outputHeight)) {
+            LOG_ERROR("Failed to create output frame");
+            return false;
+        }
+    }
+    if (m_config.enableInterpolation && !m_previousOutput.data) {
+        if (!fm.CreateFrame(m_previousOutput, m_config.outputWidth, m_config.outputHeight) ||
+            !fm.CreateFrame(m_interpolatedFrame, m_config.outputWidth, m_config.outputHeight)) {
+            LOG_ERROR("Failed to create interpolation frames");
+            return false;
+        }
+    }
+    return true;
+}
+
+bool Scaler::CaptureFrame(Frame& frame) {
+    void* host = nullptr;
+    uint32_t slot = 0;
+    if (lfg_ring_acquire(m_uploadRing, &host, &slot) != LFG_OK) {
+        LOG_ERROR("Failed to acquire an upload slot");
+        return false;
+    }
+    if (!m_source->NextFrame(static_cast<uint8_t*>(host))) {
+        LOG_ERROR("Failed to capture frame");
+        return false;
+    }
+    lfg_frame f = frame.AsAbi();
+    if (lfg_ring_upload(m_uploadRing, slot, &f) != LFG_OK) {
+        LOG_ERROR("Failed to upload captured frame: ", lfg_last_error(Ctx()));
+        return false;
+    }
+    return true;
+}
+
+bool Scaler::ScaleFrame(const Frame& input, Frame& output) {
+    LOG_DEBUG("ScaleFrame - Input: ", input.width, "x", input.height, " Output: ", output.width, "x", output.height);
+    const lfg_frame in = input.AsAbi();
+    lfg_frame out = output.AsAbi();
+    if (lfg_scale(Ctx(), &in, &out) != LFG_OK) {
+        LOG_ERROR("Failed to submit scale kernel: ", lfg_last_error(Ctx()));
+        return false;
+    }
+    return true;      // enqueued; ProcessFrame waits where it needs the pixels
+}
+
+bool Scaler::Present(const Frame& frame, bool interpolated) {
+    void* host = nullptr;
+    uint32_t slot = 0;
+    const lfg_frame f = frame.AsAbi();
+    if (lfg_ring_acquire(m_readbackRing, &host, &slot) != LFG_OK || lfg_ring_download(m_readbackRing, slot, &f) != LFG_OK) {
+        LOG_ERROR("Failed to read back frame: ", lfg_last_error(Ctx()));
+        return false;
+    }
+    if (!HipContext::Get().WaitIdle()) return false;
+    if (m_presenter) m_presenter(static_cast<const uint8_t*>(host), frame.width, frame.height, interpolated);
+    ++m_presented;
+    return true;
+}
+
+bool Scaler::ProcessFrame() {
+    if (!m_initialized) {
+        LOG_ERROR("Scaler not initialized");
+        return false;
+    }
+    // FPS meter: 60-sample sliding window, as src/scaler.cpp:428-439.
+    const auto now = std::chrono::steady_clock::now();
+    m_frameTimings.push_back(now);
+    while (m_frameTimings.size() > 60) m_frameTimings.pop_front();
+    if (m_frameTimings.size() >= 2) {
+        const auto ms = std::chrono::duration_cast<std::chrono::microseconds>(m_frameTimings.back() - m_frameTimings.front()).count();
+        if (ms > 0) m_currentFps = 1e6f * (float)(m_frameTimings.size() - 1) / (float)ms;
+    }
+
+    if (!CreateFrameResources()) return false;
+
+    if (!CaptureFrame(m_currentFrame)) {
+        LOG_ERROR("Failed to capture frame");
+        return false;
+    }
+    if (!ScaleFrame(m_currentFrame, m_outputFrame)) {
+        LOG_ERROR("Failed to scale frame");
+        return false;
+    }
+    if (m_config.enableInterpolation && m_havePrevious) {
+        if (!FrameManager::Get().InterpolateFrames(m_previousOutput, m_outputFrame, m_interpolatedFrame,
+                                                   m_config.interpolationFactor)) {
+            LOG_ERROR("Failed to interpolate frame");
+            return false;
+        }
+        if (!Present(m_interpolatedFrame, true)) return false;       // generated frame first, then the real one
+    }
+    if (!Present(m_outputFrame, false)) return false;
+
+    if (m_config.enableInterpolation) {
+        // previous <- current: swap the handles instead of copying the image (src/scaler.cpp:616-621).
+        std::swap(m_previousFrame, m_currentFrame);
+        std::swap(m_previousOutput, m_outputFrame);
+        m_havePrevious = true;
+    }
+    return true;
+}
+
+void Scaler::Cleanup() {
+    if (Ctx()) HipContext::Get().WaitIdle();
+    if (m_uploadRing) { lfg_ring_destroy(m_uploadRing); m_uploadRing = nullptr; }
+    if (m_readbackRing) { lfg_ring_destroy(m_readbackRing); m_readbackRing = nullptr; }
+    auto& fm = FrameManager::Get();
+    fm.DestroyFrame(m_currentFrame);
+    fm.DestroyFrame(m_previousFrame);
+    fm.DestroyFrame(m_outputFrame);
+    fm.DestroyFrame(m_previousOutput);
+    fm.DestroyFrame(m_interpolatedFrame);
+    m_havePrevious = false;
+    m_frameTimings.clear();
+    m_initialized = false;
+}

@@ -308,3 +308,19 @@ def test_three_stage_path_small(ctx, oracle):
     assert (On == oracle.interpolate(Pn, Cn, mv, 0.5)).all()
     for f in (p, c, P, C, O, M):
         ctx.destroy_frame(f)
+
+
+# ------------------------------------------------------------------------------ golden fixtures
+
+def test_golden_fixtures_on_device(ctx):
+    """tests/golden/golden_small.npz (oracle outputs on seeded frames, committed): the device path
+    reproduces them without the oracle being rebuilt or run."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_small.npz"))
+    assert_within_1lsb(run_scale(ctx, g["prev_in"], 128, 72), g["prev_up"])
+    assert_within_1lsb(run_scale(ctx, g["curr_in"], 128, 72), g["curr_up"])
+    assert_within_1lsb(run_scale(ctx, g["curr_in"], 53, 41), g["curr_53x41"])
+    assert (run_motion(ctx, g["prev_up"], g["curr_up"]) == g["mv"]).all()
+    assert (run_motion(ctx, g["prev_in"], g["curr_in"], 4, 3.0) == g["mv_b4_r3"]).all()
+    for t in (25, 50, 75):
+        assert (run_interpolate(ctx, g["prev_up"], g["curr_up"], g["mv"], t / 100.0) == g[f"interp_{t}"]).all()
