@@ -89,6 +89,25 @@ __device__ __forceinline__ void load_rgba8_unorm_x4(f32x4 &a, f32x4 &b, f32x4 &c
         : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(oa), "v"(ob), "v"(oc), "v"(od), "s"(rsrc) : "memory");
 }
 #undef LFG_TBUF
+__device__ __forceinline__ void load_rgba8_unorm_x10(f32x4 (&p)[10], const int (&o)[10], i32x4 rsrc) {
+    asm volatile(
+        "tbuffer_load_format_xyzw %0, %10, %20, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
+        "tbuffer_load_format_xyzw %1, %11, %20, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
+        "tbuffer_load_format_xyzw %2, %12, %20, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
+        "tbuffer_load_format_xyzw %3, %13, %20, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
+        "tbuffer_load_format_xyzw %4, %14, %20, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
+        "tbuffer_load_format_xyzw %5, %15, %20, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
+        "tbuffer_load_format_xyzw %6, %16, %20, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
+        "tbuffer_load_format_xyzw %7, %17, %20, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
+        "tbuffer_load_format_xyzw %8, %18, %20, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
+        "tbuffer_load_format_xyzw %9, %19, %20, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(p[4]),
+          "=&v"(p[5]), "=&v"(p[6]), "=&v"(p[7]), "=&v"(p[8]), "=&v"(p[9])
+        : "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(o[4]), "v"(o[5]), "v"(o[6]), "v"(o[7]), "v"(o[8]), "v"(o[9]),
+          "s"(rsrc)
+        : "memory");
+}
 
 // Sixteen consecutive floats from LDS as eight ds_read_b64 (never merged into ds_read2_b64 / split into
 // dword reads by the compiler, whose banking differs), issue and wait in one statement.

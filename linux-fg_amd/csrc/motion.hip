@@ -22,8 +22,9 @@
 //   range check.  prev is read straight from L1/L2 (the tile's search window is ~42 KB, re-read by
 //   every candidate); LDS holds only a double-buffered plane D[71][72] of distances for ONE candidate
 //   over the tile plus its block halo (41 KB: two workgroups per CU, 4 waves/SIMD).
-//   Per candidate k:   phase A  every thread computes ~10 entries of D_{k+1} (its curr texels stay in
-//                               registers as floats for the whole kernel)
+//   Per candidate k:   phase A  every thread computes 10 entries of D_{k+1}: one column of nine rows plus
+//                               one entry of the seven leftover columns (its curr texels stay in
+//                               registers as floats for the whole kernel), ten typed loads in one batch
 //                      phase B  every thread owns 8 horizontally adjacent pixels of one row and runs
 //                               their 8 chains over D_k: 8 rows x 15 floats from LDS, 512 adds
 //                      one __syncthreads().
@@ -67,86 +68,98 @@ constexpr int kTW = 64, kTH = 64;                 // pixel tile
 constexpr int kNT = 512;                          // threads per workgroup: one per 8x1 pixel patch
 constexpr int kDW = kTW + kB - 1;                 // 71 block positions across
 constexpr int kDH = kTH + kB - 1;                 // 71 down
-constexpr int kDP = 72;                           // D entries per row in the thread->entry map
 constexpr int kDS = 74;                           // D row pitch in LDS (floats): 74/2 = 37 = 1 mod 4 makes the
                                                   // chain phase's ds_read_b64 pattern conflict-free (see phase B)
-constexpr int kPos = (kDP * kDH + kNT - 1) / kNT; // D entries per thread (10)
+// Phase-A ownership of the 71 x 71 distance plane: thread (lane, wave g) computes column `lane` of rows
+// 9g .. 9g+8 (the main 64 x 72 block; row 71 does not exist), and threads 0..496 one entry each of the
+// remaining 7 columns.  Ten entries per thread, but only two base addresses to keep: the nine main
+// entries are one column, so their prev offsets differ by whole (wave-uniform) row pitches and their LDS
+// addresses by a constant.
+constexpr int kMainRows = 9;
+constexpr int kExtraCols = kDW - 64;              // 7
+constexpr int kExtra = kExtraCols * kDH;          // 497 entries
+constexpr int kPos = kMainRows + 1;               // 10
 constexpr int kSide = 2 * kR + 1;
 constexpr int kCand = kSide * kSide;
 static_assert(kTW / 8 * kTH == kNT, "one thread per 8x1 pixel patch");
-static_assert(kPos == 10, "wait_loads() lists ten registers");
+static_assert(kNT / 64 * kMainRows >= kDH && kExtra <= kNT, "phase-A map covers the plane");
 
 __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int8_t *__restrict__ mv, int mvPitch, int W, int H) {
     __shared__ __attribute__((aligned(16))) float sD[2][kDH * kDS];    // 2 x 21 KB
 
+    constexpr int kOob = (int)0x80000000;        // a buffer offset that always fails the range check
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int g = __builtin_amdgcn_readfirstlane(tid >> 6);           // wave index 0..7
     const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * kTH;         // tile origin (pixels)
     const int bx0 = tx0 - kB / 2, by0 = ty0 - kB / 2;                 // image coords of D(0,0)
     const i32x4 rPrev = make_rgba8_rsrc(prev, (uint32_t)H * (uint32_t)prevPitch);
     const i32x4 rCurr = make_rgba8_rsrc(curr, (uint32_t)H * (uint32_t)currPitch);
-    // Tiles whose search window can leave the image sideways need an explicit column test; rows
-    // above/below the image fall out of the buffer range and load zeros by themselves.
-    const bool borderX = __builtin_amdgcn_readfirstlane((bx0 - kR < 0) || (bx0 + kDW - 1 + kR >= W));
+    // Interior tiles: every block position lies inside the image and no candidate can leave it sideways.
+    // Rows above/below the image always fall out of the buffer range and load zeros by themselves.
+    const bool interior = __builtin_amdgcn_readfirstlane(
+        (bx0 - kR >= 0) && (bx0 + kDW - 1 + kR < W) && (by0 >= 0) && (by0 + kDH - 1 < H));
 
-    // This thread's D entries: linear index e = tid + kNT n  ->  (cy, cx) = (e / 72, e % 72).
-    // Entries that are padding or lie outside the image get curr = 0 (out-of-range load) and a prev
-    // offset that stays out of range for every candidate, so their distance is sqrt(0) = 0 with no
-    // per-candidate select.
-    constexpr int kOob = (int)0x80000000;
+    // ---- this thread's ten block positions and their curr texels (kept as floats for the whole kernel)
+    const int gxM = bx0 + lane, gyM0 = by0 + kMainRows * g;           // main block: column, first row
+    const bool colOkM = gxM >= 0 && gxM < W;
+    const bool hasE = tid < kExtra;
+    const int cyE = tid / kExtraCols, cxE = 64 + tid - cyE * kExtraCols;
+    const int gxE = bx0 + cxE, gyE = by0 + cyE;
+    const bool okE = hasE && gxE >= 0 && gxE < W && gyE >= 0 && gyE < H;
+    const int pb0 = (gyM0 - kR) * prevPitch + (gxM - kR) * 4;         // prev(c + (-R,-R)), main row 0 (may be < 0)
+    const int pbE = (gyE - kR) * prevPitch + (gxE - kR) * 4;
+    float *const dM = &sD[0][kMainRows * g * kDS + lane];             // LDS slot of main row 0, buffer 0
+    float *const dE = &sD[0][cyE * kDS + cxE];
     float cf[kPos][4];
-    int pbyte[kPos];             // byte offset of prev(c + (-R,-R)) in the prev frame (may be negative)
-    int daddr[kPos];             // LDS index of the entry: cy * kDS + cx
-    const int cx0 = tid % kDP;   // cx of entry n is (cx0 + 8 n) mod 72, since kNT mod 72 == 8
-    static_assert(kNT % kDP == 8, "cx recurrence below");
     {
         int co[kPos];
 #pragma unroll
-        for (int n = 0; n < kPos; ++n) {
-            const int e = tid + kNT * n;
-            const int cy = e / kDP, cx = e - cy * kDP;
-            const int gx = bx0 + cx, gy = by0 + cy;
-            const bool ok = (e < kDP * kDH) && (cx < kDW) && gx >= 0 && gy >= 0 && gx < W && gy < H;
-            co[n] = ok ? gy * currPitch + gx * 4 : kOob;
-            pbyte[n] = ok ? (gy - kR) * prevPitch + (gx - kR) * 4 : kOob;
-            daddr[n] = cy * kDS + cx;
+        for (int j = 0; j < kMainRows; ++j) {
+            const int gy = gyM0 + j;
+            co[j] = (colOkM && gy >= 0 && gy < H && kMainRows * g + j < kDH) ? gy * currPitch + gxM * 4 : kOob;
         }
+        co[kMainRows] = okE ? gyE * currPitch + gxE * 4 : kOob;
         f32x4 c4[kPos];
-        load_rgba8_unorm_x4(c4[0], c4[1], c4[2], c4[3], co[0], co[1], co[2], co[3], rCurr);
-        load_rgba8_unorm_x3(c4[4], c4[5], c4[6], co[4], co[5], co[6], rCurr);
-        load_rgba8_unorm_x3(c4[7], c4[8], c4[9], co[7], co[8], co[9], rCurr);
+        load_rgba8_unorm_x10(c4, co, rCurr);
 #pragma unroll
         for (int n = 0; n < kPos; ++n) { cf[n][0] = c4[n].x; cf[n][1] = c4[n].y; cf[n][2] = c4[n].z; cf[n][3] = c4[n].w; }
     }
 
-    // ---- phase A: D(c) = distance(curr(c), prev(c + m)) for one candidate, 0 outside the image.
-    //      Loads go out in batches of 4 + 3 + 3 so that at most 16 registers are in flight.
-    auto phaseA = [&](int cand, float *__restrict__ D) {
+    // ---- phase A: D(c) = distance(curr(c), prev(c + m)) for one candidate, 0 for c outside the image.
+    auto phaseA = [&](int cand, int buf) {
         const int dyi = cand / kSide, dxi = cand - dyi * kSide;       // dy + R, dx + R (wave-uniform)
         const int candOff = dyi * prevPitch + dxi * 4;
-        auto offset = [&](int n) -> int {
-            if (!borderX) return pbyte[n] + candOff;
-            int cx = cx0 + 8 * n;                                       // < 72 + 72
-            cx = cx >= kDP ? cx - kDP : cx;
-            const bool xin = (unsigned)(bx0 + cx - kR + dxi) < (unsigned)W;
-            return xin ? pbyte[n] + candOff : kOob;
-        };
-        auto store = [&](int n, f32x4 p) {
-            const int e = tid + kNT * n;
-            if (e < kDP * kDH) D[daddr[n]] = dist4<true>(cf[n], p);
-        };
-        {
-            f32x4 p0, p1, p2, p3;
-            load_rgba8_unorm_x4(p0, p1, p2, p3, offset(0), offset(1), offset(2), offset(3), rPrev);
-            store(0, p0); store(1, p1); store(2, p2); store(3, p3);
-        }
+        int o[kPos];
+        if (interior) {
+            const int b = pb0 + candOff;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int n0 = 4 + 3 * h;
-            f32x4 p0, p1, p2;
-            load_rgba8_unorm_x3(p0, p1, p2, offset(n0), offset(n0 + 1), offset(n0 + 2), rPrev);
-            store(n0, p0); store(n0 + 1, p1); store(n0 + 2, p2);
+            for (int j = 0; j < kMainRows; ++j) o[j] = b + j * prevPitch;
+            o[kMainRows] = hasE ? pbE + candOff : kOob;
+        } else {
+            // prev(c + m) left/right of the image -> zero texel (its row offset would alias a neighbour row)
+            const int b = (unsigned)(gxM - kR + dxi) < (unsigned)W ? pb0 + candOff : kOob;
+#pragma unroll
+            for (int j = 0; j < kMainRows; ++j) o[j] = b + j * prevPitch;   // kOob + j*pitch stays out of range
+            o[kMainRows] = (hasE && (unsigned)(gxE - kR + dxi) < (unsigned)W) ? pbE + candOff : kOob;
+        }
+        f32x4 p[kPos];
+        load_rgba8_unorm_x10(p, o, rPrev);
+        const int bo = buf * (kDH * kDS);
+#pragma unroll
+        for (int j = 0; j < kMainRows; ++j) {
+            float d = dist4<true>(cf[j], p[j]);
+            if (!interior) {
+                const int gy = gyM0 + j;
+                d = (colOkM && gy >= 0 && gy < H) ? d : 0.0f;         // block position outside the image: skipped
+            }
+            if (kMainRows * g + j < kDH) dM[bo + j * kDS] = d;        // wave-uniform: row 71 does not exist
+        }
+        if (hasE) {
+            const float d = dist4<true>(cf[kMainRows], p[kMainRows]);
+            dE[bo] = (interior || okE) ? d : 0.0f;
         }
     };
 
@@ -157,35 +170,46 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
 #pragma unroll
     for (int i = 0; i < 8; ++i) { best[i] = 1e10f; bestCand[i] = 0; }   // motion.comp:23-24
 
-    phaseA(0, sD[0]);
+    phaseA(0, 0);
     __syncthreads();
 
     for (int cand = 0; cand < kCand; ++cand) {
-        phaseA(cand + 1, sD[(cand + 1) & 1]);   // cand + 1 == kCand reads past the last row: zeros, never used
-        __builtin_amdgcn_sched_barrier(0);       // keep phase A's loaded texels out of phase B's live range
+        phaseA(cand + 1, (cand + 1) & 1);   // cand + 1 == kCand reads past the last row: zeros, never used
+        __builtin_amdgcn_sched_barrier(0);  // keep phase A's loaded texels out of phase B's live range
 
         // ---- phase B: the 8 sequential chains of this thread's pixels, block rows top to bottom,
         //      block columns left to right -- the literal order of motion.comp:33-47.
-        const float *rowp = sD[cand & 1] + ry * kDS + rxq * 8;
+        // One block row per step: eight 8-byte LDS reads (15 of the 16 floats are used) and 64 adds, the
+        // next row's reads issued before this row's adds.  With a 74-float pitch the 32 lanes of a
+        // ds_read_b64 group (4 tile rows x 8 patches) hit 32 distinct 8-byte slots of the 256-byte bank
+        // row -- (37*row + 4*patch + j) mod 32 is a bijection -- so the reads are conflict-free (16-byte
+        // reads on a 72-float pitch were 3-way conflicted, 63 % of the LDS cycles, and no pitch fixes
+        // ds_read_b128's lane groups).  The reads are volatile so the compiler keeps them as eight
+        // ds_read_b64: merged into ds_read2_b64 they bank differently and conflict again.
+        typedef const volatile __attribute__((address_space(3))) f32x2 *lds_f32x2_ptr;   // keep it a DS access
+        const lds_f32x2_ptr rowp = (lds_f32x2_ptr)(sD[cand & 1] + ry * kDS + rxq * 8);
         float acc[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
-        // One block row per step: eight 8-byte LDS reads (15 of the 16 floats are used), then its 64
-        // adds.  With a 74-float pitch the 32 lanes of a ds_read_b64 group (4 tile rows x 8 patches) hit
-        // 32 distinct 8-byte slots of the 256-byte bank row: (37*row + 4*patch + j) mod 32 is a
-        // bijection, so the reads are conflict-free (16-byte reads on a 72-float pitch were 3-way
-        // conflicted: SQ_LDS_BANK_CONFLICT was 63 % of the LDS cycles, and no pitch fixes that for
-        // ds_read_b128's lane groups).  The other waves on the SIMD cover the LDS latency.
+        f32x2 q[8], nq[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[j] = rowp[j];
 #pragma unroll
         for (int y = 0; y < kB; ++y) {
-            float e[16];
-            lds_read_16f_b64(e, rowp + y * kDS);
+            if (y + 1 < kB) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) nq[j] = rowp[(y + 1) * (kDS / 2) + j];
+            }
+            const float e[16] = {q[0].x, q[0].y, q[1].x, q[1].y, q[2].x, q[2].y, q[3].x, q[3].y,
+                                 q[4].x, q[4].y, q[5].x, q[5].y, q[6].x, q[6].y, q[7].x, q[7].y};
 #pragma unroll
             for (int x = 0; x < kB; ++x) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) acc[i] += e[i + x];       // pixel i, block column x
             }
             __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q[j] = nq[j];
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -196,23 +220,24 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
 
     const int py = ty0 + ry, px0 = tx0 + rxq * 8;
     if (py < H && px0 < W) {
-        int8_t o[16];
+        uint32_t o[4] = {0u, 0u, 0u, 0u};                             // 8 x (int8 dx, int8 dy)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int dyi = bestCand[i] / kSide, dxi = bestCand[i] - dyi * kSide;
-            o[2 * i] = (int8_t)(dxi - kR);
-            o[2 * i + 1] = (int8_t)(dyi - kR);
+            const uint32_t v = (uint32_t)(uint8_t)(int8_t)(dxi - kR) | ((uint32_t)(uint8_t)(int8_t)(dyi - kR) << 8);
+            o[i >> 1] |= v << (16 * (i & 1));
         }
         int8_t *dst = mv + (size_t)py * (size_t)mvPitch + (size_t)px0 * 2u;
         if (px0 + 7 < W && (mvPitch & 15) == 0) {
-            uint4 v;
-            v.x = (uint8_t)o[0] | ((uint32_t)(uint8_t)o[1] << 8) | ((uint32_t)(uint8_t)o[2] << 16) | ((uint32_t)(uint8_t)o[3] << 24);
-            v.y = (uint8_t)o[4] | ((uint32_t)(uint8_t)o[5] << 8) | ((uint32_t)(uint8_t)o[6] << 16) | ((uint32_t)(uint8_t)o[7] << 24);
-            v.z = (uint8_t)o[8] | ((uint32_t)(uint8_t)o[9] << 8) | ((uint32_t)(uint8_t)o[10] << 16) | ((uint32_t)(uint8_t)o[11] << 24);
-            v.w = (uint8_t)o[12] | ((uint32_t)(uint8_t)o[13] << 8) | ((uint32_t)(uint8_t)o[14] << 16) | ((uint32_t)(uint8_t)o[15] << 24);
-            *reinterpret_cast<uint4 *>(dst) = v;
+            *reinterpret_cast<uint4 *>(dst) = uint4{o[0], o[1], o[2], o[3]};
         } else {
-            for (int i = 0; i < 8 && px0 + i < W; ++i) { dst[2 * i] = o[2 * i]; dst[2 * i + 1] = o[2 * i + 1]; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (px0 + i < W) {
+                    const uint32_t v = o[i >> 1] >> (16 * (i & 1));
+                    dst[2 * i] = (int8_t)(v & 0xff); dst[2 * i + 1] = (int8_t)((v >> 8) & 0xff);
+                }
+            }
         }
     }
 }
