@@ -86,10 +86,21 @@ constexpr int kOobOffset = (int)0x80000000;   // buffer offset that always fails
 #endif
 constexpr int kStoreAux = LFG_STORE_AUX;      // gfx940+ cache policy bits: 1 = sc0, 2 = nt, 16 = sc1
 
-struct F4 { float x, y, z, w; };
+// Four channels as two register pairs: the weighted sums are written on pairs so that they compile to
+// v_pk_fma_f32 (two FMAs per instruction).  Packed FMAs have no higher lane throughput than plain ones
+// on gfx950, but a wave issues one VALU instruction per 4 cycles on its own, and this kernel is bound
+// by per-wave issue latency, not by SIMD throughput: halving the instruction count of the FMA blocks
+// shortens every step.
+struct F4 { f32x2 lo, hi; };          // lo = (r, g), hi = (b, a)
+
+__device__ __forceinline__ void fma4(F4 &acc, float w, const F4 &t) {
+    const f32x2 ww = {w, w};
+    acc.lo = __builtin_elementwise_fma(ww, t.lo, acc.lo);
+    acc.hi = __builtin_elementwise_fma(ww, t.hi, acc.hi);
+}
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ F4 unpack255(uint32_t p) { return F4{byte0(p), byte1(p), byte2(p), byte3(p)}; }
+__device__ __forceinline__ F4 unpack255(uint32_t p) { return F4{f32x2{byte0(p), byte1(p)}, f32x2{byte2(p), byte3(p)}}; }
 
 // At exact 2x, output columns 2k and 2k+1 (lane = input column k) read input columns k-3..k+2 and
 // k-2..k+3; output rows 2r-5 and 2r-4 both read input rows r-5..r (host-verified: AxisTable::pattern_2x).
@@ -142,12 +153,19 @@ __global__ __launch_bounds__(256, 3) void scale_2x_kernel(
     // with broadcast LDS reads (a scalar load per output row would sit on the critical path).
     {
         const int oyFirst = 2 * rBegin - 5;
+        constexpr int kChunks = (STEPS * 12 + 63) / 64;
+        float wv_[kChunks];
 #pragma unroll
-        for (int i0 = 0; i0 < STEPS * 12; i0 += 64) {
-            const int i = i0 + lane;
+        for (int c = 0; c < kChunks; ++c) {             // all loads first: one memory latency, not kChunks
+            const int i = c * 64 + lane;
+            const int oy = min(max(oyFirst + i / 6, 0), outH - 1);
+            wv_[c] = weightY[(size_t)oy * 6u + (size_t)(i % 6)];
+        }
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c) {
+            const int i = c * 64 + lane;
             const int oy = oyFirst + i / 6;
-            if (i < STEPS * 12)
-                wys[i] = (oy >= 0 && oy < outH) ? weightY[(size_t)oy * 6u + (size_t)(i % 6)] : 0.0f;
+            if (i < STEPS * 12) wys[i] = (oy >= 0 && oy < outH) ? wv_[c] : 0.0f;
         }
     }
 
@@ -201,13 +219,11 @@ __global__ __launch_bounds__(256, 3) void scale_2x_kernel(
 #pragma unroll
         for (int j = 0; j < 7; ++j) t[j] = buf[lane + j];
         wave_lds_sync();
-        F4 h0{0, 0, 0, 0}, h1{0, 0, 0, 0};
+        F4 h0{f32x2{0, 0}, f32x2{0, 0}}, h1{f32x2{0, 0}, f32x2{0, 0}};
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            h0.x = __builtin_fmaf(wa[j], t[j].x, h0.x); h0.y = __builtin_fmaf(wa[j], t[j].y, h0.y);
-            h0.z = __builtin_fmaf(wa[j], t[j].z, h0.z); h0.w = __builtin_fmaf(wa[j], t[j].w, h0.w);
-            h1.x = __builtin_fmaf(wb[j], t[j + 1].x, h1.x); h1.y = __builtin_fmaf(wb[j], t[j + 1].y, h1.y);
-            h1.z = __builtin_fmaf(wb[j], t[j + 1].z, h1.z); h1.w = __builtin_fmaf(wb[j], t[j + 1].w, h1.w);
+            fma4(h0, wa[j], t[j]);
+            fma4(h1, wb[j], t[j + 1]);
         }
         win[u][0] = h0; win[u][1] = h1;
         // 3. emit output rows 2r-5 and 2r-4 from window rows r-5..r = slots (u+1+j)%6.
@@ -218,19 +234,14 @@ __global__ __launch_bounds__(256, 3) void scale_2x_kernel(
                 const float2 *wyp = reinterpret_cast<const float2 *>(wys + (2 * (s - 5) + half) * 6);
                 const float2 wy01 = wyp[0], wy23 = wyp[1], wy45 = wyp[2];
                 const float wy[6] = {wy01.x, wy01.y, wy23.x, wy23.y, wy45.x, wy45.y};
-                F4 o0{0, 0, 0, 0}, o1{0, 0, 0, 0};
+                F4 o0{f32x2{0, 0}, f32x2{0, 0}}, o1{f32x2{0, 0}, f32x2{0, 0}};
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
-                    const float w = wy[j];
-                    const F4 &a = win[(u + 1 + j) % 6][0];
-                    const F4 &b = win[(u + 1 + j) % 6][1];
-                    o0.x = __builtin_fmaf(w, a.x, o0.x); o0.y = __builtin_fmaf(w, a.y, o0.y);
-                    o0.z = __builtin_fmaf(w, a.z, o0.z); o0.w = __builtin_fmaf(w, a.w, o0.w);
-                    o1.x = __builtin_fmaf(w, b.x, o1.x); o1.y = __builtin_fmaf(w, b.y, o1.y);
-                    o1.z = __builtin_fmaf(w, b.z, o1.z); o1.w = __builtin_fmaf(w, b.w, o1.w);
+                    fma4(o0, wy[j], win[(u + 1 + j) % 6][0]);
+                    fma4(o1, wy[j], win[(u + 1 + j) % 6][1]);
                 }
-                px[half][0] = pack_rgba8_255(o0.x, o0.y, o0.z, o0.w);
-                px[half][1] = pack_rgba8_255(o1.x, o1.y, o1.z, o1.w);
+                px[half][0] = pack_rgba8_255(o0.lo.x, o0.lo.y, o0.hi.x, o0.hi.y);
+                px[half][1] = pack_rgba8_255(o1.lo.x, o1.lo.y, o1.hi.x, o1.hi.y);
             }
             // One 16-byte store per lane instead of two 8-byte ones (8-byte-per-lane stores are
             // issue-bound at ~7 B/clk/CU on gfx950, which capped this kernel at ~7.5 us).  Lanes pair up:
