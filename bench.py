@@ -120,11 +120,18 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # One rank per GPU.  LFG_BENCH_BACKEND=gloo (rehearsal only) lets several ranks share one card so the
+    # N > 1 code path can be exercised on a one-GPU box; RCCL itself needs one device per rank.
+    backend = os.environ.get("LFG_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from linux_fg_amd import capi, sharding, synth
 
@@ -134,7 +141,7 @@ def main():
     steps = args.steps if args.steps is not None else (200 if args.workload == "scale" else 20)
     warmup = args.warmup if args.warmup is not None else (20 if args.workload == "scale" else 3)
 
-    ctx = capi.Context(local_rank)
+    ctx = capi.Context(dev_index)
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
 
@@ -241,10 +248,12 @@ def main():
             roofline = {"kernel": {"scale": "scale_2x_kernel", "interpolate": "interpolate_kernel"}[dominant],
                         "bound": "hbm", "achieved": s["hbm_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": s["hbm_frac"], "traffic": None}
+        size_name = {"540p": "540p->1080p", "1080p": "1080p->4K", "4k": "4K->8K", "8k": "8K->16K"}[args.input]
         total_bytes = sum(algorithmic_bytes(n, w_in, h_in, w, h) * (len(factors) if n == "interpolate" else 1)
                           for n in stage_ms)
         line = {
-            "metric": "interpolated frames/s, 1080p->4K RGBA8" if args.workload == "pipeline" else "upscaled frames/s, 1080p->4K RGBA8 (Lanczos only)",
+            "metric": (f"interpolated frames/s, {size_name} RGBA8" if args.workload == "pipeline"
+                       else f"upscaled frames/s, {size_name} RGBA8 (Lanczos only)"),
             "value": round(value, 3),
             "unit": "frames/s",
             "n_gpus": world, "steps": steps, "warmup": warmup,
