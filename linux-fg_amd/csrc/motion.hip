@@ -35,21 +35,21 @@
 
 namespace lfg {
 
-// Correctly rounded sqrtf for x = 0 or normal x (here x is a sum of four squares in [0, 4]).
-// v_sqrt_f32 is within 1 ulp; the two FMA residuals against the neighbouring floats decide whether
-// to step down or up (the same fix-up LLVM emits for IEEE sqrt, minus its denormal scaling, which
-// this input range never needs).  ~12 VALU-op equivalents instead of ~23 for __builtin_sqrtf
-// (tools/microbench.hip).  Checked against __builtin_sqrtf for every float in [2^-20, 8] and 0 by
-// lfg_selftest_sqrt (tests/test_gpu_parity.py::test_exact_sqrt_exhaustive).
+// Correctly rounded sqrtf for the inputs this kernel produces: x = 0, or a sum of four squares in
+// [(1/255)^2, 4].  One Newton step on v_rsq_f32 with an FMA residual (Markstein's form):
+//     y = rsq(x),  g = x*y,  h = y/2,  r = x - g*g (exact in the FMA),  result = g + r*h.
+// Unlike the compiler's IEEE sqrtf (v_sqrt_f32 + two residual tests + denormal scaling, ~23 VALU-op
+// equivalents, tools/microbench.hip) this is 5 plain ops and one transcendental.  It is not proven
+// correctly rounded in general; it IS verified exhaustively: lfg_selftest_sqrt compares it on the
+// device with __builtin_sqrtf for every float in [2^-21, 8] and for 0
+// (tests/test_gpu_parity.py::test_exact_sqrt_exhaustive: 0 mismatches in 201,326,593 values).
 __device__ __forceinline__ float exact_sqrt(float x) {
-    float y = __builtin_amdgcn_sqrtf(x);
-    const float ydn = __builtin_bit_cast(float, __builtin_bit_cast(int, y) - 1);
-    const float yup = __builtin_bit_cast(float, __builtin_bit_cast(int, y) + 1);
-    const float rdn = __builtin_fmaf(-ydn, y, x);
-    const float rup = __builtin_fmaf(-yup, y, x);
-    y = (rdn <= 0.0f) ? ydn : y;
-    y = (rup > 0.0f) ? yup : y;
-    return y;
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float g = x * y;
+    const float h = 0.5f * y;
+    const float r = __builtin_fmaf(-g, g, x);
+    const float g2 = __builtin_fmaf(r, h, g);
+    return x == 0.0f ? 0.0f : g2;          // rsq(0) = inf
 }
 
 // distance() of two texels already converted to float, oracle choice (7):

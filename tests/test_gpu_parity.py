@@ -180,7 +180,7 @@ def test_motion_4k_translation_property(ctx, oracle):
 
 
 def test_exact_sqrt_exhaustive(ctx):
-    """csrc/motion.hip: exact_sqrt (v_sqrt_f32 + two-FMA fix-up) against the compiler's IEEE sqrtf for
+    """csrc/motion.hip: exact_sqrt (one Newton step on v_rsq_f32) against the compiler's IEEE sqrtf for
     every float from 2^-21 to 8 (the motion kernel feeds it sums of four squares in [0, 4], the
     smallest non-zero one being (1/255)^2 ~ 1.5e-5) and for 0."""
     lo = int(np.float32(2.0 ** -21).view(np.uint32))
