@@ -324,3 +324,72 @@ def test_golden_fixtures_on_device(ctx):
     assert (run_motion(ctx, g["prev_in"], g["curr_in"], 4, 3.0) == g["mv_b4_r3"]).all()
     for t in (25, 50, 75):
         assert (run_interpolate(ctx, g["prev_up"], g["curr_up"], g["mv"], t / 100.0) == g[f"interp_{t}"]).all()
+
+
+# ------------------------------------------------------------------------------ pitched frames
+
+def _pitched(ctx, host, pad_px, fmt=None):
+    """Upload `host` into the left part of a wider device allocation and describe it with a row pitch
+    larger than width * bpp (lfg_frame_wrap), as a caller handing over a sub-rectangle would."""
+    from linux_fg_amd import capi
+    fmt = capi.FORMAT_RGBA8 if fmt is None else fmt
+    h, w, ch = host.shape
+    wide = np.zeros((h, w + pad_px, ch), host.dtype)
+    wide[:, :w] = host
+    wide[:, w:] = 0x5A if host.dtype == np.uint8 else 3          # poison the padding
+    big = ctx.frame_from(wide, fmt)
+    view = capi.Context.wrap(big.data, w, h, fmt, pitch=(w + pad_px) * ch)
+    return big, view
+
+
+def _read_pitched(ctx, big, w):
+    return ctx.download(big)[:, :w]
+
+
+@pytest.mark.parametrize("pad", [4, 12])
+def test_all_stages_with_row_pitch_larger_than_width(ctx, oracle, pad):
+    from linux_fg_amd import capi
+    w, h = 64, 36
+    prev, curr = synth.make_pair(w, h, stream=4, shift=(-2, 1))
+    bp, vp = _pitched(ctx, prev, pad)
+    bc, vc = _pitched(ctx, curr, pad)
+    W, H = 2 * w, 2 * h
+    bP, vP = _pitched(ctx, np.zeros((H, W, 4), np.uint8), pad)
+    bC, vC = _pitched(ctx, np.zeros((H, W, 4), np.uint8), pad)
+    bO, vO = _pitched(ctx, np.zeros((H, W, 4), np.uint8), pad)
+    bM, vM = _pitched(ctx, np.zeros((H, W, 2), np.int8), pad, capi.FORMAT_MV_S8X2)
+    ctx.scale(vp, vP); ctx.scale(vc, vC)
+    ctx.motion(vP, vC, vM)
+    ctx.interpolate(vP, vC, vM, vO, 0.5)
+    Pn, Cn, Mn, On = (_read_pitched(ctx, b, W) for b in (bP, bC, bM, bO))
+    assert_within_1lsb(Pn, oracle.scale(prev, W, H))
+    assert_within_1lsb(Cn, oracle.scale(curr, W, H))
+    mv = oracle.motion(Pn, Cn)
+    assert (Mn == mv.astype(np.int8)).all()
+    assert (On == oracle.interpolate(Pn, Cn, mv, 0.5)).all()
+    for b in (bP, bC, bO):                                   # nothing was written into the padding
+        assert (ctx.download(b)[:, W:] == 0x5A).all()
+    assert (ctx.download(bM)[:, W:] == 3).all()
+    for b in (bp, bc, bP, bC, bO, bM):
+        ctx.destroy_frame(b)
+
+
+def test_argument_validation_on_device(ctx):
+    from linux_fg_amd import capi
+    a = ctx.create_frame(32, 16)
+    b = ctx.create_frame(64, 32)
+    m = ctx.create_frame(32, 16, capi.FORMAT_MV_S8X2)
+    with pytest.raises(capi.LfgError, match="differ in size"):
+        ctx.motion(a, b, m)
+    with pytest.raises(capi.LfgError, match="searchRadius"):
+        ctx.motion(a, a, m, 8, 2.5)
+    with pytest.raises(capi.LfgError, match="blockSize"):
+        ctx.motion(a, a, m, 0, 16.0)
+    with pytest.raises(capi.LfgError, match="wrong format|bad frame"):
+        ctx.interpolate(a, a, a, a, 0.5)
+    with pytest.raises(capi.LfgError, match="dimensions do not match"):
+        ctx.copy(a, b)
+    with pytest.raises(capi.LfgError, match="smaller than expected"):
+        ctx._check(ctx.lib.lfg_frame_upload(ctx.h, a, np.zeros(8, np.uint8).ctypes.data, 8), "lfg_frame_upload")
+    for f in (a, b, m):
+        ctx.destroy_frame(f)
