@@ -65,6 +65,28 @@ def algorithmic_bytes(stage: str, w_in: int, h_in: int, w: int, h: int) -> int:
     raise ValueError(stage)
 
 
+def pmc_traffic(kernel_prefix: str):
+    """HBM bytes per launch of `kernel_prefix` from the newest committed two-pass PMC summary
+    (profiles/rNN_hbm_traffic_pmc.txt: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3
+    passes, values in KB).  bench.py cannot run the profiler on itself; None if no summary exists."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.txt")))
+    if not files:
+        return None, None
+    vals, cur = {}, None
+    for line in open(files[-1]):
+        m = re.match(r"^(?:void )?(lfg::\w+)", line)
+        if m:
+            cur = m.group(1)
+        m = re.match(r"^\s+(FETCH_SIZE|WRITE_SIZE)\s+([0-9.e+]+)", line)
+        if m and cur and cur.startswith(kernel_prefix):
+            vals[m.group(1)] = float(m.group(2)) * 1024.0
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        return int(vals["FETCH_SIZE"] + vals["WRITE_SIZE"]), os.path.relpath(files[-1], ROOT)
+    return None, None
+
+
 def motion_flops(w: int, h: int, block: int = 8, radius: int = 16) -> float:
     """Algorithmic flops of motion.comp with per-position distance reuse: per candidate, one distance
     per pixel (4 sub, 4 mul, 3 add, 1 sqrt = 12 flops) and block*block adds per pixel."""
@@ -249,6 +271,13 @@ def main():
                         "bound": "hbm", "achieved": s["hbm_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": s["hbm_frac"], "traffic": None}
         size_name = {"540p": "540p->1080p", "1080p": "1080p->4K", "4k": "4K->8K", "8k": "8K->16K"}[args.input]
+        if args.input == "1080p":
+            t, src = pmc_traffic({"motion_tiled_8_16_kernel": "lfg::motion_tiled", "scale_2x_kernel": "lfg::scale_2x",
+                                  "interpolate_kernel": "lfg::interpolate"}[roofline["kernel"]])
+            if t is not None:
+                roofline["traffic"] = t
+                roofline["traffic_source"] = (f"{src}: FETCH_SIZE + WRITE_SIZE from two separate rocprofv3 --pmc passes, bytes per "
+                                              "launch; FETCH_SIZE raw (uncalibrated for 4-byte-per-lane loads)")
         total_bytes = sum(algorithmic_bytes(n, w_in, h_in, w, h) * (len(factors) if n == "interpolate" else 1)
                           for n in stage_ms)
         line = {
