@@ -156,6 +156,21 @@ int  lfg_scale(lfg_context *ctx, const lfg_frame *in, lfg_frame *out);
 int  lfg_motion(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *curr, lfg_frame *mv,
                 int block_size, float search_radius);
 
+/* How lfg_motion evaluates blockSize 8 / searchRadius 16.  Both modes return bit-identical motion
+ * vectors for every input; they differ in run time only.
+ *   LFG_MOTION_PREFILTERED (default): a pairwise-tree approximation of every candidate's cost, whose
+ *       distance from the shader's sequential fp32 sum is bounded rigorously (4.2e-6 relative), selects
+ *       the few candidates that can still be the minimum; only those get the literal 64-term chain.
+ *       Tiles where the filter cannot separate the candidates (flat or finely tied content) fall back to
+ *       the exact kernel, so such content costs what LFG_MOTION_EXACT_ONLY costs.
+ *   LFG_MOTION_EXACT_ONLY: the literal chain for every (pixel, candidate); content-independent time. */
+typedef enum lfg_motion_mode { LFG_MOTION_PREFILTERED = 0, LFG_MOTION_EXACT_ONLY = 1 } lfg_motion_mode;
+int  lfg_set_motion_mode(lfg_context *ctx, int mode);
+/* After a prefiltered lfg_motion: number of 64x64 tiles, how many of them fell back to the exact kernel,
+ * and the mean number of candidates recorded per pixel in the others (synchronises; reporting only). */
+int  lfg_motion_last_stats(lfg_context *ctx, uint32_t *out_tiles, uint32_t *out_fallback_tiles,
+                           double *out_mean_recorded);
+
 /* shaders/interpolate.comp (src/frame_manager.cpp:351-366): MV-displaced bilinear fetch of prev
  * and curr, blended by `factor`.  Literal reference semantics (MV in pixels added to normalised
  * UV). */

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "liblinuxfg_hip.so")
 FORMAT_RGBA8 = 0
 FORMAT_MV_S8X2 = 1
 STAGE_SCALE, STAGE_MOTION, STAGE_INTERPOLATE = 0, 1, 2
+MOTION_PREFILTERED, MOTION_EXACT_ONLY = 0, 1
 _BPP = {FORMAT_RGBA8: 4, FORMAT_MV_S8X2: 2}
 
 
@@ -60,6 +61,8 @@ SIGNATURES = {
     "lfg_ring_download": (_i, [_vp, _u32, _FP]),
     "lfg_scale": (_i, [_vp, _FP, _FP]),
     "lfg_motion": (_i, [_vp, _FP, _FP, _FP, _i, ctypes.c_float]),
+    "lfg_set_motion_mode": (_i, [_vp, _i]),
+    "lfg_motion_last_stats": (_i, [_vp, ctypes.POINTER(_u32), ctypes.POINTER(_u32), ctypes.POINTER(ctypes.c_double)]),
     "lfg_interpolate": (_i, [_vp, _FP, _FP, _FP, _FP, ctypes.c_float]),
     "lfg_interpolate_frames": (_i, [_vp, _FP, _FP, _FP, ctypes.c_float]),
     "lfg_mv_export_rgba32f": (_i, [_vp, _FP, _vp]),
@@ -180,6 +183,16 @@ class Context:
     def motion(self, prev: Frame, curr: Frame, mv: Frame, block_size: int = 8, search_radius: float = 16.0):
         self._check(self.lib.lfg_motion(self.h, ctypes.byref(prev), ctypes.byref(curr), ctypes.byref(mv),
                                         block_size, search_radius), "lfg_motion")
+
+    def set_motion_mode(self, mode: int):
+        """0 = prefiltered (default), 1 = exact kernel only; results are identical."""
+        self._check(self.lib.lfg_set_motion_mode(self.h, mode), "lfg_set_motion_mode")
+
+    def motion_last_stats(self):
+        """(tiles, tiles that fell back to the exact kernel, mean candidates recorded per pixel elsewhere)."""
+        t, f, m = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_double()
+        self._check(self.lib.lfg_motion_last_stats(self.h, ctypes.byref(t), ctypes.byref(f), ctypes.byref(m)), "lfg_motion_last_stats")
+        return t.value, f.value, m.value
 
     def interpolate(self, prev: Frame, curr: Frame, mv: Frame, out: Frame, factor: float = 0.5):
         self._check(self.lib.lfg_interpolate(self.h, ctypes.byref(prev), ctypes.byref(curr), ctypes.byref(mv),

@@ -3,6 +3,7 @@
 // There is no CPU fallback anywhere: every entry point needs a live HIP device.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -107,6 +108,29 @@ void trim_axis_tables(lfg_context *ctx) {
     }
 }
 
+// ---- scratch of the prefiltered motion path (per frame size; kept between calls)
+
+int ensure_motion_workspace(lfg_context *ctx, uint32_t width, uint32_t height) {
+    if (ctx->motion_ws && ctx->motion_ws_w == width && ctx->motion_ws_h == height) return LFG_OK;
+    lfg::MotionWorkspaceLayout layout;
+    const size_t bytes = lfg::motion_workspace_bytes(width, height, &layout);
+    if (bytes > ctx->motion_ws_bytes) {
+        LFG_HIP(ctx, hipStreamSynchronize(ctx->stream));          // a queued kernel may still use the old one
+        if (ctx->motion_ws) (void)hipFree(ctx->motion_ws);
+        ctx->motion_ws = nullptr; ctx->motion_ws_bytes = 0; ctx->motion_ws_w = ctx->motion_ws_h = 0;
+        LFG_HIP(ctx, hipMalloc((void **)&ctx->motion_ws, bytes));
+        ctx->motion_ws_bytes = bytes;
+    } else {
+        LFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    uint16_t order[33 * 33];
+    lfg::motion_candidate_order(order);
+    LFG_HIP(ctx, hipMemcpy(ctx->motion_ws + layout.order, order, sizeof order, hipMemcpyHostToDevice));
+    ctx->motion_ws_layout = layout;
+    ctx->motion_ws_w = width; ctx->motion_ws_h = height;
+    return LFG_OK;
+}
+
 // ---- profiling
 
 struct StageTimer {
@@ -179,6 +203,7 @@ LFG_EXPORT int lfg_context_create(int device_ordinal, lfg_context **out_ctx) {
     if (e != hipSuccess) { delete ctx; return fail_hip(nullptr, e, "hipStreamCreate"); }
     ctx->stream = ctx->own_stream;
     ctx->tables.reserve(17);                 // AxisTable pointers handed out stay valid
+    if (const char *m = getenv("LFG_MOTION_MODE")) ctx->motion_mode = atoi(m) == 1 ? LFG_MOTION_EXACT_ONLY : LFG_MOTION_PREFILTERED;
     *out_ctx = ctx;
     return LFG_OK;
 }
@@ -192,6 +217,7 @@ LFG_EXPORT void lfg_context_destroy(lfg_context *ctx) {
     for (auto &p : ctx->prof_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto &t : ctx->tables) { (void)hipFree(t.d_start); (void)hipFree(t.d_weight); }
     if (ctx->mv_tmp.data && ctx->mv_tmp.owned) (void)hipFree(ctx->mv_tmp.data);
+    if (ctx->motion_ws) (void)hipFree(ctx->motion_ws);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -385,11 +411,53 @@ LFG_EXPORT int lfg_motion(lfg_context *ctx, const lfg_frame *prev, const lfg_fra
     if ((prev->pitch | curr->pitch) % 4u || ((uintptr_t)prev->data | (uintptr_t)curr->data) % 4u)
         return fail(ctx, LFG_ERR_INVALID, "lfg_motion: RGBA8 frames must be 4-byte aligned");
     const int R = (int)search_radius;
+    const bool tiled = block_size == 8 && R == 16;
+    if (tiled && ctx->motion_mode == LFG_MOTION_PREFILTERED) {
+        int rc = ensure_motion_workspace(ctx, curr->width, curr->height);
+        if (rc != LFG_OK) return rc;
+    }
     StageTimer timer(ctx, LFG_STAGE_MOTION);
     hipError_t e;
-    if (block_size == 8 && R == 16) e = lfg::launch_motion_tiled_8_16(ctx->stream, *prev, *curr, *mv);
+    if (tiled && ctx->motion_mode == LFG_MOTION_PREFILTERED)
+        e = lfg::launch_motion_prefiltered_8_16(ctx->stream, *prev, *curr, *mv, ctx->motion_ws, ctx->motion_ws_layout);
+    else if (tiled) e = lfg::launch_motion_tiled_8_16(ctx->stream, *prev, *curr, *mv, nullptr);
     else e = lfg::launch_motion_generic(ctx->stream, *prev, *curr, *mv, block_size, R);
     if (e != hipSuccess) return fail_hip(ctx, e, "motion kernel launch");
+    return LFG_OK;
+}
+
+LFG_EXPORT int lfg_set_motion_mode(lfg_context *ctx, int mode) {
+    if (!ctx || (mode != LFG_MOTION_PREFILTERED && mode != LFG_MOTION_EXACT_ONLY))
+        return fail(ctx, LFG_ERR_INVALID, "lfg_set_motion_mode: unknown mode");
+    ctx->motion_mode = mode;
+    return LFG_OK;
+}
+
+LFG_EXPORT int lfg_motion_last_stats(lfg_context *ctx, uint32_t *out_tiles, uint32_t *out_fallback_tiles,
+                                     double *out_mean_recorded) {
+    if (!ctx) return LFG_ERR_INVALID;
+    if (!ctx->motion_ws || ctx->motion_ws_w == 0) return fail(ctx, LFG_ERR_INVALID, "lfg_motion_last_stats: the prefiltered path has not run");
+    LFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t tx = (ctx->motion_ws_w + 63u) / 64u, ty = (ctx->motion_ws_h + 63u) / 64u;
+    std::vector<uint32_t> flags((size_t)tx * ty);
+    LFG_HIP(ctx, hipMemcpy(flags.data(), ctx->motion_ws + ctx->motion_ws_layout.tileFlags, flags.size() * 4, hipMemcpyDeviceToHost));
+    uint32_t fb = 0;
+    for (uint32_t f : flags) fb += f != 0u;
+    if (getenv("LFG_DEBUG"))
+        for (size_t i = 0; i < flags.size(); ++i)
+            if (flags[i]) fprintf(stderr, "lfg: motion fallback tile (%zu, %zu)\n", i % tx, i / tx);
+    if (out_tiles) *out_tiles = tx * ty;
+    if (out_fallback_tiles) *out_fallback_tiles = fb;
+    if (out_mean_recorded) {
+        const size_t px = (size_t)ctx->motion_ws_w * ctx->motion_ws_h;
+        std::vector<uint32_t> cnt(px);
+        LFG_HIP(ctx, hipMemcpy(cnt.data(), ctx->motion_ws + ctx->motion_ws_layout.count, px * 4, hipMemcpyDeviceToHost));
+        double sum = 0; size_t n = 0;
+        for (uint32_t y = 0; y < ctx->motion_ws_h; ++y)
+            for (uint32_t x = 0; x < ctx->motion_ws_w; ++x)
+                if (!flags[(size_t)(y / 64u) * tx + x / 64u]) { sum += cnt[(size_t)y * ctx->motion_ws_w + x]; ++n; }
+        *out_mean_recorded = n ? sum / (double)n : 0.0;
+    }
     return LFG_OK;
 }
 

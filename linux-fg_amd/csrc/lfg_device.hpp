@@ -89,6 +89,18 @@ __device__ __forceinline__ void load_rgba8_unorm_x4(f32x4 &a, f32x4 &b, f32x4 &c
         : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(oa), "v"(ob), "v"(oc), "v"(od), "s"(rsrc) : "memory");
 }
 #undef LFG_TBUF
+__device__ __forceinline__ void load_rgba8_unorm_x5(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d, f32x4 &e,
+                                                    int oa, int ob, int oc, int od, int oe, i32x4 rsrc) {
+    asm volatile(
+        "tbuffer_load_format_xyzw %0, %5, %10, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
+        "tbuffer_load_format_xyzw %1, %6, %10, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
+        "tbuffer_load_format_xyzw %2, %7, %10, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
+        "tbuffer_load_format_xyzw %3, %8, %10, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
+        "tbuffer_load_format_xyzw %4, %9, %10, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e)
+        : "v"(oa), "v"(ob), "v"(oc), "v"(od), "v"(oe), "s"(rsrc) : "memory");
+}
 __device__ __forceinline__ void load_rgba8_unorm_x10(f32x4 (&p)[10], const int (&o)[10], i32x4 rsrc) {
     asm volatile(
         "tbuffer_load_format_xyzw %0, %10, %20, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"

@@ -24,6 +24,8 @@ struct AxisTable {
     float *d_weight = nullptr;    // [out_size][6]
 };
 
+struct MotionWorkspaceLayout { size_t list, listC, umin, count, tileFlags, order, total; };
+
 struct ProfileSlot {
     hipEvent_t begin = nullptr, end = nullptr;
     int stage = 0;
@@ -38,6 +40,12 @@ struct lfg_context {
     std::string error;
     std::vector<lfg::AxisTable> tables;       // small cache, linear search
     lfg_frame mv_tmp{};                        // temporary of lfg_interpolate_frames
+    // prefiltered motion path: scratch for one frame size, grown on demand
+    uint8_t *motion_ws = nullptr;
+    size_t motion_ws_bytes = 0;
+    uint32_t motion_ws_w = 0, motion_ws_h = 0;
+    lfg::MotionWorkspaceLayout motion_ws_layout{};
+    int motion_mode = 0;                       // 0: prefilter + exact fallback, 1: exact kernel only
     // profiling
     bool profile = false;
     std::vector<lfg::ProfileSlot> prof_pending;
@@ -56,7 +64,12 @@ hipError_t launch_scale_2x(hipStream_t s, const lfg_frame &in, const lfg_frame &
                            const AxisTable &tx, const AxisTable &ty);
 bool scale_2x_supported(const lfg_frame &in, const lfg_frame &out);
 hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
-                                    const lfg_frame &mv);
+                                    const lfg_frame &mv, const uint32_t *tileFlags);
+// Prefiltered motion path (motion.hip): MotionWorkspaceLayout = byte offsets of its scratch arrays.
+size_t motion_workspace_bytes(uint32_t width, uint32_t height, MotionWorkspaceLayout *layout);
+void motion_candidate_order(uint16_t *order_1089);
+hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
+                                          const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &layout);
 hipError_t launch_motion_generic(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                  const lfg_frame &mv, int block_size, int radius);
 hipError_t launch_interpolate(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,

@@ -86,8 +86,11 @@ static_assert(kNT / 64 * kMainRows >= kDH && kExtra <= kNT, "phase-A map covers 
 
 __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
-    int8_t *__restrict__ mv, int mvPitch, int W, int H) {
+    int8_t *__restrict__ mv, int mvPitch, int W, int H, const uint32_t *__restrict__ tileFlags) {
     __shared__ __attribute__((aligned(16))) float sD[2][kDH * kDS];    // 2 x 21 KB
+
+    // Second pass of the prefiltered path: only the tiles the prefilter gave up on (flag != 0).
+    if (tileFlags && tileFlags[blockIdx.y * gridDim.x + blockIdx.x] == 0u) return;
 
     constexpr int kOob = (int)0x80000000;        // a buffer offset that always fails the range check
     const int tid = threadIdx.x;
@@ -242,13 +245,346 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------ prefiltered path
+//
+// The exact chain of motion.comp costs 64 dependent-order adds per (pixel, candidate), but only the
+// candidates that can still be THE minimum need it.  For sums of non-negative fp32 terms every summation
+// order is close to the real sum T: the shader's sequential chain S lies in [T(1-u)^63, T(1+u)^63] and a
+// depth-6 pairwise tree S~ in [T(1-u)^6, T(1+u)^6] (u = 2^-24), so  |S/S~ - 1| <= 69u = 4.2e-6  whatever
+// the data (measured on frames: <= 2.4e-6).  The tree sums are cheap because neighbouring pixels share
+// their partial sums: 8-wide row sums once per block row (3 adds per entry), then 8 rows per pixel
+// (7 adds) -- ~12 adds per (pixel, candidate) instead of 64.
+//
+//   motion_prefilter_kernel  for every candidate: distance plane D (as in the exact kernel) -> row sums
+//       H8 -> per pixel S~; a candidate is recorded in the pixel's list when S~(1-1e-5) <= min over the
+//       candidates seen so far of S~(1+1e-5) (it may still be the exact minimum); at most kListK per
+//       pixel, else the whole tile is flagged and left to the exact kernel.  Candidates are visited in a
+//       fixed pseudo-random order (see motion_candidate_order).
+//   motion_resolve_kernel    per pixel: the recorded candidates that pass the final bound (typically
+//       one) get the literal chain of motion.comp:33-47; the smallest (cost, scan index) wins, which is
+//       the shader's first strict minimum in scan order.
+//   motion_tiled_8_16_kernel with the tile flags: full exact evaluation of the flagged tiles (flat or
+//       finely tied content, where every candidate survives the filter).
+// Every exact minimiser m* is recorded and survives: S~(m*)(1-1e-5) <= S(m*) <= S(j) <= S~(j)(1+1e-5) for
+// all j.  Results are therefore identical to the exact kernel's for any input; only the run time depends
+// on the content.
+
+constexpr int kHP = 66;                 // H8 row pitch (floats): 66/2 = 33 = 1 mod 4 -> conflict-free ds b64
+constexpr int kListK = 32;              // recorded candidates per pixel.  A pseudo-random visiting order makes the
+                                        // number of running minima ~Poisson(ln 1089 = 7.6) whatever the content:
+                                        // P(> 32) ~ 1e-11 per pixel, so only genuinely tied content overflows
+constexpr float kLo = 0.99999f, kHi = 1.00001f;       // 1 -/+ 1e-5: the 4.2e-6 bound with slack for the products
+
+typedef volatile __attribute__((address_space(3))) f32x2 *lds_rw_f32x2_ptr;
+typedef const volatile __attribute__((address_space(3))) f32x2 *lds_ro_f32x2_ptr;
+
+__global__ __launch_bounds__(kNT, 4) void motion_prefilter_kernel(
+    const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
+    int W, int H, float *__restrict__ listS, uint16_t *__restrict__ listC, float *__restrict__ uminOut,
+    uint32_t *__restrict__ countOut, uint32_t *__restrict__ tileFlags, const uint16_t *__restrict__ order) {
+    __shared__ __attribute__((aligned(16))) float sD[2][kDH * kDS];    // 2 x 21.0 KB distance planes
+    __shared__ __attribute__((aligned(16))) float sH[2][kDH * kHP];    // 2 x 18.7 KB row-sum planes
+    __shared__ uint32_t sGiveUp;
+
+    constexpr int kOob = (int)0x80000000;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * kTH;
+    const int bx0 = tx0 - kB / 2, by0 = ty0 - kB / 2;
+    const i32x4 rPrev = make_rgba8_rsrc(prev, (uint32_t)H * (uint32_t)prevPitch);
+    const i32x4 rCurr = make_rgba8_rsrc(curr, (uint32_t)H * (uint32_t)currPitch);
+    const bool interior = __builtin_amdgcn_readfirstlane(
+        (bx0 - kR >= 0) && (bx0 + kDW - 1 + kR < W) && (by0 >= 0) && (by0 + kDH - 1 < H));
+    if (tid == 0) sGiveUp = 0u;
+
+    // ---- stage A set-up: identical to the exact kernel's phase A
+    const int gxM = bx0 + lane, gyM0 = by0 + kMainRows * g;
+    const bool colOkM = gxM >= 0 && gxM < W;
+    const bool hasE = tid < kExtra;
+    const int cyE = tid / kExtraCols, cxE = 64 + tid - cyE * kExtraCols;
+    const int gxE = bx0 + cxE, gyE = by0 + cyE;
+    const bool okE = hasE && gxE >= 0 && gxE < W && gyE >= 0 && gyE < H;
+    const int pb0 = (gyM0 - kR) * prevPitch + (gxM - kR) * 4;
+    const int pbE = (gyE - kR) * prevPitch + (gxE - kR) * 4;
+    float *const dM = &sD[0][kMainRows * g * kDS + lane];
+    float *const dE = &sD[0][cyE * kDS + cxE];
+    float cf[kPos][4];
+    {
+        int co[kPos];
+#pragma unroll
+        for (int j = 0; j < kMainRows; ++j) {
+            const int gy = gyM0 + j;
+            co[j] = (colOkM && gy >= 0 && gy < H && kMainRows * g + j < kDH) ? gy * currPitch + gxM * 4 : kOob;
+        }
+        co[kMainRows] = okE ? gyE * currPitch + gxE * 4 : kOob;
+        f32x4 c4[kPos];
+        load_rgba8_unorm_x10(c4, co, rCurr);
+#pragma unroll
+        for (int n = 0; n < kPos; ++n) { cf[n][0] = c4[n].x; cf[n][1] = c4[n].y; cf[n][2] = c4[n].z; cf[n][3] = c4[n].w; }
+    }
+    auto stageA = [&](int cand, int buf) {
+        const int dyi = cand / kSide, dxi = cand - dyi * kSide;
+        const int candOff = dyi * prevPitch + dxi * 4;
+        int o[kPos];
+        if (interior) {
+            const int b = pb0 + candOff;
+#pragma unroll
+            for (int j = 0; j < kMainRows; ++j) o[j] = b + j * prevPitch;
+            o[kMainRows] = hasE ? pbE + candOff : kOob;
+        } else {
+            const int b = (unsigned)(gxM - kR + dxi) < (unsigned)W ? pb0 + candOff : kOob;
+#pragma unroll
+            for (int j = 0; j < kMainRows; ++j) o[j] = b + j * prevPitch;
+            o[kMainRows] = (hasE && (unsigned)(gxE - kR + dxi) < (unsigned)W) ? pbE + candOff : kOob;
+        }
+        const int bo = buf * (kDH * kDS);
+        auto putMain = [&](int j, f32x4 pj) {
+            float d = dist4<true>(cf[j], pj);
+            if (!interior) {
+                const int gy = gyM0 + j;
+                d = (colOkM && gy >= 0 && gy < H) ? d : 0.0f;
+            }
+            if (kMainRows * g + j < kDH) dM[bo + j * kDS] = d;
+        };
+        {   // two batches of five loads: 20 registers in flight instead of 40
+            f32x4 p0, p1, p2, p3, p4;
+            load_rgba8_unorm_x5(p0, p1, p2, p3, p4, o[0], o[1], o[2], o[3], o[4], rPrev);
+            putMain(0, p0); putMain(1, p1); putMain(2, p2); putMain(3, p3); putMain(4, p4);
+            load_rgba8_unorm_x5(p0, p1, p2, p3, p4, o[5], o[6], o[7], o[8], o[9], rPrev);
+            putMain(5, p0); putMain(6, p1); putMain(7, p2); putMain(8, p3);
+            if (hasE) {
+                const float d = dist4<true>(cf[kMainRows], p4);
+                dE[bo] = (interior || okE) ? d : 0.0f;
+            }
+        }
+    };
+
+    // ---- stage H: H8[r][x] = pairwise sum of D[r][x .. x+7]; thread = (row tid>>3, eight columns 8*(tid&7)),
+    //      rows 64..70 by the first 56 threads of wave 0.
+    const int seg = tid & 7, hrow = tid >> 3;
+    auto rowSums = [&](int row, int buf) {
+        const lds_ro_f32x2_ptr src = (lds_ro_f32x2_ptr)(sD[buf] + row * kDS + seg * 8);
+        f32x2 q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[j] = src[j];
+        const float d[16] = {q[0].x, q[0].y, q[1].x, q[1].y, q[2].x, q[2].y, q[3].x, q[3].y,
+                             q[4].x, q[4].y, q[5].x, q[5].y, q[6].x, q[6].y, q[7].x, q[7].y};
+        float h2[14], h4[12], h8[8];
+#pragma unroll
+        for (int i = 0; i < 14; ++i) h2[i] = d[i] + d[i + 1];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) h4[i] = h2[i] + h2[i + 2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h8[i] = h4[i] + h4[i + 4];
+        const lds_rw_f32x2_ptr dst = (lds_rw_f32x2_ptr)(sH[buf] + row * kHP + seg * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j] = f32x2{h8[2 * j], h8[2 * j + 1]};
+    };
+    auto stageH = [&](int buf) {
+        rowSums(hrow, buf);
+        if (g == 0 && tid < (kDH - 64) * 8) rowSums(64 + hrow, buf);
+    };
+
+    // ---- stage V: S~ of the thread's 8 pixels, bound test, candidate lists
+    const int rxq = tid & 7, ry = tid >> 3;
+    const int py = ty0 + ry, px0 = tx0 + rxq * 8;
+    float umin[8];
+    uint32_t cnt4[2] = {0u, 0u};          // eight 8-bit counters
+#pragma unroll
+    for (int i = 0; i < 8; ++i) umin[i] = __builtin_inff();
+    auto stageV = [&](int buf, int cand) {
+        const lds_ro_f32x2_ptr src = (lds_ro_f32x2_ptr)(sH[buf] + ry * kHP + rxq * 8);
+        float s[8];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {              // rows 0-3, then rows 4-7
+            float a[8], b[8];
+#pragma unroll
+            for (int y2 = 0; y2 < 2; ++y2) {
+                const int y = 4 * half + 2 * y2;
+                f32x2 r0[4], r1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { r0[j] = src[y * (kHP / 2) + j]; r1[j] = src[(y + 1) * (kHP / 2) + j]; }
+                float *dst = y2 ? b : a;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { dst[2 * j] = r0[j].x + r1[j].x; dst[2 * j + 1] = r0[j].y + r1[j].y; }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float v4 = a[i] + b[i]; s[i] = half ? s[i] + v4 : v4; }
+        }
+        bool giveUp = false;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float lo = s[i] * kLo, hi = s[i] * kHi;
+            const bool ev = (lo <= umin[i]) && (py < H) && (px0 + i < W);
+            umin[i] = __builtin_fminf(umin[i], hi);
+            if (ev) {
+                const uint32_t n = (cnt4[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                if (n < (uint32_t)kListK) {
+                    const size_t at = ((size_t)py * (size_t)W + (size_t)(px0 + i)) * kListK + n;
+                    listS[at] = s[i];
+                    listC[at] = (uint16_t)cand;
+                    cnt4[i >> 2] += 1u << (8 * (i & 3));
+                } else {
+                    giveUp = true;
+                }
+            }
+        }
+        if (giveUp) sGiveUp = 1u;
+    };
+
+    // ---- three-stage pipeline, one barrier per candidate:
+    //      A(e+2) -> D[e&1],   H(e+1): D[(e+1)&1] -> H8[(e+1)&1],   V(e): H8[e&1]
+    __syncthreads();
+    stageA(order[0], 0);
+    stageA(order[1], 1);
+    __syncthreads();
+    stageH(0);
+    __syncthreads();
+    bool gaveUp = false;
+    for (int e = 0; e < kCand; ++e) {
+        if (e + 2 < kCand) stageA(order[e + 2], e & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (e + 1 < kCand) stageH((e + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        stageV(e & 1, order[e]);
+        __syncthreads();
+        if (sGiveUp != 0u) { gaveUp = true; break; }      // uniform: every thread reads the same word after the barrier
+    }
+    if (tid == 0) tileFlags[blockIdx.y * gridDim.x + blockIdx.x] = gaveUp ? 1u : 0u;
+    if (gaveUp) return;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (py < H && px0 + i < W) {
+            const size_t gp = (size_t)py * (size_t)W + (size_t)(px0 + i);
+            uminOut[gp] = umin[i];
+            countOut[gp] = (cnt4[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+        }
+    }
+}
+
+// Exact chain of motion.comp:27-47 for ONE candidate of ONE pixel (literal loops, same distance
+// arithmetic as everywhere else in this file).
+__device__ float exact_cost(const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr,
+                            int currPitch, int W, int H, int px, int py, int dx, int dy) {
+    float diff = 0.0f;
+    for (int y = 0; y < kB; ++y) {
+        const int cy = py - kB / 2 + y;
+        if (cy < 0 || cy >= H) continue;
+        for (int x = 0; x < kB; ++x) {
+            const int cx = px - kB / 2 + x;
+            if (cx < 0 || cx >= W) continue;
+            const uint32_t c = *reinterpret_cast<const uint32_t *>(curr + (size_t)cy * (size_t)currPitch + (size_t)cx * 4u);
+            const int qx = cx + dx, qy = cy + dy;
+            uint32_t p = 0u;
+            if (qx >= 0 && qy >= 0 && qx < W && qy < H)
+                p = *reinterpret_cast<const uint32_t *>(prev + (size_t)qy * (size_t)prevPitch + (size_t)qx * 4u);
+            const float cc[4] = {unorm8_to_float(byte0(c)), unorm8_to_float(byte1(c)),
+                                 unorm8_to_float(byte2(c)), unorm8_to_float(byte3(c))};
+            const f32x4 pp = {unorm8_to_float(byte0(p)), unorm8_to_float(byte1(p)),
+                              unorm8_to_float(byte2(p)), unorm8_to_float(byte3(p))};
+            diff += dist4<true>(cc, pp);
+        }
+    }
+    return diff;
+}
+
+__global__ __launch_bounds__(256) void motion_resolve_kernel(
+    const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
+    int8_t *__restrict__ mv, int mvPitch, int W, int H, const float *__restrict__ listS,
+    const uint16_t *__restrict__ listC, const float *__restrict__ uminIn, const uint32_t *__restrict__ countIn, const uint32_t *__restrict__ tileFlags,
+    int tilesX) {
+    const int px = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (px >= W || py >= H) return;
+    if (tileFlags[(py / kTH) * tilesX + px / kTW] != 0u) return;       // this tile goes through the exact kernel
+    const size_t gp = (size_t)py * (size_t)W + (size_t)px;
+    const float bound = uminIn[gp];
+    const uint32_t n = min(countIn[gp], (uint32_t)kListK);
+    float bestV = __builtin_inff();
+    uint32_t bestC = 0xFFFFFFFFu;
+    // Lanes find their next surviving entry independently and only then meet in the expensive exact
+    // evaluation, so a wave runs it max-over-lanes(survivors) times (typically once), not once per list
+    // position that holds a survivor for some lane.
+    uint32_t k = 0;
+    for (;;) {
+        uint32_t cand = 0xFFFFFFFFu;
+        while (k < n) {
+            const float st = listS[gp * kListK + k];
+            const uint32_t c = listC[gp * kListK + k];
+            ++k;
+            if (st * kLo <= bound) { cand = c; break; }
+        }
+        if (cand == 0xFFFFFFFFu) break;
+        const int dyi = (int)cand / kSide, dxi = (int)cand - dyi * kSide;
+        const float v = exact_cost(prev, prevPitch, curr, currPitch, W, H, px, py, dxi - kR, dyi - kR);
+        if (v < bestV || (v == bestV && cand < bestC)) { bestV = v; bestC = cand; }
+    }
+    const int dyi = (int)bestC / kSide, dxi = (int)bestC - dyi * kSide;
+    int8_t *dst = mv + (size_t)py * (size_t)mvPitch + (size_t)px * 2u;
+    dst[0] = (int8_t)(dxi - kR);
+    dst[1] = (int8_t)(dyi - kR);
+}
+
 hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
-                                    const lfg_frame &mv) {
+                                    const lfg_frame &mv, const uint32_t *tileFlags) {
     dim3 grid((curr.width + kTW - 1) / kTW, (curr.height + kTH - 1) / kTH);
     hipLaunchKernelGGL(motion_tiled_8_16_kernel, grid, dim3(kNT), 0, s,
                        (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
-                       (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height);
+                       (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, tileFlags);
     return hipGetLastError();
+}
+
+size_t motion_workspace_bytes(uint32_t width, uint32_t height, MotionWorkspaceLayout *layout) {
+    const size_t px = (size_t)width * height;
+    const size_t tiles = (size_t)((width + kTW - 1) / kTW) * ((height + kTH - 1) / kTH);
+    auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    MotionWorkspaceLayout l;
+    l.list = 0;
+    l.listC = align(l.list + px * kListK * sizeof(float));
+    l.umin = align(l.listC + px * kListK * sizeof(uint16_t));
+    l.count = align(l.umin + px * sizeof(float));
+    l.tileFlags = align(l.count + px * sizeof(uint32_t));
+    l.order = align(l.tileFlags + tiles * sizeof(uint32_t));
+    l.total = align(l.order + kCand * sizeof(uint16_t));
+    if (layout) *layout = l;
+    return l.total;
+}
+
+void motion_candidate_order(uint16_t *order) {
+    // A fixed pseudo-random permutation (Fisher-Yates driven by a 32-bit LCG).  Visiting the candidates in
+    // an order unrelated to their position makes the sequence of costs behave like a random sample, so a
+    // pixel sees only ~ln(1089) running minima -- for smooth content and for image borders alike, where a
+    // spatially ordered walk would keep finding slightly better candidates and overflow the lists.
+    for (int i = 0; i < kCand; ++i) order[i] = (uint16_t)i;
+    uint32_t state = 0x9E3779B9u;
+    for (int i = kCand - 1; i > 0; --i) {
+        state = state * 1664525u + 1013904223u;
+        const int j = (int)((state >> 8) % (uint32_t)(i + 1));
+        const uint16_t t = order[i]; order[i] = order[j]; order[j] = t;
+    }
+}
+
+hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
+                                          const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &l) {
+    const int tilesX = ((int)curr.width + kTW - 1) / kTW, tilesY = ((int)curr.height + kTH - 1) / kTH;
+    float *listS = reinterpret_cast<float *>(workspace + l.list);
+    uint16_t *listC = reinterpret_cast<uint16_t *>(workspace + l.listC);
+    float *umin = reinterpret_cast<float *>(workspace + l.umin);
+    uint32_t *count = reinterpret_cast<uint32_t *>(workspace + l.count);
+    uint32_t *flags = reinterpret_cast<uint32_t *>(workspace + l.tileFlags);
+    const uint16_t *order = reinterpret_cast<const uint16_t *>(workspace + l.order);
+    hipLaunchKernelGGL(motion_prefilter_kernel, dim3(tilesX, tilesY), dim3(kNT), 0, s,
+                       (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
+                       (int)curr.width, (int)curr.height, listS, listC, umin, count, flags, order);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(motion_resolve_kernel, dim3((curr.width + 63) / 64, (curr.height + 3) / 4), dim3(256), 0, s,
+                       (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
+                       (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, listS, listC, umin, count, flags, tilesX);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_motion_tiled_8_16(s, prev, curr, mv, flags);
 }
 
 // Diagnostic: compares exact_sqrt with __builtin_sqrtf for every float whose bit pattern lies in
