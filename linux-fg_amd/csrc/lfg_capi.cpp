@@ -123,7 +123,7 @@ int ensure_motion_workspace(lfg_context *ctx, uint32_t width, uint32_t height) {
     } else {
         LFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    uint16_t order[33 * 33];
+    uint32_t order[33 * 33];
     lfg::motion_candidate_order(order);
     LFG_HIP(ctx, hipMemcpy(ctx->motion_ws + layout.order, order, sizeof order, hipMemcpyHostToDevice));
     ctx->motion_ws_layout = layout;

@@ -67,7 +67,7 @@ hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const 
                                     const lfg_frame &mv, const uint32_t *tileFlags);
 // Prefiltered motion path (motion.hip): MotionWorkspaceLayout = byte offsets of its scratch arrays.
 size_t motion_workspace_bytes(uint32_t width, uint32_t height, MotionWorkspaceLayout *layout);
-void motion_candidate_order(uint16_t *order_1089);
+void motion_candidate_order(uint32_t *order32_1089);
 hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                           const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &layout);
 hipError_t launch_motion_generic(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,

@@ -280,40 +280,49 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
 // Data flow of the prefilter (no texture unit, no fp32 texels -- bytes and integer dot products):
 //   * a 256-thread workgroup owns a 56 x 64 pixel tile = 63 x 71 block positions; prev's search window
 //     (95 x 103 texels, zero outside the image like texelFetch) is staged ONCE in LDS as packed RGBA8;
-//   * stage AV, thread = (position column `lane`, 16-row segment `seg`): its 23 curr texels stay in registers
-//     (packed, plus their squared norms); per candidate 23 conflict-free ds_read_b32 of the window,
-//     n = |c|^2 + |p|^2 - 2 c.p by two v_dot4_u32_u8 and a mad, cvt, v_sqrt_f32, then the 16 column sums
-//     V8(r) = D(r) + ... + D(r+7) as a shared pairwise tree (58 adds) -> LDS plane V8[64][65], double-buffered;
-//   * stage H, thread = (pixel row `lane`, 14-pixel run `seg`): 21 values of its V8 row (pitch 65: lanes hit
-//     distinct banks), shared pairwise tree (52 adds) -> 14 S~, bound test, list append;
-//   * one barrier per candidate: AV(e+1) and H(e) work on different halves of the V8 double buffer.
+//     after that its four waves never synchronise again: wave `seg` owns pixel rows 16 seg .. 16 seg + 15;
+//   * column sums, thread = position column `lane`: the 23 curr texels of rows 16 seg .. 16 seg + 22 stay in
+//     registers (packed, plus their squared norms); per candidate 23 conflict-free ds_read_b32 of the
+//     window, n = |c|^2 + |p|^2 - 2 c.p by two v_dot4_u32_u8 whose accumulators are float bit patterns (so n
+//     comes out as a float without conversions), v_sqrt_f32, then the 16 column sums
+//     V8(r) = D(r) + ... + D(r+7) as a shared pairwise tree (58 adds);
+//   * transposition through a wave-private LDS slab of 8 rows x 68 floats, eight rows at a time (writes:
+//     lane = column; reads: lane = (row lane&7, 7-pixel run lane>>3), banks 4 row + 7 run: all distinct);
+//   * row sums, per lane two runs of 7 pixels (rows r and r+8): 13 values -> shared pairwise tree (29 adds) ->
+//     7 S~, threshold test, list append.
+//   LDS: 38.2 KB window + 4 x 2.1 KB slabs = 46.9 KB -> three workgroups (12 waves) per CU.  DS operations of
+//   one wave execute in order, so a slab needs neither double buffering nor barriers.  Loop order per
+//   candidate e: window reads(e+1) issued | row sums + test(e) | column sums(e+1) | slab write/read(e+1);
+//   the slab round trip is the one exposed latency, covered by the other two waves of the SIMD.
 
 constexpr int kPTW = 56, kPTH = 64;               // prefilter tile (pixels): 56 + 7 = 63 position columns <= 64 lanes
 constexpr int kPNT = 256;
-constexpr int kSeg = 16;                          // position rows whose column sums one thread produces
+constexpr int kSeg = 16;                          // pixel rows per wave
 constexpr int kSegD = kSeg + kB - 1;              // 23 distances per thread and candidate
-constexpr int kWinW = 96;                         // window pitch (texels): 64 lanes + 2R = 96
+constexpr int kWinW = 95;                         // window pitch (texels): 63 columns + 2R
 constexpr int kWinH = kPTH + kB - 1 + 2 * kR;     // 103 rows
-constexpr int kVP = 65;                           // V8 row pitch (floats), odd: a column of 32 rows spans 32 banks
-constexpr int kHOut = 14;                         // pixels per thread in stage H: 4 runs x 14 = 56
-constexpr int kHIn = kHOut + kB - 1;              // 21
+constexpr int kSlabP = 68;                        // slab row pitch (floats), = 4 mod 32
+constexpr int kRun = 7;                           // pixels per row-sum run: 8 runs x 7 = 56
+constexpr int kRunIn = kRun + kB - 1;             // 13
 constexpr int kListK = 32;              // recorded candidates per pixel.  A pseudo-random visiting order makes the
                                         // number of running minima ~Poisson(ln 1089 = 7.6) whatever the content:
                                         // P(> 32) ~ 1e-11 per pixel, so only genuinely tied content overflows
 constexpr float kRatio = 1.00008f;      // >= (1 + 3.6e-5) / (1 - 3.6e-5) with room for the product's rounding ("Bracket")
-static_assert(kPNT / 64 * kSeg == kPTH && kPNT / 64 * kHOut == kPTW, "stage maps cover the tile");
-static_assert(kPTW + kB - 1 <= 64 && kWinW >= 64 + 2 * kR, "one lane per position column");
+static_assert(kPNT / 64 * kSeg == kPTH && 8 * kRun == kPTW && kPTH == kTH, "stage maps cover the tile");
+static_assert(kPTW + kB - 1 <= 64 && kWinW >= kPTW + kB - 1 + 2 * kR, "one lane per position column");
 
 typedef const __attribute__((address_space(3))) uint32_t *lds_ro_u32_ptr;
 typedef const __attribute__((address_space(3))) float *lds_ro_f32_ptr;
 
-__global__ __launch_bounds__(kPNT, 2) void motion_prefilter_kernel(
+// order32[e] = candidate index (dy+R)*33 + (dx+R) in the low half, its window offset (dy+R)*kWinW + (dx+R)
+// in the high half; 32-bit entries so the wave-uniform reads are scalar loads.
+__global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int W, int H, float *__restrict__ listS, uint16_t *__restrict__ listC, float *__restrict__ uminOut,
     uint32_t *__restrict__ countOut, uint32_t *__restrict__ tileFlags, int flagTilesX,
-    const uint16_t *__restrict__ order) {
-    __shared__ uint32_t sWin[kWinH * kWinW];                           // 38.6 KB packed RGBA8 search window
-    __shared__ float sV[2][kPTH * kVP];                                // 2 x 16.3 KB column-sum planes
+    const uint32_t *__restrict__ order32) {
+    __shared__ uint32_t sWin[kWinH * kWinW];                           // 38.2 KB packed RGBA8 search window
+    __shared__ float sSlab[kPNT / 64][8 * kSlabP];                     // 4 x 2.1 KB
     __shared__ uint32_t sGiveUp;
 
     const int tid = threadIdx.x;
@@ -333,7 +342,7 @@ __global__ __launch_bounds__(kPNT, 2) void motion_prefilter_kernel(
         sWin[i] = v;
     }
 
-    // ---- stage AV set-up: this thread's 23 block positions (column bx0 + lane, rows by0 + 16 seg + j)
+    // ---- this thread's 23 block positions (column bx0 + lane, rows by0 + 16 seg + j)
     uint32_t c[kSegD], cc[kSegD];
     uint32_t valid = 0u;                                               // bit j: position j lies inside the image
     {
@@ -343,133 +352,144 @@ __global__ __launch_bounds__(kPNT, 2) void motion_prefilter_kernel(
             const int gy = by0 + kSeg * seg + j;
             const bool ok = gx >= 0 && gx < W && gy >= 0 && gy < H;
             c[j] = ok ? *reinterpret_cast<const uint32_t *>(curr + (size_t)gy * (size_t)currPitch + (size_t)gx * 4u) : 0u;
-            cc[j] = __builtin_amdgcn_udot4(c[j], c[j], 0u, false);
+            cc[j] = __builtin_amdgcn_udot4(c[j], c[j], 0x4B000000u, false);   // 2^23 + |c|^2 as float bits
             valid |= (ok ? 1u : 0u) << j;
         }
     }
     // Interior tiles: every block position the outputs use (columns 0..62) lies inside the image.
-    const bool interior = __builtin_amdgcn_readfirstlane(
-        (bx0 >= 0) && (bx0 + kPTW + kB - 2 < W) && (by0 >= 0) && (by0 + kPTH + kB - 2 < H));
+    const int borderTile = __builtin_amdgcn_readfirstlane(
+        !((bx0 >= 0) && (bx0 + kPTW + kB - 2 < W) && (by0 >= 0) && (by0 + kPTH + kB - 2 < H)));
 
-    // ---- stage AV, split in two so the window reads of candidate e+2 are in flight while e+1 is computed
-    auto windowPtr = [&](int cand) {
-        const int dyi = cand / kSide, dxi = cand - dyi * kSide;        // dy + R, dx + R (wave-uniform)
-        return (lds_ro_u32_ptr)(sWin + (kSeg * seg + dyi) * kWinW + dxi + lane);
-    };
-    auto fetchWindow = [&](uint32_t (&p)[kSegD], int cand) {
-        const lds_ro_u32_ptr w = windowPtr(cand);
+    __syncthreads();                       // window staged; the only workgroup barrier
+    if (ty0 + kSeg * seg >= H) return;     // this wave's rows lie below the image
+
+    const lds_ro_u32_ptr winBase = (lds_ro_u32_ptr)(sWin + (kSeg * seg) * kWinW + lane);
+    auto fetchWindow = [&](uint32_t (&p)[kSegD], uint32_t ord) {
+        const lds_ro_u32_ptr w = winBase + (ord >> 16);
 #pragma unroll
         for (int j = 0; j < kSegD; ++j) p[j] = w[j * kWinW];
     };
-    auto columnSums = [&](const uint32_t (&p)[kSegD], int buf, auto interiorTag) {
-        constexpr bool kInterior = decltype(interiorTag)::value;
-        int n[kSegD];
-#pragma unroll
-        for (int j = 0; j < kSegD; ++j) {
-            const uint32_t t = __builtin_amdgcn_udot4(p[j], p[j], cc[j], false);    // |c|^2 + |p|^2
-            const uint32_t cp = __builtin_amdgcn_udot4(c[j], p[j], 0u, false);      // c.p
-            // (no inline asm on dot results: a VALU op that reads a v_dot4 result needs 3 wait states on
-            //  gfx950, which only the compiler's hazard recogniser provides)
-            n[j] = (int)(t - 2u * cp);
-        }
+    auto columnSums = [&](const uint32_t (&p)[kSegD], float (&v8)[kSeg]) {
+        // n = |c|^2 + |p|^2 - 2 c.p without integer->float conversions or shifts (half-rate ops on gfx950):
+        // the dot products accumulate onto float bit patterns, 0x4B000000 + k = 2^23 + k and
+        // 0x4B800000 + k = 2^24 + 2k (k < 2^23), so two exact fp32 operations give n as a float.
+        // (No inline asm on dot results: a VALU op that reads a v_dot4 result needs 3 wait states on
+        //  gfx950, which only the compiler's hazard recogniser provides.)
         float d[kSegD];
 #pragma unroll
         for (int j = 0; j < kSegD; ++j) {
-            d[j] = __builtin_amdgcn_sqrtf((float)n[j]);
-            if (!kInterior) d[j] = ((valid >> j) & 1u) ? d[j] : 0.0f;  // position outside the image: skipped
+            const float f1 = __builtin_bit_cast(float, __builtin_amdgcn_udot4(p[j], p[j], cc[j], false));       // 2^23 + |c|^2 + |p|^2
+            const float f2 = __builtin_bit_cast(float, __builtin_amdgcn_udot4(c[j], p[j], 0x4B800000u, false)); // 2^24 + 2 c.p
+            const float n = (f1 - f2) + 8388608.0f;
+            d[j] = __builtin_amdgcn_sqrtf(n);
         }
-        float v2[kSegD - 1], v4[kSegD - 3], v8[kSeg];
+        // Border tiles only (one wave-uniform branch; the flag is laundered through an empty asm so the loop
+        // is not unswitched into two copies, which doubles the register pressure of the function).
+        int border = borderTile;
+        asm volatile("" : "+s"(border));
+        if (border) {
+#pragma unroll
+            for (int j = 0; j < kSegD; ++j) d[j] = ((valid >> j) & 1u) ? d[j] : 0.0f;   // position outside the image: skipped
+        }
+        float v2[kSegD - 1], v4[kSegD - 3];
 #pragma unroll
         for (int j = 0; j < kSegD - 1; ++j) v2[j] = d[j] + d[j + 1];
 #pragma unroll
         for (int j = 0; j < kSegD - 3; ++j) v4[j] = v2[j] + v2[j + 2];
 #pragma unroll
         for (int j = 0; j < kSeg; ++j) v8[j] = v4[j] + v4[j + 4];
-        float *dst = sV[buf] + (kSeg * seg) * kVP + lane;
-#pragma unroll
-        for (int j = 0; j < kSeg; ++j) dst[j * kVP] = v8[j];
     };
 
-    // ---- stage H: pixel row ty0 + lane, pixels tx0 + 14 seg + i.  thr[i] = kRatio * (smallest S~ so far):
-    //      a candidate can only be the exact minimum while S~ <= thr (see "Bracket").
-    const int py = ty0 + lane, px0 = tx0 + kHOut * seg;
-    float thr[kHOut];
-    uint32_t cnt4[(kHOut + 3) / 4];       // 8-bit counters
+    // ---- row sums: rows r8 and r8 + 8 of the wave's 16, pixels tx0 + 7 q .. + 6
+    const int r8 = lane & 7, q = lane >> 3;
+    const int px0 = tx0 + kRun * q;
+    float *const slabW = sSlab[seg] + lane;                            // write: row j, column lane
+    const lds_ro_f32_ptr slabR = (lds_ro_f32_ptr)(sSlab[seg] + r8 * kSlabP + kRun * q);
+    float thr[2][kRun];                   // kRatio * (smallest S~ so far); a candidate survives while S~ <= thr
+    uint32_t cnt4[2][2] = {{0u, 0u}, {0u, 0u}};                        // 8-bit counters
+    // List addressing: a wave-uniform 64-bit base (first pixel of the wave's rows) plus a 32-bit lane offset,
+    // so the rare append costs one add and the loop keeps two address registers, not fourteen pointers.
+    const size_t waveFirst = ((size_t)(ty0 + kSeg * seg) * (size_t)W + (size_t)tx0) * kListK;
+    float *const waveListS = listS + waveFirst;
+    uint16_t *const waveListC = listC + waveFirst;
+    uint32_t laneOff[2];
 #pragma unroll
-    for (int i = 0; i < (kHOut + 3) / 4; ++i) cnt4[i] = 0u;
+    for (int hb = 0; hb < 2; ++hb) {
+        const int py = ty0 + kSeg * seg + 8 * hb + r8;
+        laneOff[hb] = ((uint32_t)(8 * hb + r8) * (uint32_t)W + (uint32_t)(kRun * q)) * kListK;   // < 16 W K
 #pragma unroll
-    for (int i = 0; i < kHOut; ++i)       // pixels outside the image never pass the test (S~ >= 0 > -inf)
-        thr[i] = (py < H && px0 + i < W) ? __builtin_inff() : -__builtin_inff();
-    const size_t listBase = ((size_t)py * (size_t)W + (size_t)px0) * kListK;
-
-    auto fetchV = [&](float (&x)[kHIn], int buf) {
-        const lds_ro_f32_ptr src = (lds_ro_f32_ptr)(sV[buf] + lane * kVP + kHOut * seg);
+        for (int i = 0; i < kRun; ++i)    // pixels outside the image never pass the test (S~ >= 0 > -inf)
+            thr[hb][i] = (py < H && px0 + i < W) ? __builtin_inff() : -__builtin_inff();
+    }
+    bool overflow = false;
+    auto rowSumsAndTest = [&](const float (&x)[kRunIn], int hb, uint32_t cand) {
+        float h2[kRunIn - 1], h4[kRunIn - 3], s[kRun];
 #pragma unroll
-        for (int i = 0; i < kHIn; ++i) x[i] = src[i];
-    };
-    auto rowSumsAndTest = [&](const float (&x)[kHIn], int cand) {
-        float h2[kHIn - 1], h4[kHIn - 3], s[kHOut];
+        for (int i = 0; i < kRunIn - 1; ++i) h2[i] = x[i] + x[i + 1];
 #pragma unroll
-        for (int i = 0; i < kHIn - 1; ++i) h2[i] = x[i] + x[i + 1];
+        for (int i = 0; i < kRunIn - 3; ++i) h4[i] = h2[i] + h2[i + 2];
 #pragma unroll
-        for (int i = 0; i < kHIn - 3; ++i) h4[i] = h2[i] + h2[i + 2];
+        for (int i = 0; i < kRun; ++i) s[i] = h4[i] + h4[i + 4];
 #pragma unroll
-        for (int i = 0; i < kHOut; ++i) s[i] = h4[i] + h4[i + 4];
-        bool giveUp = false;
-#pragma unroll
-        for (int i = 0; i < kHOut; ++i) {
-            if (s[i] <= thr[i]) {                                      // rare: ~7.6 times per pixel in 1089
-                thr[i] = __builtin_fminf(thr[i], s[i] * kRatio);
-                const uint32_t n = (cnt4[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+        for (int i = 0; i < kRun; ++i) {
+            if (s[i] <= thr[hb][i]) {                                  // rare: ~7.6 times per pixel in 1089
+                thr[hb][i] = __builtin_fminf(thr[hb][i], s[i] * kRatio);
+                const uint32_t n = (cnt4[hb][i >> 2] >> (8 * (i & 3))) & 0xFFu;
                 if (n < (uint32_t)kListK) {
-                    const size_t at = listBase + (size_t)(i * kListK) + n;
-                    listS[at] = s[i];
-                    listC[at] = (uint16_t)cand;
-                    cnt4[i >> 2] += 1u << (8 * (i & 3));
+                    const uint32_t at = laneOff[hb] + n + (uint32_t)(i * kListK);
+                    waveListS[at] = s[i];
+                    waveListC[at] = (uint16_t)cand;
+                    cnt4[hb][i >> 2] += 1u << (8 * (i & 3));
                 } else {
-                    giveUp = true;
+                    overflow = true;
                 }
             }
         }
-        if (giveUp) sGiveUp = 1u;
+    };
+    // slab traffic of one candidate: rows 0-7 out, their transposed runs in, rows 8-15 out, runs in
+    auto transpose = [&](const float (&v8)[kSeg], float (&xa)[kRunIn], float (&xb)[kRunIn]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) slabW[j * kSlabP] = v8[j];
+#pragma unroll
+        for (int i = 0; i < kRunIn; ++i) xa[i] = slabR[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) slabW[j * kSlabP] = v8[8 + j];
+#pragma unroll
+        for (int i = 0; i < kRunIn; ++i) xb[i] = slabR[i];
     };
 
-    // ---- pipeline, one barrier per candidate e:  window reads of e+2 | column sums of e+1 -> V8[(e+1)&1] |
-    //      row sums and test of e from V8[e&1]
-    auto run = [&](auto interiorTag) -> bool {
-        uint32_t pa[kSegD], pb[kSegD];
-        __syncthreads();                   // window staged
-        fetchWindow(pa, order[0]);
-        fetchWindow(pb, order[1]);
-        columnSums(pa, 0, interiorTag);
-        __syncthreads();
-        for (int e = 0; e < kCand + 1; e += 2) {                       // kCand is odd: the last pair is half empty
-            float x[kHIn];
-            // even step: H(e) | AV(e+1) from pb | prefetch e+2 into pa
-            fetchV(x, 0);
-            if (e + 2 < kCand) fetchWindow(pa, order[e + 2]);
+    auto run = [&]() -> bool {
+        uint32_t p[kSegD];
+        float v8[kSeg], xa[kRunIn], xb[kRunIn];
+        uint32_t ordE = order32[0], ordN = order32[1];                 // candidates e, e+1 (scalar loads, one step ahead)
+        fetchWindow(p, ordE);
+        columnSums(p, v8);
+        transpose(v8, xa, xb);
+        for (int e = 0; e < kCand; ++e) {
+            const uint32_t ordNN = order32[min(e + 2, kCand - 1)];
+            if (e + 1 < kCand) fetchWindow(p, ordN);                   // candidate e+1: reads in flight ...
+            rowSumsAndTest(xa, 0, ordE & 0xFFFFu);                     // ... while candidate e is finished
+            rowSumsAndTest(xb, 1, ordE & 0xFFFFu);
             __builtin_amdgcn_sched_barrier(0);
-            if (e + 1 < kCand) columnSums(pb, 1, interiorTag);
-            rowSumsAndTest(x, order[e]);
-            __syncthreads();
-            if (sGiveUp != 0u) return true;                            // uniform: read after the barrier
-            if (e + 1 >= kCand) break;
-            // odd step: H(e+1) | AV(e+2) from pa | prefetch e+3 into pb
-            fetchV(x, 1);
-            if (e + 3 < kCand) fetchWindow(pb, order[e + 3]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (e + 2 < kCand) columnSums(pa, 0, interiorTag);
-            rowSumsAndTest(x, order[e + 1]);
-            __syncthreads();
-            if (sGiveUp != 0u) return true;
+            if (e + 1 < kCand) {
+                columnSums(p, v8);
+                transpose(v8, xa, xb);
+            }
+            ordE = ordN; ordN = ordNN;
+            if ((e & 15) == 15) {                                      // lists full somewhere in the tile: stop early
+                if (__builtin_amdgcn_readfirstlane(__ballot(overflow) != 0ull)) sGiveUp = 1u;
+                if (*(volatile uint32_t *)&sGiveUp != 0u) return true;
+            }
         }
-        return false;
+        return __builtin_amdgcn_readfirstlane(__ballot(overflow) != 0ull);
     };
-    const bool gaveUp = interior ? run(std::true_type{}) : run(std::false_type{});
+    const bool gaveUp = run();
     if (gaveUp) {
         // Flags live on the exact kernel's 64 x 64 tile grid (cleared before this launch): this tile spans
-        // one or two of its columns.  Racing writers all store 1.
-        if (tid == 0) {
+        // one or two of its columns.  Racing writers all store 1.  Sibling waves that already finished have
+        // written their thresholds and counts; the resolve kernel ignores flagged tiles.
+        if (lane == 0) {
+            sGiveUp = 1u;
             const int ex0 = tx0 / kTW, ex1 = min(tx0 + kPTW - 1, W - 1) / kTW;
             tileFlags[blockIdx.y * flagTilesX + ex0] = 1u;
             tileFlags[blockIdx.y * flagTilesX + ex1] = 1u;
@@ -477,11 +497,15 @@ __global__ __launch_bounds__(kPNT, 2) void motion_prefilter_kernel(
         return;
     }
 #pragma unroll
-    for (int i = 0; i < kHOut; ++i) {
-        if (py < H && px0 + i < W) {
-            const size_t gp = (size_t)py * (size_t)W + (size_t)(px0 + i);
-            uminOut[gp] = thr[i];
-            countOut[gp] = (cnt4[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+    for (int hb = 0; hb < 2; ++hb) {
+        const int py = ty0 + kSeg * seg + 8 * hb + r8;
+#pragma unroll
+        for (int i = 0; i < kRun; ++i) {
+            if (py < H && px0 + i < W) {
+                const size_t gp = (size_t)py * (size_t)W + (size_t)(px0 + i);
+                uminOut[gp] = thr[hb][i];
+                countOut[gp] = (cnt4[hb][i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            }
         }
     }
 }
@@ -569,12 +593,13 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, MotionWorkspaceLa
     l.count = align(l.umin + px * sizeof(float));
     l.tileFlags = align(l.count + px * sizeof(uint32_t));
     l.order = align(l.tileFlags + tiles * sizeof(uint32_t));
-    l.total = align(l.order + kCand * sizeof(uint16_t));
+    l.total = align(l.order + kCand * sizeof(uint32_t));
     if (layout) *layout = l;
     return l.total;
 }
 
-void motion_candidate_order(uint16_t *order) {
+void motion_candidate_order(uint32_t *order32) {
+    uint16_t order[kCand];
     // A fixed pseudo-random permutation (Fisher-Yates driven by a 32-bit LCG).  Visiting the candidates in
     // an order unrelated to their position makes the sequence of costs behave like a random sample, so a
     // pixel sees only ~ln(1089) running minima -- for smooth content and for image borders alike, where a
@@ -586,6 +611,10 @@ void motion_candidate_order(uint16_t *order) {
         const int j = (int)((state >> 8) % (uint32_t)(i + 1));
         const uint16_t t = order[i]; order[i] = order[j]; order[j] = t;
     }
+    for (int i = 0; i < kCand; ++i) {      // low half: candidate index, high half: its offset in the LDS window
+        const uint32_t dyi = order[i] / kSide, dxi = order[i] % kSide;
+        order32[i] = order[i] | ((dyi * kWinW + dxi) << 16);
+    }
 }
 
 hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
@@ -596,7 +625,7 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
     float *umin = reinterpret_cast<float *>(workspace + l.umin);
     uint32_t *count = reinterpret_cast<uint32_t *>(workspace + l.count);
     uint32_t *flags = reinterpret_cast<uint32_t *>(workspace + l.tileFlags);
-    const uint16_t *order = reinterpret_cast<const uint16_t *>(workspace + l.order);
+    const uint32_t *order = reinterpret_cast<const uint32_t *>(workspace + l.order);
     static_assert(kPTH == kTH, "prefilter tiles and exact tiles share their rows");
     hipError_t e = hipMemsetAsync(flags, 0, (size_t)tilesX * tilesY * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;

@@ -13,7 +13,7 @@ from linux_fg_amd import capi, synth  # noqa: E402
 stage = sys.argv[1] if len(sys.argv) > 1 else "pipeline"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 content = sys.argv[3] if len(sys.argv) > 3 else "translated"
-w, h = 1920, 1080
+w, h = (int(v) for v in os.environ.get("LFG_STAGE_INPUT", "1920x1080").split("x"))
 W, H = 2 * w, 2 * h
 ctx = capi.Context(0)
 prev_in = synth.make_prev(w, h, synth.BASE_SEED)
