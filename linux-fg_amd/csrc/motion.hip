@@ -309,6 +309,7 @@ constexpr int kListK = 32;              // recorded candidates per pixel.  A pse
                                         // P(> 32) ~ 1e-11 per pixel, so only genuinely tied content overflows
 constexpr float kRatio = 1.00008f;      // >= (1 + 3.6e-5) / (1 - 3.6e-5) with room for the product's rounding ("Bracket")
 static_assert(kPNT / 64 * kSeg == kPTH && 8 * kRun == kPTW && kPTH == kTH, "stage maps cover the tile");
+static_assert(kRunIn == 2 * kRun, "row-sum inputs pair up as (x_i, x_{i+7})");
 static_assert(kPTW + kB - 1 <= 64 && kWinW >= kPTW + kB - 1 + 2 * kR, "one lane per position column");
 
 typedef const __attribute__((address_space(3))) uint32_t *lds_ro_u32_ptr;
@@ -365,39 +366,71 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
 
     const lds_ro_u32_ptr winBase = (lds_ro_u32_ptr)(sWin + (kSeg * seg) * kWinW + lane);
     auto fetchWindow = [&](uint32_t (&p)[kSegD], uint32_t ord) {
+#if defined(LFG_EXP) && (LFG_EXP & 8)      // experiment: no window reads
+#pragma unroll
+        for (int j = 0; j < kSegD; ++j) p[j] = c[j] + ord + j;
+        return;
+#endif
         const lds_ro_u32_ptr w = winBase + (ord >> 16);
 #pragma unroll
         for (int j = 0; j < kSegD; ++j) p[j] = w[j * kWinW];
     };
+    // Packed fp32 throughout (v_pk_add_f32: two adds per issue slot; a wave issues one VALU op per four
+    // cycles whatever its width): position j is paired with position j + 12, so every level of the sliding
+    // tree is "pair j + pair j+k" with a few scalar adds where the two halves meet.
+    constexpr int kHalf = 12;
+    static_assert(kSegD == 2 * kHalf - 1, "pairing (j, j+12) covers 23 positions with position 11 alone");
     auto columnSums = [&](const uint32_t (&p)[kSegD], float (&v8)[kSeg]) {
         // n = |c|^2 + |p|^2 - 2 c.p without integer->float conversions or shifts (half-rate ops on gfx950):
         // the dot products accumulate onto float bit patterns, 0x4B000000 + k = 2^23 + k and
         // 0x4B800000 + k = 2^24 + 2k (k < 2^23), so two exact fp32 operations give n as a float.
         // (No inline asm on dot results: a VALU op that reads a v_dot4 result needs 3 wait states on
         //  gfx950, which only the compiler's hazard recogniser provides.)
-        float d[kSegD];
+#if defined(LFG_EXP) && (LFG_EXP & 16)     // experiment: no dot products
+        auto f1of = [&](int j) { return __builtin_bit_cast(float, p[j] + cc[j]); };
+        auto f2of = [&](int j) { return __builtin_bit_cast(float, p[j] & c[j]); };
+#else
+        auto f1of = [&](int j) { return __builtin_bit_cast(float, __builtin_amdgcn_udot4(p[j], p[j], cc[j], false)); };        // 2^23 + |c|^2 + |p|^2
+        auto f2of = [&](int j) { return __builtin_bit_cast(float, __builtin_amdgcn_udot4(c[j], p[j], 0x4B800000u, false)); };  // 2^24 + 2 c.p
+#endif
+        const f32x2 kBias = {8388608.0f, 8388608.0f};
+        f32x2 A[kHalf - 1];                                            // (d_j, d_{j+12}), j = 0..10
 #pragma unroll
-        for (int j = 0; j < kSegD; ++j) {
-            const float f1 = __builtin_bit_cast(float, __builtin_amdgcn_udot4(p[j], p[j], cc[j], false));       // 2^23 + |c|^2 + |p|^2
-            const float f2 = __builtin_bit_cast(float, __builtin_amdgcn_udot4(c[j], p[j], 0x4B800000u, false)); // 2^24 + 2 c.p
-            const float n = (f1 - f2) + 8388608.0f;
-            d[j] = __builtin_amdgcn_sqrtf(n);
+        for (int j = 0; j < kHalf - 1; ++j) {
+            const f32x2 F1 = {f1of(j), f1of(j + kHalf)}, F2 = {f2of(j), f2of(j + kHalf)};
+            const f32x2 N = (F1 - F2) + kBias;
+#if defined(LFG_EXP) && (LFG_EXP & 4)      // experiment: no sqrt
+            A[j] = N;
+#else
+            A[j] = f32x2{__builtin_amdgcn_sqrtf(N.x), __builtin_amdgcn_sqrtf(N.y)};
+#endif
         }
+        float dMid = __builtin_amdgcn_sqrtf((f1of(kHalf - 1) - f2of(kHalf - 1)) + 8388608.0f);   // d_11
         // Border tiles only (one wave-uniform branch; the flag is laundered through an empty asm so the loop
         // is not unswitched into two copies, which doubles the register pressure of the function).
         int border = borderTile;
         asm volatile("" : "+s"(border));
-        if (border) {
+        if (border) {                      // position outside the image: skipped by the shader, adds 0 here
 #pragma unroll
-            for (int j = 0; j < kSegD; ++j) d[j] = ((valid >> j) & 1u) ? d[j] : 0.0f;   // position outside the image: skipped
+            for (int j = 0; j < kHalf - 1; ++j) {
+                A[j].x = ((valid >> j) & 1u) ? A[j].x : 0.0f;
+                A[j].y = ((valid >> (j + kHalf)) & 1u) ? A[j].y : 0.0f;
+            }
+            dMid = ((valid >> (kHalf - 1)) & 1u) ? dMid : 0.0f;
         }
-        float v2[kSegD - 1], v4[kSegD - 3];
+        f32x2 B[kHalf - 2], G[kHalf - 4], C[kHalf - 8];
 #pragma unroll
-        for (int j = 0; j < kSegD - 1; ++j) v2[j] = d[j] + d[j + 1];
+        for (int j = 0; j < kHalf - 2; ++j) B[j] = A[j] + A[j + 1];    // (v2_j, v2_{j+12}), j = 0..9
+        const float v2_10 = A[10].x + dMid, v2_11 = dMid + A[0].y;
 #pragma unroll
-        for (int j = 0; j < kSegD - 3; ++j) v4[j] = v2[j] + v2[j + 2];
+        for (int j = 0; j < kHalf - 4; ++j) G[j] = B[j] + B[j + 2];    // (v4_j, v4_{j+12}), j = 0..7
+        const float v4_8 = B[8].x + v2_10, v4_9 = B[9].x + v2_11, v4_10 = v2_10 + B[0].y, v4_11 = v2_11 + B[1].y;
 #pragma unroll
-        for (int j = 0; j < kSeg; ++j) v8[j] = v4[j] + v4[j + 4];
+        for (int j = 0; j < kHalf - 8; ++j) C[j] = G[j] + G[j + 4];    // (v8_j, v8_{j+12}), j = 0..3
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v8[j] = C[j].x; v8[j + kHalf] = C[j].y; }
+        v8[4] = G[4].x + v4_8;  v8[5] = G[5].x + v4_9;  v8[6] = G[6].x + v4_10;  v8[7] = G[7].x + v4_11;
+        v8[8] = v4_8 + G[0].y;  v8[9] = v4_9 + G[1].y;  v8[10] = v4_10 + G[2].y; v8[11] = v4_11 + G[3].y;
     };
 
     // ---- row sums: rows r8 and r8 + 8 of the wave's 16, pixels tx0 + 7 q .. + 6
@@ -422,45 +455,80 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
             thr[hb][i] = (py < H && px0 + i < W) ? __builtin_inff() : -__builtin_inff();
     }
     bool overflow = false;
-    auto rowSumsAndTest = [&](const float (&x)[kRunIn], int hb, uint32_t cand) {
-        float h2[kRunIn - 1], h4[kRunIn - 3], s[kRun];
+    // One run of 14 inputs -> 7 sums, inputs paired (x_i, x_{i+7}) as the slab reads deliver them.
+    auto runSums = [&](const f32x2 (&X)[kRun], float (&sOut)[kRun]) {
+        f32x2 H2[kRun - 1], H4[kRun - 3];
 #pragma unroll
-        for (int i = 0; i < kRunIn - 1; ++i) h2[i] = x[i] + x[i + 1];
+        for (int i = 0; i < kRun - 1; ++i) H2[i] = X[i] + X[i + 1];    // (h2_i, h2_{i+7}), i = 0..5
+        const float h2_6 = X[6].x + X[0].y;
 #pragma unroll
-        for (int i = 0; i < kRunIn - 3; ++i) h4[i] = h2[i] + h2[i + 2];
+        for (int i = 0; i < kRun - 3; ++i) H4[i] = H2[i] + H2[i + 2];  // (h4_i, h4_{i+7}), i = 0..3
+        const float h4_4 = H2[4].x + h2_6, h4_5 = H2[5].x + H2[0].y, h4_6 = h2_6 + H2[1].y;
+        sOut[0] = H4[0].x + h4_4;   sOut[1] = H4[1].x + h4_5;   sOut[2] = H4[2].x + h4_6;
+        sOut[3] = H4[3].x + H4[0].y; sOut[4] = h4_4 + H4[1].y;  sOut[5] = h4_5 + H4[2].y;  sOut[6] = h4_6 + H4[3].y;
+    };
+    // The test is two-level: all fourteen comparisons first (VALU -> scalar masks, pipelined), then one
+    // SCALAR branch per pixel column; only a taken branch (about one in five) touches EXEC.  A divergent
+    // `if` per pixel costs ~6 VALU slots each in compare -> saveexec -> branch latency (tools/bench_intops.hip).
+    auto rowSumsAndTest = [&](const f32x2 (&XA)[kRun], const f32x2 (&XB)[kRun], uint32_t cand) {
+        float sv[2][kRun];
+        runSums(XA, sv[0]);
+        runSums(XB, sv[1]);
+#if defined(LFG_EXP) && (LFG_EXP & 1)      // experiment: no tests
 #pragma unroll
-        for (int i = 0; i < kRun; ++i) s[i] = h4[i] + h4[i + 4];
+        for (int i = 0; i < kRun; ++i) { thr[0][i] += sv[0][i]; thr[1][i] += sv[1][i]; }
+        return;
+#endif
+        unsigned long long hit[2][kRun];
 #pragma unroll
-        for (int i = 0; i < kRun; ++i) {
-            if (s[i] <= thr[hb][i]) {                                  // rare: ~7.6 times per pixel in 1089
-                thr[hb][i] = __builtin_fminf(thr[hb][i], s[i] * kRatio);
-                const uint32_t n = (cnt4[hb][i >> 2] >> (8 * (i & 3))) & 0xFFu;
-                if (n < (uint32_t)kListK) {
-                    const uint32_t at = laneOff[hb] + n + (uint32_t)(i * kListK);
-                    waveListS[at] = s[i];
-                    waveListC[at] = (uint16_t)cand;
-                    cnt4[hb][i >> 2] += 1u << (8 * (i & 3));
-                } else {
-                    overflow = true;
+        for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+            for (int i = 0; i < kRun; ++i) hit[hb][i] = __ballot(sv[hb][i] <= thr[hb][i]);
+        }
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+            for (int i = 0; i < kRun; ++i) {
+                if (hit[hb][i] != 0ull) {                              // wave-uniform
+                    asm volatile("; some lane records a candidate");  // keeps this a scalar branch of its own
+                    const float s = sv[hb][i];
+                    if (s <= thr[hb][i]) {                             // rare: ~7.6 times per pixel in 1089
+                        thr[hb][i] = __builtin_fminf(thr[hb][i], s * kRatio);
+                        const uint32_t n = (cnt4[hb][i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                        if (n < (uint32_t)kListK) {
+                            const uint32_t at = laneOff[hb] + n + (uint32_t)(i * kListK);
+                            waveListS[at] = s;
+                            waveListC[at] = (uint16_t)cand;
+                            cnt4[hb][i >> 2] += 1u << (8 * (i & 3));
+                        } else {
+                            overflow = true;
+                        }
+                    }
                 }
             }
         }
     };
     // slab traffic of one candidate: rows 0-7 out, their transposed runs in, rows 8-15 out, runs in
-    auto transpose = [&](const float (&v8)[kSeg], float (&xa)[kRunIn], float (&xb)[kRunIn]) {
+    auto transpose = [&](const float (&v8)[kSeg], f32x2 (&XA)[kRun], f32x2 (&XB)[kRun]) {
+#if defined(LFG_EXP) && (LFG_EXP & 2)      // experiment: no slab round trip
+#pragma unroll
+        for (int i = 0; i < kRun; ++i) { XA[i] = f32x2{v8[i], v8[i + 7]}; XB[i] = f32x2{v8[i + 2], v8[i + 9]}; }
+        return;
+#endif
 #pragma unroll
         for (int j = 0; j < 8; ++j) slabW[j * kSlabP] = v8[j];
 #pragma unroll
-        for (int i = 0; i < kRunIn; ++i) xa[i] = slabR[i];
+        for (int i = 0; i < kRun; ++i) XA[i] = f32x2{slabR[i], slabR[i + kRun]};
 #pragma unroll
         for (int j = 0; j < 8; ++j) slabW[j * kSlabP] = v8[8 + j];
 #pragma unroll
-        for (int i = 0; i < kRunIn; ++i) xb[i] = slabR[i];
+        for (int i = 0; i < kRun; ++i) XB[i] = f32x2{slabR[i], slabR[i + kRun]};
     };
 
     auto run = [&]() -> bool {
         uint32_t p[kSegD];
-        float v8[kSeg], xa[kRunIn], xb[kRunIn];
+        float v8[kSeg];
+        f32x2 xa[kRun], xb[kRun];
         uint32_t ordE = order32[0], ordN = order32[1];                 // candidates e, e+1 (scalar loads, one step ahead)
         fetchWindow(p, ordE);
         columnSums(p, v8);
@@ -468,8 +536,7 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
         for (int e = 0; e < kCand; ++e) {
             const uint32_t ordNN = order32[min(e + 2, kCand - 1)];
             if (e + 1 < kCand) fetchWindow(p, ordN);                   // candidate e+1: reads in flight ...
-            rowSumsAndTest(xa, 0, ordE & 0xFFFFu);                     // ... while candidate e is finished
-            rowSumsAndTest(xb, 1, ordE & 0xFFFFu);
+            rowSumsAndTest(xa, xb, ordE & 0xFFFFu);                    // ... while candidate e is finished
             __builtin_amdgcn_sched_barrier(0);
             if (e + 1 < kCand) {
                 columnSums(p, v8);
@@ -548,24 +615,35 @@ __global__ __launch_bounds__(256) void motion_resolve_kernel(
     const size_t gp = (size_t)py * (size_t)W + (size_t)px;
     const float bound = uminIn[gp];
     const uint32_t n = min(countIn[gp], (uint32_t)kListK);
-    float bestV = __builtin_inff();
-    uint32_t bestC = 0xFFFFFFFFu;
-    // Lanes find their next surviving entry independently and only then meet in the expensive exact
-    // evaluation, so a wave runs it max-over-lanes(survivors) times (typically once), not once per list
-    // position that holds a survivor for some lane.
-    uint32_t k = 0;
-    for (;;) {
-        uint32_t cand = 0xFFFFFFFFu;
-        while (k < n) {
-            const float st = listS[gp * kListK + k];
-            const uint32_t c = listC[gp * kListK + k];
-            ++k;
-            if (st <= bound) { cand = c; break; }
+    // A single survivor IS the shader's answer (the exact minimiser always survives), no evaluation needed.
+    uint32_t survivors = 0u, firstK = 0u;
+    for (uint32_t k = 0; k < n; ++k) {
+        if (listS[gp * kListK + k] <= bound) {
+            if (survivors == 0u) firstK = k;
+            ++survivors;
         }
-        if (cand == 0xFFFFFFFFu) break;
-        const int dyi = (int)cand / kSide, dxi = (int)cand - dyi * kSide;
-        const float v = exact_cost(prev, prevPitch, curr, currPitch, W, H, px, py, dxi - kR, dyi - kR);
-        if (v < bestV || (v == bestV && cand < bestC)) { bestV = v; bestC = cand; }
+    }
+    uint32_t bestC = listC[gp * kListK + firstK];
+    if (survivors > 1u) {
+        // Several candidates within the bracket of the minimum: the literal chain decides.  Lanes find their
+        // next surviving entry independently and only then meet in the expensive exact evaluation, so a wave
+        // runs it max-over-lanes(survivors) times, not once per list position that holds a survivor for some lane.
+        float bestV = __builtin_inff();
+        bestC = 0xFFFFFFFFu;
+        uint32_t k = firstK;
+        for (;;) {
+            uint32_t cand = 0xFFFFFFFFu;
+            while (k < n) {
+                const float st = listS[gp * kListK + k];
+                const uint32_t c = listC[gp * kListK + k];
+                ++k;
+                if (st <= bound) { cand = c; break; }
+            }
+            if (cand == 0xFFFFFFFFu) break;
+            const int dyi = (int)cand / kSide, dxi = (int)cand - dyi * kSide;
+            const float v = exact_cost(prev, prevPitch, curr, currPitch, W, H, px, py, dxi - kR, dyi - kR);
+            if (v < bestV || (v == bestV && cand < bestC)) { bestV = v; bestC = cand; }
+        }
     }
     const int dyi = (int)bestC / kSide, dxi = (int)bestC - dyi * kSide;
     int8_t *dst = mv + (size_t)py * (size_t)mvPitch + (size_t)px * 2u;

@@ -2,6 +2,7 @@
 // (gfx950): 16 independent accumulators per lane, 2 waves per SIMD.  Prints lane-ops/s relative to v_add_f32.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
@@ -13,7 +14,7 @@
         for (int it = 0; it < ITERS; ++it) {                                                           \
             _Pragma("unroll") for (int r = 0; r < 8; ++r) {                                            \
                 _Pragma("unroll") for (int i = 0; i < 16; ++i)                                         \
-                    asm volatile(ASMSTR : "+v"(a[i]) : "v"(x), "v"(y));                                \
+                    asm volatile(ASMSTR : "+v"(a[i]) : "v"(x), "v"(y) : "s40", "s41", "s42", "s43", "vcc", "scc");                                \
             }                                                                                          \
         }                                                                                              \
         unsigned s = 0;                                                                                \
@@ -49,6 +50,12 @@ CHAIN_KERNEL(k_cmp_sgpr, "v_cmp_le_f32 s[40:41], %0, %1")
 CHAIN_KERNEL(k_cnd_sgpr, "v_cndmask_b32 %0, %0, %1, s[40:41]")
 CHAIN_KERNEL(k_cmp_cnd, "v_cmp_le_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %2, vcc")
 CHAIN_KERNEL(k_min3, "v_min3_f32 %0, %0, %1, %2")
+CHAIN_KERNEL(k_add_salu, "v_add_f32 %0, %0, %1\n s_add_u32 s40, s40, 1")
+CHAIN_KERNEL(k_add_2salu, "v_add_f32 %0, %0, %1\n s_add_u32 s40, s40, 1\n s_and_b64 s[42:43], s[42:43], exec")
+CHAIN_KERNEL(k_dot_salu, "v_dot4_u32_u8 %0, %1, %2, %0\n s_add_u32 s40, s40, 1")
+CHAIN_KERNEL(k_add_nop, "v_add_f32 %0, %0, %1\n s_nop 0")
+CHAIN_KERNEL(k_add_branch, "v_add_f32 %0, %0, %1\n s_cbranch_execz 1f\n 1:")
+CHAIN_KERNEL(k_cmp_saveexec, "v_cmp_le_f32 vcc, %0, %1\n s_and_saveexec_b64 s[42:43], vcc\n s_cbranch_execz 2f\n 2: s_or_b64 exec, exec, s[42:43]")
 CHAIN_KERNEL(k_dot4_add, "v_dot4_u32_u8 %0, %1, %2, %0\n v_add_u32 %0, %0, %1")
 
 template <typename K>
@@ -67,12 +74,13 @@ static double time_kernel(K launch, int reps) {
 }
 
 int main() {
+    setvbuf(stdout, nullptr, _IOLBF, 0);
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     unsigned *out;
     CK(hipMalloc(&out, 256 * 16 * 1024 * sizeof(unsigned)));
     constexpr int IT = 1000;
-    for (int wps : {2}) {
+    for (int wps : {2, 3}) {
         const int blocks = prop.multiProcessorCount * wps;
         const double insts = (double)blocks * 256 * IT * 8 * 16;
 #define RUN(K, PER) { double t = time_kernel([&] { hipLaunchKernelGGL(K<IT>, dim3(blocks), dim3(256), 0, 0, out, 3u); }, 5); \
@@ -82,6 +90,7 @@ int main() {
         RUN(k_mul_f32, 1) RUN(k_fma_f32, 1) RUN(k_sub_f32, 1) RUN(k_sub_u32, 1) RUN(k_lshlrev, 1) RUN(k_and, 1) RUN(k_max_f32, 1)
         RUN(k_mov, 1) RUN(k_add3, 1) RUN(k_cvt_i32, 1) RUN(k_cvt_ub0, 1) RUN(k_cmp_vcc, 1) RUN(k_cmp_sgpr, 1) RUN(k_cnd_sgpr, 1)
         RUN(k_cmp_cnd, 2) RUN(k_min3, 1)
+        RUN(k_add_salu, 1) RUN(k_add_2salu, 1) RUN(k_dot_salu, 1) RUN(k_add_nop, 1) RUN(k_add_branch, 1) RUN(k_cmp_saveexec, 1)
     }
     return 0;
 }

@@ -1,0 +1,23 @@
+#!/bin/bash
+# On the GPU box: motion-stage time (HIP events via bench stage profile) for each build_variants/lib_*.so.
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cp $R/linux-fg_amd/liblinuxfg_hip.so /tmp/lib_base.so
+for f in /tmp/lib_base.so $R/build_variants/lib_*.so; do
+  cp "$f" $R/linux-fg_amd/liblinuxfg_hip.so
+  python3 - <<PY
+import sys, time
+sys.path.insert(0, '$R')
+from linux_fg_amd import capi, synth
+ctx = capi.Context(0)
+W, H = 3840, 2160
+prev = synth.make_prev(W, H, seed=synth.BASE_SEED); curr = synth.translate(prev, (3, -2), synth.BASE_SEED)
+P, C = ctx.frame_from(prev), ctx.frame_from(curr); M = ctx.create_frame(W, H, capi.FORMAT_MV_S8X2)
+ctx.motion(P, C, M); ctx.sync()
+ctx.profile_enable(True); ctx.profile_reset()
+for _ in range(5): ctx.motion(P, C, M)
+ctx.sync()
+ms, n = ctx.profile_get(capi.STAGE_MOTION)
+print('$f'.split('/')[-1], round(ms / n, 3), 'ms per motion call')
+PY
+done
+cp /tmp/lib_base.so $R/linux-fg_amd/liblinuxfg_hip.so
