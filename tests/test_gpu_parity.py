@@ -179,6 +179,70 @@ def test_motion_4k_translation_property(ctx, oracle):
         assert (got[y0:y1, x0:x1] == want[y0:y1, x0:x1]).all(), roi
 
 
+def run_motion_mode(ctx, prev, curr, mode):
+    from linux_fg_amd import capi
+    ctx.set_motion_mode(mode)
+    try:
+        out = run_motion(ctx, prev, curr)
+        stats = ctx.motion_last_stats() if mode == capi.MOTION_PREFILTERED else None
+    finally:
+        ctx.set_motion_mode(capi.MOTION_PREFILTERED)
+    return out, stats
+
+
+def _adversarial_pairs():
+    """Frame pairs aimed at the prefilter's error bracket (csrc/motion.hip, "Bracket") and its bookkeeping."""
+    rng = np.random.default_rng(77)
+    w, h = 200, 150                                    # 4 x 3 prefilter tiles, all partial at the far edges
+    hi = rng.integers(254, 256, size=(h, w, 4), dtype=np.uint8)          # byte differences of 1 at the top of the
+    hi2 = rng.integers(254, 256, size=(h, w, 4), dtype=np.uint8)         # range: largest fp32 error of a texel difference
+    lo = rng.integers(0, 2, size=(h, w, 4), dtype=np.uint8)
+    lo2 = rng.integers(0, 2, size=(h, w, 4), dtype=np.uint8)
+    noise = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    noise2 = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    # periodic texture: many candidates with almost the same cost (period 4 in x, 6 in y) plus faint noise
+    yy, xx = np.mgrid[0:h, 0:w]
+    tex = ((xx % 4) * 40 + (yy % 6) * 20).astype(np.uint8)
+    per = np.stack([tex, tex // 2, 255 - tex, np.full_like(tex, 255)], -1)
+    per2 = per.copy()
+    per2[..., 0] ^= rng.integers(0, 2, size=(h, w), dtype=np.uint8)
+    # half flat (every candidate ties: list overflow -> exact fallback), half noise
+    mix = noise.copy(); mix[:, : w // 2] = (10, 20, 30, 255)
+    mix2 = noise2.copy(); mix2[:, : w // 2] = (10, 20, 30, 255)
+    return {"high bytes": (hi, hi2), "low bytes": (lo, lo2), "noise": (noise, noise2),
+            "periodic": (per, per2), "flat + noise": (mix, mix2)}
+
+
+@pytest.mark.parametrize("name", ["high bytes", "low bytes", "noise", "periodic", "flat + noise"])
+def test_motion_prefilter_bracket_adversarial(ctx, oracle, name):
+    """The prefiltered path must return the oracle's MVs on content built to stress its bracket: unit byte
+    differences at both ends of the range, uncorrelated noise, near-tied periodic texture, and flat areas
+    that overflow the candidate lists (those tiles must come back through the exact kernel)."""
+    from linux_fg_amd import capi
+    prev, curr = _adversarial_pairs()[name]
+    want = as_int(oracle.motion(prev, curr))
+    got, stats = run_motion_mode(ctx, prev, curr, capi.MOTION_PREFILTERED)
+    assert (got == want).all(), f"{(got != want).any(-1).sum()} pixels differ ({name}, stats {stats})"
+    exact, _ = run_motion_mode(ctx, prev, curr, capi.MOTION_EXACT_ONLY)
+    assert (exact == want).all()
+    if name == "flat + noise":
+        assert stats[1] > 0, "flat half should have fallen back to the exact kernel"
+    if name == "noise":
+        assert stats[1] == 0, "uncorrelated noise must not overflow the lists"
+
+
+@pytest.mark.parametrize("wh", [(56, 64), (57, 65), (113, 129), (300, 70), (64, 200)])
+def test_motion_prefilter_equals_exact_kernel_on_ragged_sizes(ctx, wh):
+    """Prefilter tiles are 56 x 64, exact tiles 64 x 64: sizes around their multiples, both modes identical."""
+    from linux_fg_amd import capi
+    w, h = wh
+    prev = synth.make_prev(w, h, seed=w * 1000 + h)
+    curr = synth.translate(prev, (-4, 3), seed=w * 1000 + h)
+    a, _ = run_motion_mode(ctx, prev, curr, capi.MOTION_PREFILTERED)
+    b, _ = run_motion_mode(ctx, prev, curr, capi.MOTION_EXACT_ONLY)
+    assert (a == b).all()
+
+
 def test_exact_sqrt_exhaustive(ctx):
     """csrc/motion.hip: exact_sqrt (one Newton step on v_rsq_f32) against the compiler's IEEE sqrtf for
     every float from 2^-21 to 8 (the motion kernel feeds it sums of four squares in [0, 4], the
