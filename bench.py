@@ -65,25 +65,29 @@ def algorithmic_bytes(stage: str, w_in: int, h_in: int, w: int, h: int) -> int:
     raise ValueError(stage)
 
 
-def pmc_traffic(kernel_prefix: str):
-    """HBM bytes per launch of `kernel_prefix` from the newest committed two-pass PMC summary
-    (profiles/rNN_hbm_traffic_pmc.txt: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3
-    passes, values in KB).  bench.py cannot run the profiler on itself; None if no summary exists."""
+def pmc_traffic(kernel_prefixes):
+    """HBM bytes per launch of the kernels whose names start with one of `kernel_prefixes`, summed, from the
+    newest committed two-pass PMC summary (profiles/rNN_hbm_traffic_pmc.txt: FETCH_SIZE and WRITE_SIZE
+    collected in separate rocprofv3 passes, values in KB).  bench.py cannot run the profiler on itself;
+    None if no summary exists."""
     import glob
     import re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.txt")))
     if not files:
         return None, None
+    if isinstance(kernel_prefixes, str):
+        kernel_prefixes = [kernel_prefixes]
     vals, cur = {}, None
     for line in open(files[-1]):
         m = re.match(r"^(?:void )?(lfg::\w+)", line)
         if m:
             cur = m.group(1)
         m = re.match(r"^\s+(FETCH_SIZE|WRITE_SIZE)\s+([0-9.e+]+)", line)
-        if m and cur and cur.startswith(kernel_prefix):
-            vals[m.group(1)] = float(m.group(2)) * 1024.0
-    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
-        return int(vals["FETCH_SIZE"] + vals["WRITE_SIZE"]), os.path.relpath(files[-1], ROOT)
+        if m and cur and any(cur.startswith(k) for k in kernel_prefixes):
+            vals[(cur, m.group(1))] = float(m.group(2)) * 1024.0        # the last block of a kernel wins
+    have = {k for k, _ in vals}
+    if have and all((k, c) in vals for k in have for c in ("FETCH_SIZE", "WRITE_SIZE")):
+        return int(sum(vals.values())), os.path.relpath(files[-1], ROOT)
     return None, None
 
 
@@ -233,6 +237,9 @@ def main():
         for k in range(steps):
             step(k)
         torch.cuda.synchronize(dev)
+    motion_stats = None
+    if args.workload == "pipeline" and os.environ.get("LFG_MOTION_MODE", "0") != "1":
+        motion_stats = ctx.motion_last_stats()        # after the timed region: it synchronises and copies counters
     stage_ms = {}
     for name, sid in (("scale", capi.STAGE_SCALE), ("motion", capi.STAGE_MOTION), ("interpolate", capi.STAGE_INTERPOLATE)):
         ms, n = ctx.profile_get(sid)
@@ -259,12 +266,25 @@ def main():
         if dominant == "motion":
             fl = motion_flops(w, h)
             tf = fl / (stage_ms["motion"] * 1e-3) / 1e12
-            roofline = {"kernel": "motion_tiled_8_16_kernel", "bound": "valu", "achieved": round(tf, 2),
+            exact_only = os.environ.get("LFG_MOTION_MODE", "0") == "1"
+            roofline = {"kernel": ("motion_tiled_8_16_kernel" if exact_only else
+                                   "motion_prefilter_kernel (+ motion_resolve_kernel + motion_tiled_8_16_kernel on flagged tiles)"),
+                        "bound": "valu", "achieved": round(tf, 2),
                         "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_VALU_PEAK_TFLOPS, 4),
                         "traffic": None,
-                        "note": ("motion.comp is fp32-VALU bound, not HBM bound (SURVEY.md F7): flops = W*H*1089*(64 adds "
-                                 "+ 12 per distance); the 157.3 TFLOP/s peak counts an FMA as 2, an add-only stream "
-                                 "tops out at 78.65; the same kernel against HBM is in stages.motion")}
+                        "algorithmic_flops": fl,
+                        "note": ("motion.comp is fp32-VALU bound, not HBM bound (SURVEY.md F7).  achieved = ALGORITHMIC flops of "
+                                 "the shader (W*H*1089*(64 adds + 12 per distance)) / duration of the whole lfg_motion call (HIP "
+                                 "events around its launches).  The default path does not execute all of them: an exact bracket "
+                                 "on the cost rules out all but ~1 candidate per pixel before the literal 64-add chain is "
+                                 "needed (DESIGN.md, motion); LFG_MOTION_MODE=1 runs the literal kernel alone.  The 157.3 "
+                                 "TFLOP/s peak counts an FMA as 2; an add-only stream tops out at 78.65.")}
+            if motion_stats is not None:
+                roofline["motion_mode"] = "prefiltered"
+                roofline["fallback_tiles"] = {"of": motion_stats[0], "exact_kernel": motion_stats[1]}
+                roofline["candidates_recorded_per_pixel"] = round(motion_stats[2], 2)
+            else:
+                roofline["motion_mode"] = "exact kernel only"
         else:
             s = stages[dominant]
             roofline = {"kernel": {"scale": "scale_2x_kernel", "interpolate": "interpolate_kernel"}[dominant],
@@ -272,8 +292,8 @@ def main():
                         "frac": s["hbm_frac"], "traffic": None}
         size_name = {"540p": "540p->1080p", "1080p": "1080p->4K", "4k": "4K->8K", "8k": "8K->16K"}[args.input]
         if args.input == "1080p":
-            t, src = pmc_traffic({"motion_tiled_8_16_kernel": "lfg::motion_tiled", "scale_2x_kernel": "lfg::scale_2x",
-                                  "interpolate_kernel": "lfg::interpolate"}[roofline["kernel"]])
+            t, src = pmc_traffic(["lfg::motion_tiled", "lfg::motion_prefilter", "lfg::motion_resolve"] if dominant == "motion"
+                                 else {"scale_2x_kernel": "lfg::scale_2x", "interpolate_kernel": "lfg::interpolate"}[roofline["kernel"]])
             if t is not None:
                 roofline["traffic"] = t
                 roofline["traffic_source"] = (f"{src}: FETCH_SIZE + WRITE_SIZE from two separate rocprofv3 --pmc passes, bytes per "

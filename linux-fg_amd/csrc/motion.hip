@@ -319,7 +319,7 @@ typedef const __attribute__((address_space(3))) float *lds_ro_f32_ptr;
 // in the high half; 32-bit entries so the wave-uniform reads are scalar loads.
 __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
-    int W, int H, float *__restrict__ listS, uint16_t *__restrict__ listC, float *__restrict__ uminOut,
+    int W, int H, uint2 *__restrict__ list, float *__restrict__ uminOut,
     uint32_t *__restrict__ countOut, uint32_t *__restrict__ tileFlags, int flagTilesX,
     const uint32_t *__restrict__ order32) {
     __shared__ uint32_t sWin[kWinH * kWinW];                           // 38.2 KB packed RGBA8 search window
@@ -439,22 +439,23 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     float *const slabW = sSlab[seg] + lane;                            // write: row j, column lane
     const lds_ro_f32_ptr slabR = (lds_ro_f32_ptr)(sSlab[seg] + r8 * kSlabP + kRun * q);
     float thr[2][kRun];                   // kRatio * (smallest S~ so far); a candidate survives while S~ <= thr
-    uint32_t cnt4[2][2] = {{0u, 0u}, {0u, 0u}};                        // 8-bit counters
-    // List addressing: a wave-uniform 64-bit base (first pixel of the wave's rows) plus a 32-bit lane offset,
-    // so the rare append costs one add and the loop keeps two address registers, not fourteen pointers.
-    const size_t waveFirst = ((size_t)(ty0 + kSeg * seg) * (size_t)W + (size_t)tx0) * kListK;
-    float *const waveListS = listS + waveFirst;
-    uint16_t *const waveListC = listC + waveFirst;
+    uint32_t cnt2[2][(kRun + 1) / 2];                                  // 16-bit counters (1089 events at most)
+    // Records {S~ bits, candidate}: record k of pixel (x, y) lives at list[(y * kListK + k) * W + x] -- K planes
+    // per image row, so the resolve kernel reads record k of 64 neighbouring pixels as one 512-byte line.
+    // Address = wave-uniform base + 32-bit lane offset; k * W is a 24-bit multiply.
+    uint2 *const waveList = list + ((size_t)(ty0 + kSeg * seg) * (size_t)kListK * (size_t)W + (size_t)tx0);
     uint32_t laneOff[2];
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
         const int py = ty0 + kSeg * seg + 8 * hb + r8;
-        laneOff[hb] = ((uint32_t)(8 * hb + r8) * (uint32_t)W + (uint32_t)(kRun * q)) * kListK;   // < 16 W K
+        laneOff[hb] = (uint32_t)(8 * hb + r8) * (uint32_t)(kListK * W) + (uint32_t)(kRun * q);   // < 16 K W
+#pragma unroll
+        for (int i = 0; i < (kRun + 1) / 2; ++i) cnt2[hb][i] = 0u;
 #pragma unroll
         for (int i = 0; i < kRun; ++i)    // pixels outside the image never pass the test (S~ >= 0 > -inf)
             thr[hb][i] = (py < H && px0 + i < W) ? __builtin_inff() : -__builtin_inff();
     }
-    bool overflow = false;
+    uint32_t maxCount = 0u;               // largest per-pixel count of this lane (lists hold kListK; more = give up)
     // One run of 14 inputs -> 7 sums, inputs paired (x_i, x_{i+7}) as the slab reads deliver them.
     auto runSums = [&](const f32x2 (&X)[kRun], float (&sOut)[kRun]) {
         f32x2 H2[kRun - 1], H4[kRun - 3];
@@ -493,16 +494,16 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
                     asm volatile("; some lane records a candidate");  // keeps this a scalar branch of its own
                     const float s = sv[hb][i];
                     if (s <= thr[hb][i]) {                             // rare: ~7.6 times per pixel in 1089
-                        thr[hb][i] = __builtin_fminf(thr[hb][i], s * kRatio);
-                        const uint32_t n = (cnt4[hb][i >> 2] >> (8 * (i & 3))) & 0xFFu;
-                        if (n < (uint32_t)kListK) {
-                            const uint32_t at = laneOff[hb] + n + (uint32_t)(i * kListK);
-                            waveListS[at] = s;
-                            waveListC[at] = (uint16_t)cand;
-                            cnt4[hb][i >> 2] += 1u << (8 * (i & 3));
-                        } else {
-                            overflow = true;
-                        }
+                        float t;
+                        asm("v_min_f32 %0, %1, %2" : "=v"(t) : "v"(thr[hb][i]), "v"(s * kRatio));   // no NaNs here
+                        thr[hb][i] = t;
+                        const uint32_t n = (cnt2[hb][i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+                        // past the end of the list the last slot is overwritten; the count keeps growing and
+                        // flags the tile
+                        const uint32_t at = __umul24(min(n, (uint32_t)kListK - 1u), (uint32_t)W) + laneOff[hb] + (uint32_t)i;
+                        waveList[at] = uint2{__builtin_bit_cast(uint32_t, s), cand};
+                        cnt2[hb][i >> 1] += 1u << (16 * (i & 1));
+                        maxCount = max(maxCount, n + 1u);
                     }
                 }
             }
@@ -544,11 +545,11 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
             }
             ordE = ordN; ordN = ordNN;
             if ((e & 15) == 15) {                                      // lists full somewhere in the tile: stop early
-                if (__builtin_amdgcn_readfirstlane(__ballot(overflow) != 0ull)) sGiveUp = 1u;
+                if (__builtin_amdgcn_readfirstlane(__ballot(maxCount > (uint32_t)kListK) != 0ull)) sGiveUp = 1u;
                 if (*(volatile uint32_t *)&sGiveUp != 0u) return true;
             }
         }
-        return __builtin_amdgcn_readfirstlane(__ballot(overflow) != 0ull);
+        return __builtin_amdgcn_readfirstlane(__ballot(maxCount > (uint32_t)kListK) != 0ull);
     };
     const bool gaveUp = run();
     if (gaveUp) {
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
             if (py < H && px0 + i < W) {
                 const size_t gp = (size_t)py * (size_t)W + (size_t)(px0 + i);
                 uminOut[gp] = thr[hb][i];
-                countOut[gp] = (cnt4[hb][i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                countOut[gp] = (cnt2[hb][i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
             }
         }
     }
@@ -605,25 +606,26 @@ __device__ float exact_cost(const uint8_t *__restrict__ prev, int prevPitch, con
 
 __global__ __launch_bounds__(256) void motion_resolve_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
-    int8_t *__restrict__ mv, int mvPitch, int W, int H, const float *__restrict__ listS,
-    const uint16_t *__restrict__ listC, const float *__restrict__ uminIn, const uint32_t *__restrict__ countIn, const uint32_t *__restrict__ tileFlags,
+    int8_t *__restrict__ mv, int mvPitch, int W, int H, const uint2 *__restrict__ list,
+    const float *__restrict__ uminIn, const uint32_t *__restrict__ countIn, const uint32_t *__restrict__ tileFlags,
     int tilesX) {
     const int px = blockIdx.x * 64 + (threadIdx.x & 63);
     const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (px >= W || py >= H) return;
     if (tileFlags[(py / kTH) * tilesX + px / kTW] != 0u) return;       // this tile goes through the exact kernel
     const size_t gp = (size_t)py * (size_t)W + (size_t)px;
+    const uint2 *const rowList = list + (size_t)py * (size_t)kListK * (size_t)W + (size_t)px;   // record k: rowList[k * W]
     const float bound = uminIn[gp];
     const uint32_t n = min(countIn[gp], (uint32_t)kListK);
     // A single survivor IS the shader's answer (the exact minimiser always survives), no evaluation needed.
     uint32_t survivors = 0u, firstK = 0u;
     for (uint32_t k = 0; k < n; ++k) {
-        if (listS[gp * kListK + k] <= bound) {
+        if (__builtin_bit_cast(float, rowList[(size_t)k * (size_t)W].x) <= bound) {
             if (survivors == 0u) firstK = k;
             ++survivors;
         }
     }
-    uint32_t bestC = listC[gp * kListK + firstK];
+    uint32_t bestC = rowList[(size_t)firstK * (size_t)W].y;
     if (survivors > 1u) {
         // Several candidates within the bracket of the minimum: the literal chain decides.  Lanes find their
         // next surviving entry independently and only then meet in the expensive exact evaluation, so a wave
@@ -634,8 +636,9 @@ __global__ __launch_bounds__(256) void motion_resolve_kernel(
         for (;;) {
             uint32_t cand = 0xFFFFFFFFu;
             while (k < n) {
-                const float st = listS[gp * kListK + k];
-                const uint32_t c = listC[gp * kListK + k];
+                const uint2 rec = rowList[(size_t)k * (size_t)W];
+                const float st = __builtin_bit_cast(float, rec.x);
+                const uint32_t c = rec.y;
                 ++k;
                 if (st <= bound) { cand = c; break; }
             }
@@ -666,8 +669,8 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, MotionWorkspaceLa
     auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
     MotionWorkspaceLayout l;
     l.list = 0;
-    l.listC = align(l.list + px * kListK * sizeof(float));
-    l.umin = align(l.listC + px * kListK * sizeof(uint16_t));
+    l.listC = 0;                                                      // (unused: records carry their candidate)
+    l.umin = align(l.list + px * kListK * sizeof(uint2));
     l.count = align(l.umin + px * sizeof(float));
     l.tileFlags = align(l.count + px * sizeof(uint32_t));
     l.order = align(l.tileFlags + tiles * sizeof(uint32_t));
@@ -698,8 +701,7 @@ void motion_candidate_order(uint32_t *order32) {
 hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                           const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &l) {
     const int tilesX = ((int)curr.width + kTW - 1) / kTW, tilesY = ((int)curr.height + kTH - 1) / kTH;
-    float *listS = reinterpret_cast<float *>(workspace + l.list);
-    uint16_t *listC = reinterpret_cast<uint16_t *>(workspace + l.listC);
+    uint2 *list = reinterpret_cast<uint2 *>(workspace + l.list);
     float *umin = reinterpret_cast<float *>(workspace + l.umin);
     uint32_t *count = reinterpret_cast<uint32_t *>(workspace + l.count);
     uint32_t *flags = reinterpret_cast<uint32_t *>(workspace + l.tileFlags);
@@ -709,12 +711,12 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(motion_prefilter_kernel, dim3(((int)curr.width + kPTW - 1) / kPTW, tilesY), dim3(kPNT), 0, s,
                        (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
-                       (int)curr.width, (int)curr.height, listS, listC, umin, count, flags, tilesX, order);
+                       (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, order);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(motion_resolve_kernel, dim3((curr.width + 63) / 64, (curr.height + 3) / 4), dim3(256), 0, s,
                        (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
-                       (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, listS, listC, umin, count, flags, tilesX);
+                       (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     return launch_motion_tiled_8_16(s, prev, curr, mv, flags);
