@@ -312,7 +312,8 @@ static_assert(kPNT / 64 * kSeg == kPTH && 8 * kRun == kPTW && kPTH == kTH, "stag
 static_assert(kRunIn == 2 * kRun, "row-sum inputs pair up as (x_i, x_{i+7})");
 static_assert(kPTW + kB - 1 <= 64 && kWinW >= kPTW + kB - 1 + 2 * kR, "one lane per position column");
 
-typedef const __attribute__((address_space(3))) uint32_t *lds_ro_u32_ptr;
+typedef const volatile __attribute__((address_space(3))) uint32_t *lds_ro_u32_ptr;   // volatile: keep 23 ds_read_b32 with
+                                                                 // immediate offsets (merged ds_read2 pairs need ten extra address adds)
 typedef const __attribute__((address_space(3))) float *lds_ro_f32_ptr;
 
 // order32[e] = candidate index (dy+R)*33 + (dx+R) in the low half, its window offset (dy+R)*kWinW + (dx+R)
@@ -494,16 +495,24 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
                     asm volatile("; some lane records a candidate");  // keeps this a scalar branch of its own
                     const float s = sv[hb][i];
                     if (s <= thr[hb][i]) {                             // rare: ~7.6 times per pixel in 1089
+                        // S~ == 0 means every distance is exactly 0, so the shader's cost is exactly 0 too: the
+                        // answer is the first such candidate in scan order.  Its index goes into the threshold
+                        // itself (0x00800000 + cand: a tiny normal float, below every non-zero S~ >= 1), nothing
+                        // is appended -- static or flat areas, where many candidates cost 0, never fill the lists.
+                        const bool zero = s == 0.0f;
+                        const float cap = zero ? __builtin_bit_cast(float, 0x00800000u + cand) : s * kRatio;
                         float t;
-                        asm("v_min_f32 %0, %1, %2" : "=v"(t) : "v"(thr[hb][i]), "v"(s * kRatio));   // no NaNs here
+                        asm("v_min_f32 %0, %1, %2" : "=v"(t) : "v"(thr[hb][i]), "v"(cap));   // no NaNs here
                         thr[hb][i] = t;
-                        const uint32_t n = (cnt2[hb][i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
-                        // past the end of the list the last slot is overwritten; the count keeps growing and
-                        // flags the tile
-                        const uint32_t at = __umul24(min(n, (uint32_t)kListK - 1u), (uint32_t)W) + laneOff[hb] + (uint32_t)i;
-                        waveList[at] = uint2{__builtin_bit_cast(uint32_t, s), cand};
-                        cnt2[hb][i >> 1] += 1u << (16 * (i & 1));
-                        maxCount = max(maxCount, n + 1u);
+                        if (!zero) {
+                            const uint32_t n = (cnt2[hb][i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+                            // past the end of the list the last slot is overwritten; the count keeps growing and
+                            // flags the tile
+                            const uint32_t at = __umul24(min(n, (uint32_t)kListK - 1u), (uint32_t)W) + laneOff[hb] + (uint32_t)i;
+                            waveList[at] = uint2{__builtin_bit_cast(uint32_t, s), cand};
+                            cnt2[hb][i >> 1] += 1u << (16 * (i & 1));
+                            maxCount = max(maxCount, n + 1u);
+                        }
                     }
                 }
             }
@@ -546,7 +555,7 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
             ordE = ordN; ordN = ordNN;
             if ((e & 15) == 15) {                                      // lists full somewhere in the tile: stop early
                 if (__builtin_amdgcn_readfirstlane(__ballot(maxCount > (uint32_t)kListK) != 0ull)) sGiveUp = 1u;
-                if (*(volatile uint32_t *)&sGiveUp != 0u) return true;
+                if (__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)&sGiveUp) != 0) return true;   // keeps the loop uniform
             }
         }
         return __builtin_amdgcn_readfirstlane(__ballot(maxCount > (uint32_t)kListK) != 0ull);
@@ -617,6 +626,14 @@ __global__ __launch_bounds__(256) void motion_resolve_kernel(
     const uint2 *const rowList = list + (size_t)py * (size_t)kListK * (size_t)W + (size_t)px;   // record k: rowList[k * W]
     const float bound = uminIn[gp];
     const uint32_t n = min(countIn[gp], (uint32_t)kListK);
+    if (bound < 0.5f) {                    // a zero-cost candidate exists; the first one in scan order is encoded here
+        const uint32_t zc = __builtin_bit_cast(uint32_t, bound) - 0x00800000u;
+        const int zdy = (int)zc / kSide, zdx = (int)zc - zdy * kSide;
+        int8_t *zdst = mv + (size_t)py * (size_t)mvPitch + (size_t)px * 2u;
+        zdst[0] = (int8_t)(zdx - kR);
+        zdst[1] = (int8_t)(zdy - kR);
+        return;
+    }
     // A single survivor IS the shader's answer (the exact minimiser always survives), no evaluation needed.
     uint32_t survivors = 0u, firstK = 0u;
     for (uint32_t k = 0; k < n; ++k) {
@@ -691,6 +708,11 @@ void motion_candidate_order(uint32_t *order32) {
         state = state * 1664525u + 1013904223u;
         const int j = (int)((state >> 8) % (uint32_t)(i + 1));
         const uint16_t t = order[i]; order[i] = order[j]; order[j] = t;
+    }
+    // ... except that zero motion goes first: static areas (where m = 0 costs exactly 0) then close their
+    // threshold at once, before the exactly tied candidates at the rim of a flat area can fill the lists.
+    for (int i = 0; i < kCand; ++i) {
+        if (order[i] == kR * kSide + kR) { order[i] = order[0]; order[0] = (uint16_t)(kR * kSide + kR); break; }
     }
     for (int i = 0; i < kCand; ++i) {      // low half: candidate index, high half: its offset in the LDS window
         const uint32_t dyi = order[i] / kSide, dxi = order[i] % kSide;

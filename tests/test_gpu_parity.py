@@ -206,18 +206,22 @@ def _adversarial_pairs():
     per = np.stack([tex, tex // 2, 255 - tex, np.full_like(tex, 255)], -1)
     per2 = per.copy()
     per2[..., 0] ^= rng.integers(0, 2, size=(h, w), dtype=np.uint8)
-    # half flat (every candidate ties: list overflow -> exact fallback), half noise
+    # half flat with a brightness change (every candidate ties at a NON-zero cost: list overflow -> exact
+    # fallback), half noise
     mix = noise.copy(); mix[:, : w // 2] = (10, 20, 30, 255)
-    mix2 = noise2.copy(); mix2[:, : w // 2] = (10, 20, 30, 255)
+    mix2 = noise2.copy(); mix2[:, : w // 2] = (12, 20, 30, 255)
+    # static frame with flat areas: many zero-cost candidates per pixel, which must NOT need the fallback
+    stat = noise.copy(); stat[40:110, 30:150] = (90, 90, 90, 255); stat[:, 160:] = 0
     return {"high bytes": (hi, hi2), "low bytes": (lo, lo2), "noise": (noise, noise2),
-            "periodic": (per, per2), "flat + noise": (mix, mix2)}
+            "periodic": (per, per2), "flat + noise": (mix, mix2), "static with flat areas": (stat, stat.copy())}
 
 
-@pytest.mark.parametrize("name", ["high bytes", "low bytes", "noise", "periodic", "flat + noise"])
+@pytest.mark.parametrize("name", ["high bytes", "low bytes", "noise", "periodic", "flat + noise", "static with flat areas"])
 def test_motion_prefilter_bracket_adversarial(ctx, oracle, name):
     """The prefiltered path must return the oracle's MVs on content built to stress its bracket: unit byte
-    differences at both ends of the range, uncorrelated noise, near-tied periodic texture, and flat areas
-    that overflow the candidate lists (those tiles must come back through the exact kernel)."""
+    differences at both ends of the range, uncorrelated noise, near-tied periodic texture, flat areas tied at
+    a non-zero cost that overflow the candidate lists (those tiles must come back through the exact kernel), and a
+    static frame whose flat areas give many zero-cost candidates (handled without lists or fallback)."""
     from linux_fg_amd import capi
     prev, curr = _adversarial_pairs()[name]
     want = as_int(oracle.motion(prev, curr))
@@ -227,8 +231,21 @@ def test_motion_prefilter_bracket_adversarial(ctx, oracle, name):
     assert (exact == want).all()
     if name == "flat + noise":
         assert stats[1] > 0, "flat half should have fallen back to the exact kernel"
-    if name == "noise":
-        assert stats[1] == 0, "uncorrelated noise must not overflow the lists"
+    if name in ("noise", "static with flat areas"):       # (zero motion is visited first: static rims stay cheap)
+        assert stats[1] == 0, f"{name} must not overflow the lists"
+
+
+def test_motion_prefilter_zero_cost_candidates_need_no_fallback(ctx, oracle):
+    """Static frames: a flat one (all 1089 candidates cost exactly 0 in the interior) and a noisy one (only m = 0
+    does).  The zero-cost rule keeps both off the exact kernel and still returns the oracle's first-in-scan-order
+    answer."""
+    from linux_fg_amd import capi
+    flat = np.empty((130, 120, 4), np.uint8); flat[...] = (33, 66, 99, 255)
+    noisy = np.random.default_rng(5).integers(0, 256, size=(130, 120, 4), dtype=np.uint8)
+    for frame in (flat, noisy):
+        got, stats = run_motion_mode(ctx, frame, frame.copy(), capi.MOTION_PREFILTERED)
+        assert (got == as_int(oracle.motion(frame, frame))).all()
+        assert stats[1] == 0, stats
 
 
 @pytest.mark.parametrize("wh", [(56, 64), (57, 65), (113, 129), (300, 70), (64, 200)])
