@@ -1,0 +1,34 @@
+#!/bin/bash
+# Runs on the MI355X box (gpurun): regenerates every file profiles/README.md lists into gpurun_out/profiles_new/.
+# usage: tools/collect_profiles.sh rNN
+set -e
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/profiles_new
+rm -rf $OUT && mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+stats() {   # $1 = name, rest = bench args [env prefix via LFG_MOTION_MODE]
+  local name=$1; shift
+  rm -rf /tmp/prof_$name
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python3 $R/bench.py "$@" --no-cpu-baseline \
+      > $OUT/${TAG}_${name}_bench_under_rocprof.json 2> /tmp/prof_$name.err
+  cp $(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${name}_kernel_stats.csv
+}
+stats pipeline --steps 10 --warmup 2
+stats scale --workload scale
+LFG_MOTION_MODE=1 stats pipeline_exact_only --steps 5 --warmup 1
+echo "kernel stats done"
+python3 $R/bench.py --steps 10 --warmup 2 > $OUT/${TAG}_pipeline_bench.json 2> /tmp/bench.err
+python3 $R/bench.py --workload scale > $OUT/${TAG}_scale_bench.json 2>> /tmp/bench.err
+echo "bench done"
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_$c
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+done
+python3 $R/tools/pmc_summary.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE | sed "s#/tmp/##" > $OUT/${TAG}_hbm_traffic_pmc.txt
+for c in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT"; do
+  rm -rf /tmp/pmc_sq
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_sq -- python3 $R/tools/run_stage.py motion 2 > /dev/null 2>&1
+done
+python3 $R/tools/pmc_summary.py /tmp/pmc_sq | sed "s#/tmp/##" > $OUT/${TAG}_motion_sq_counters.txt
+echo "pmc done"; ls -la $OUT
