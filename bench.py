@@ -11,6 +11,11 @@ frame pair per GPU, inputs already resident in HBM:
       scale(curr 1080p -> 4K)  ->  motion(prev4K, curr4K; blockSize 8, searchRadius 16)
       ->  interpolate(prev4K, curr4K, mv, t = 0.5)          = one interpolated 4K frame
   scale (BASELINE config 2): the Lanczos kernel alone, 1080p -> 4K, one upscaled frame per step.
+  pipeline_input_res (labelled variant): the reference's own data flow keeps prev/curr at input
+      resolution (src/scaler.cpp:443,451), so motion + interpolate run at 1080p and both the real and the
+      generated frame are upscaled: motion(prev, curr) -> interpolate -> scale(curr) + scale(interpolated).
+      Same deliverables per step (one real and one generated 4K frame) but NOT the same pixels as the
+      north_star order; never the headline value.
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), launched by torch.distributed.run.
 Frame pairs are independent, so the work shards one pair per GPU with no data-path collective except
@@ -45,7 +50,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", choices=["pipeline", "scale"], default="pipeline")
+    ap.add_argument("--workload", choices=["pipeline", "scale", "pipeline_input_res"], default="pipeline")
     ap.add_argument("--input", choices=list(SIZES), default="1080p", help="input size; output is 2x")
     ap.add_argument("--factors", default="0.5", help="comma-separated interpolation factors per pair")
     ap.add_argument("--content", choices=["translated", "uncorrelated"], default="translated")
@@ -113,7 +118,11 @@ def cpu_baseline(w_in, h_in, w, h, factors, workload):
         return {"value": 1.0 / t_scale, "unit": "upscaled frames/s", "cores": threads, "kind": "port",
                 "sample": f"oracle scale.comp restatement on {band} of {h} output rows at {w_in}x{h_in}->{w}x{h}, "
                           f"extrapolated by rows; {threads} threads"}
-    # motion + interpolate at output resolution on synthetic frames of that size
+    # motion + interpolate at output resolution (input resolution for the labelled variant) on synthetic frames
+    n_scales = 1
+    if workload == "pipeline_input_res":
+        w, h = w_in, h_in
+        n_scales = 1 + len(factors)
     prev, curr = synth.make_pair(w, h, stream=0)
     mw, mh = min(512, w // 2), min(512, h // 2)                      # crop away from the borders: ~6 s at 16 threads
     t0 = time.perf_counter()
@@ -124,9 +133,9 @@ def cpu_baseline(w_in, h_in, w, h, factors, workload):
     t0 = time.perf_counter()
     oracle.interpolate(prev, curr, mv_roi, 0.5, roi=(0, 0, w, iband), threads=threads)
     t_interp = (time.perf_counter() - t0) * (h / iband)
-    t_pair = t_scale + t_motion + len(factors) * t_interp
+    t_pair = n_scales * t_scale + t_motion + len(factors) * t_interp
     return {"value": len(factors) / t_pair, "unit": "interpolated frames/s", "cores": threads, "kind": "port",
-            "sample": (f"oracle (CPU restatement of the reference shaders, not lavapipe): scale on {band}/{h} rows, "
+            "sample": (f"oracle (CPU restatement of the reference shaders, not lavapipe): {n_scales} x scale on {band}/{2 * h_in} rows, "
                        f"motion on a {mw}x{mh}-pixel crop of the {w}x{h} frame, interpolate on {iband}/{h} rows, "
                        f"each extrapolated by area; {threads} threads; per-frame seconds scale/motion/interpolate = "
                        f"{t_scale:.3f}/{t_motion:.1f}/{t_interp:.3f}")}
@@ -192,6 +201,9 @@ def main():
     t_curr4, f_curr4 = empty_frame(w, h)
     t_out, f_out = empty_frame(w, h)
     t_mv, f_mv = empty_frame(w, h, capi.FORMAT_MV_S8X2)
+    if args.workload == "pipeline_input_res":
+        t_mv_in, f_mv_in = empty_frame(w_in, h_in, capi.FORMAT_MV_S8X2)
+        t_mid_in, f_mid_in = empty_frame(w_in, h_in)
     prev_slots = [empty_frame(w, h) for _ in range(2 if world > 1 else 1)]
     for _, f in prev_slots:
         ctx.scale(f_prev_in, f)                     # rank 0's copy is the broadcast source
@@ -204,6 +216,13 @@ def main():
         # the shared previous 4K frame of this step (waits for its RCCL broadcast, issues the next one)
         t_prev4 = shared_prev.acquire(k)
         f_prev4 = prev_slots[[t.data_ptr() for t, _ in prev_slots].index(t_prev4.data_ptr())][1]
+        if args.workload == "pipeline_input_res":
+            ctx.motion(f_prev_in, f_curr_in, f_mv_in, 8, 16.0)
+            ctx.scale(f_curr_in, f_curr4)
+            for t in factors:
+                ctx.interpolate(f_prev_in, f_curr_in, f_mv_in, f_mid_in, t)
+                ctx.scale(f_mid_in, f_out)
+            return
         ctx.scale(f_curr_in, f_curr4)
         if args.workload == "pipeline":
             ctx.motion(f_prev4, f_curr4, f_mv, 8, 16.0)
@@ -220,7 +239,7 @@ def main():
     for k in range(warmup):
         step(k)
     ctx.profile_reset()
-    ctx.profile_enable(args.workload == "pipeline")   # events around every stage launch (ms-scale kernels)
+    ctx.profile_enable(args.workload != "scale")      # events around every stage launch (ms-scale kernels)
     barrier_sync()
     t0 = time.perf_counter()
     for k in range(warmup, warmup + steps):
@@ -238,7 +257,7 @@ def main():
             step(k)
         torch.cuda.synchronize(dev)
     motion_stats = None
-    if args.workload == "pipeline" and os.environ.get("LFG_MOTION_MODE", "0") != "1":
+    if args.workload != "scale" and os.environ.get("LFG_MOTION_MODE", "0") != "1":
         motion_stats = ctx.motion_last_stats()        # after the timed region: it synchronises and copies counters
     stage_ms = {}
     for name, sid in (("scale", capi.STAGE_SCALE), ("motion", capi.STAGE_MOTION), ("interpolate", capi.STAGE_INTERPOLATE)):
@@ -252,19 +271,21 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    units_per_step = len(factors) if args.workload == "pipeline" else 1
+    units_per_step = 1 if args.workload == "scale" else len(factors)
+    in_res = args.workload == "pipeline_input_res"
+    mw, mh = (w_in, h_in) if in_res else (w, h)        # resolution motion and interpolate run at
     value = world * steps * units_per_step / elapsed
 
     if rank == 0:
         stages = {}
         for name, avg in stage_ms.items():
-            b = algorithmic_bytes(name, w_in, h_in, w, h)
+            b = algorithmic_bytes(name, w_in, h_in, w if name == "scale" else mw, h if name == "scale" else mh)
             gbs = b / (avg * 1e-3) / 1e9
             stages[name] = {"avg_ms": round(avg, 5), "algorithmic_bytes": b, "hbm_gbs": round(gbs, 1),
                             "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
         dominant = max(stage_ms, key=stage_ms.get)
         if dominant == "motion":
-            fl = motion_flops(w, h)
+            fl = motion_flops(mw, mh)
             tf = fl / (stage_ms["motion"] * 1e-3) / 1e12
             exact_only = os.environ.get("LFG_MOTION_MODE", "0") == "1"
             roofline = {"kernel": ("motion_tiled_8_16_kernel" if exact_only else
@@ -291,17 +312,22 @@ def main():
                         "bound": "hbm", "achieved": s["hbm_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": s["hbm_frac"], "traffic": None}
         size_name = {"540p": "540p->1080p", "1080p": "1080p->4K", "4k": "4K->8K", "8k": "8K->16K"}[args.input]
-        if args.input == "1080p":
+        if args.input == "1080p" and not in_res:
             t, src = pmc_traffic(["lfg::motion_tiled", "lfg::motion_prefilter", "lfg::motion_resolve"] if dominant == "motion"
                                  else {"scale_2x_kernel": "lfg::scale_2x", "interpolate_kernel": "lfg::interpolate"}[roofline["kernel"]])
             if t is not None:
                 roofline["traffic"] = t
                 roofline["traffic_source"] = (f"{src}: FETCH_SIZE + WRITE_SIZE from two separate rocprofv3 --pmc passes, bytes per "
                                               "launch; FETCH_SIZE raw (uncalibrated for 4-byte-per-lane loads)")
-        total_bytes = sum(algorithmic_bytes(n, w_in, h_in, w, h) * (len(factors) if n == "interpolate" else 1)
+        def launches(n):        # per step
+            if n == "interpolate":
+                return len(factors)
+            return 1 + len(factors) if (n == "scale" and in_res) else 1
+        total_bytes = sum(algorithmic_bytes(n, w_in, h_in, w if n == "scale" else mw, h if n == "scale" else mh) * launches(n)
                           for n in stage_ms)
         line = {
             "metric": (f"interpolated frames/s, {size_name} RGBA8" if args.workload == "pipeline"
+                       else f"interpolated frames/s, {size_name} RGBA8 (variant: motion + interpolate at input resolution)" if in_res
                        else f"upscaled frames/s, {size_name} RGBA8 (Lanczos only)"),
             "value": round(value, 3),
             "unit": "frames/s",
@@ -310,8 +336,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 arithmetic on u8 RGBA (u8 in, u8 out; int8 motion vectors)",
             "data": "synthetic",
-            "config": {"workload": (f"{args.input}->{2 * h_in}p " + ("scale+motion(8,16)+interpolate" if args.workload == "pipeline" else "scale only")),
-                       "input": [w_in, h_in], "output": [w, h], "factors": factors if args.workload == "pipeline" else [],
+            "config": {"workload": (f"{args.input}->{2 * h_in}p " + ("scale+motion(8,16)+interpolate" if args.workload == "pipeline"
+                                                                    else "motion(8,16)+interpolate at input resolution, then scale real and generated frame" if in_res
+                                                                    else "scale only")),
+                       "input": [w_in, h_in], "output": [w, h], "factors": factors if args.workload != "scale" else [],
                        "content": args.content, "parallelism": f"one frame pair per GPU x{world}" + (", RCCL broadcast of the shared previous 4K frame per step" if world > 1 else "")},
             "roofline": roofline,
             "stages": stages,

@@ -544,7 +544,12 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
         columnSums(p, v8);
         transpose(v8, xa, xb);
         for (int e = 0; e < kCand; ++e) {
+#if defined(LFG_EXP) && (LFG_EXP & 32)     // experiment: no scalar loads of the order table
+            const uint32_t eN = (uint32_t)min(e + 2, kCand - 1);
+            const uint32_t ordNN = eN | (((eN / 33u) * kWinW + eN % 33u) << 16);
+#else
             const uint32_t ordNN = order32[min(e + 2, kCand - 1)];
+#endif
             if (e + 1 < kCand) fetchWindow(p, ordN);                   // candidate e+1: reads in flight ...
             rowSumsAndTest(xa, xb, ordE & 0xFFFFu);                    // ... while candidate e is finished
             __builtin_amdgcn_sched_barrier(0);
