@@ -438,6 +438,7 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     const int r8 = lane & 7, q = lane >> 3;
     const int px0 = tx0 + kRun * q;
     float *const slabW = sSlab[seg] + lane;                            // write: row j, column lane
+    float *const slabW2 = slabW + 4 * kSlabP;                          // rows 4-7 (so that row pairs fit ds_write2's offsets)
     const lds_ro_f32_ptr slabR = (lds_ro_f32_ptr)(sSlab[seg] + r8 * kSlabP + kRun * q);
     float thr[2][kRun];                   // kRatio * (smallest S~ so far); a candidate survives while S~ <= thr
     uint32_t cnt2[2][(kRun + 1) / 2];                                  // 16-bit counters (1089 events at most)
@@ -456,7 +457,16 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
         for (int i = 0; i < kRun; ++i)    // pixels outside the image never pass the test (S~ >= 0 > -inf)
             thr[hb][i] = (py < H && px0 + i < W) ? __builtin_inff() : -__builtin_inff();
     }
-    uint32_t maxCount = 0u;               // largest per-pixel count of this lane (lists hold kListK; more = give up)
+    // some pixel of this lane has more than kListK records: bit 15 of a 16-bit counter biased by 0x7FFF - kListK
+    auto listsOverflowed = [&]() -> bool {
+        uint32_t any = 0u;
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+            for (int i = 0; i < (kRun + 1) / 2; ++i) any |= cnt2[hb][i] + (uint32_t)(0x7FFF - kListK) * 0x10001u;
+        }
+        return (any & 0x80008000u) != 0u;
+    };
     // One run of 14 inputs -> 7 sums, inputs paired (x_i, x_{i+7}) as the slab reads deliver them.
     auto runSums = [&](const f32x2 (&X)[kRun], float (&sOut)[kRun]) {
         f32x2 H2[kRun - 1], H4[kRun - 3];
@@ -473,6 +483,7 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     // SCALAR branch per pixel column; only a taken branch (about one in five) touches EXEC.  A divergent
     // `if` per pixel costs ~6 VALU slots each in compare -> saveexec -> branch latency (tools/bench_intops.hip).
     auto rowSumsAndTest = [&](const f32x2 (&XA)[kRun], const f32x2 (&XB)[kRun], uint32_t cand) {
+        const uint32_t zeroCap = 0x00800000u + cand;                   // float bits, wave-uniform
         float sv[2][kRun];
         runSums(XA, sv[0]);
         runSums(XB, sv[1]);
@@ -497,22 +508,20 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
                     if (s <= thr[hb][i]) {                             // rare: ~7.6 times per pixel in 1089
                         // S~ == 0 means every distance is exactly 0, so the shader's cost is exactly 0 too: the
                         // answer is the first such candidate in scan order.  Its index goes into the threshold
-                        // itself (0x00800000 + cand: a tiny normal float, below every non-zero S~ >= 1), nothing
-                        // is appended -- static or flat areas, where many candidates cost 0, never fill the lists.
-                        const bool zero = s == 0.0f;
-                        const float cap = zero ? __builtin_bit_cast(float, 0x00800000u + cand) : s * kRatio;
-                        float t;
-                        asm("v_min_f32 %0, %1, %2" : "=v"(t) : "v"(thr[hb][i]), "v"(cap));   // no NaNs here
+                        // itself (zeroCap = 0x00800000 + cand as a float: tiny, yet above 0 and below every
+                        // non-zero S~ >= 1) and the list does not grow -- static or flat areas, where many
+                        // candidates cost 0, never fill the lists.  Branch-free: max() picks zeroCap only for
+                        // S~ == 0, and the record written for a zero is overwritten by the next real one.
+                        float cap, t;
+                        asm("v_max_f32 %0, %2, %1" : "=v"(cap) : "v"(s * kRatio), "s"(zeroCap));   // no NaNs here
+                        asm("v_min_f32 %0, %1, %2" : "=v"(t) : "v"(thr[hb][i]), "v"(cap));
                         thr[hb][i] = t;
-                        if (!zero) {
-                            const uint32_t n = (cnt2[hb][i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
-                            // past the end of the list the last slot is overwritten; the count keeps growing and
-                            // flags the tile
-                            const uint32_t at = __umul24(min(n, (uint32_t)kListK - 1u), (uint32_t)W) + laneOff[hb] + (uint32_t)i;
-                            waveList[at] = uint2{__builtin_bit_cast(uint32_t, s), cand};
-                            cnt2[hb][i >> 1] += 1u << (16 * (i & 1));
-                            maxCount = max(maxCount, n + 1u);
-                        }
+                        const uint32_t n = (cnt2[hb][i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+                        // past the end of the list the last slot is overwritten; the count keeps growing and
+                        // flags the tile
+                        const uint32_t at = __umul24(min(n, (uint32_t)kListK - 1u), (uint32_t)W) + laneOff[hb] + (uint32_t)i;
+                        waveList[at] = uint2{__builtin_bit_cast(uint32_t, s), cand};
+                        cnt2[hb][i >> 1] += (s != 0.0f) ? (1u << (16 * (i & 1))) : 0u;
                     }
                 }
             }
@@ -526,11 +535,15 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
         return;
 #endif
 #pragma unroll
-        for (int j = 0; j < 8; ++j) slabW[j * kSlabP] = v8[j];
+        for (int j = 0; j < 4; ++j) slabW[j * kSlabP] = v8[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) slabW2[j * kSlabP] = v8[4 + j];
 #pragma unroll
         for (int i = 0; i < kRun; ++i) XA[i] = f32x2{slabR[i], slabR[i + kRun]};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) slabW[j * kSlabP] = v8[8 + j];
+        for (int j = 0; j < 4; ++j) slabW[j * kSlabP] = v8[8 + j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) slabW2[j * kSlabP] = v8[12 + j];
 #pragma unroll
         for (int i = 0; i < kRun; ++i) XB[i] = f32x2{slabR[i], slabR[i + kRun]};
     };
@@ -559,11 +572,11 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
             }
             ordE = ordN; ordN = ordNN;
             if ((e & 15) == 15) {                                      // lists full somewhere in the tile: stop early
-                if (__builtin_amdgcn_readfirstlane(__ballot(maxCount > (uint32_t)kListK) != 0ull)) sGiveUp = 1u;
+                if (__builtin_amdgcn_readfirstlane(__ballot(listsOverflowed()) != 0ull)) sGiveUp = 1u;
                 if (__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)&sGiveUp) != 0) return true;   // keeps the loop uniform
             }
         }
-        return __builtin_amdgcn_readfirstlane(__ballot(maxCount > (uint32_t)kListK) != 0ull);
+        return __builtin_amdgcn_readfirstlane(__ballot(listsOverflowed()) != 0ull);
     };
     const bool gaveUp = run();
     if (gaveUp) {

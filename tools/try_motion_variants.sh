@@ -14,7 +14,7 @@ prev = synth.make_prev(W, H, seed=synth.BASE_SEED); curr = synth.translate(prev,
 P, C = ctx.frame_from(prev), ctx.frame_from(curr); M = ctx.create_frame(W, H, capi.FORMAT_MV_S8X2)
 ctx.motion(P, C, M); ctx.sync()
 ctx.profile_enable(True); ctx.profile_reset()
-for _ in range(5): ctx.motion(P, C, M)
+for _ in range(20): ctx.motion(P, C, M)
 ctx.sync()
 ms, n = ctx.profile_get(capi.STAGE_MOTION)
 print('$f'.split('/')[-1], round(ms / n, 3), 'ms per motion call')
