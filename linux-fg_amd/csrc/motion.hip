@@ -286,8 +286,9 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
 //     window, n = |c|^2 + |p|^2 - 2 c.p by two v_dot4_u32_u8 whose accumulators are float bit patterns (so n
 //     comes out as a float without conversions), v_sqrt_f32, then the 16 column sums
 //     V8(r) = D(r) + ... + D(r+7) as a shared pairwise tree (58 adds);
-//   * transposition through a wave-private LDS slab of 8 rows x 68 floats, eight rows at a time (writes:
-//     lane = column; reads: lane = (row lane&7, 7-pixel run lane>>3), banks 4 row + 7 run: all distinct);
+//   * transposition through a wave-private LDS slab, eight rows at a time, rows interleaved in pairs (writes:
+//     lane = column, one ds_write_b64 per row pair; reads: lane = (row lane&7, 7-pixel run lane>>3), one
+//     ds_read2_b32 per input pair, all 32 banks distinct);
 //   * row sums, per lane two runs of 7 pixels (rows r and r+8): 13 values -> shared pairwise tree (29 adds) ->
 //     7 S~, threshold test, list append.
 //   LDS: 38.2 KB window + 4 x 2.1 KB slabs = 46.9 KB -> three workgroups (12 waves) per CU.  DS operations of
@@ -299,9 +300,13 @@ constexpr int kPTW = 56, kPTH = 64;               // prefilter tile (pixels): 56
 constexpr int kPNT = 256;
 constexpr int kSeg = 16;                          // pixel rows per wave
 constexpr int kSegD = kSeg + kB - 1;              // 23 distances per thread and candidate
-constexpr int kWinW = 95;                         // window pitch (texels): 63 columns + 2R
-constexpr int kWinH = kPTH + kB - 1 + 2 * kR;     // 103 rows
-constexpr int kSlabP = 68;                        // slab row pitch (floats), = 4 mod 32
+constexpr int kWinW = 95;                         // window columns: 63 positions + 2R
+constexpr int kWinH = kPTH + kB - 1 + 2 * kR;     // 103 rows; the window is stored COLUMN-major (pitch kWinH, odd), so
+                                                  // a thread's 23 texels are consecutive words (ds_read2_b32 pairs) and
+                                                  // the 64 lanes of a read still fall into distinct banks
+constexpr int kSlabP = 136;                       // slab pitch of a ROW PAIR (floats): rows 2a, 2a+1 interleaved per column,
+                                                  // so a thread writes two rows with one ds_write_b64; 136 keeps the
+                                                  // transposed reads on 32 distinct banks
 constexpr int kRun = 7;                           // pixels per row-sum run: 8 runs x 7 = 56
 constexpr int kRunIn = kRun + kB - 1;             // 13
 constexpr int kListK = 32;              // recorded candidates per pixel.  A pseudo-random visiting order makes the
@@ -312,11 +317,10 @@ static_assert(kPNT / 64 * kSeg == kPTH && 8 * kRun == kPTW && kPTH == kTH, "stag
 static_assert(kRunIn == 2 * kRun, "row-sum inputs pair up as (x_i, x_{i+7})");
 static_assert(kPTW + kB - 1 <= 64 && kWinW >= kPTW + kB - 1 + 2 * kR, "one lane per position column");
 
-typedef const volatile __attribute__((address_space(3))) uint32_t *lds_ro_u32_ptr;   // volatile: keep 23 ds_read_b32 with
-                                                                 // immediate offsets (merged ds_read2 pairs need ten extra address adds)
+typedef const __attribute__((address_space(3))) uint32_t *lds_ro_u32_ptr;
 typedef const __attribute__((address_space(3))) float *lds_ro_f32_ptr;
 
-// order32[e] = candidate index (dy+R)*33 + (dx+R) in the low half, its window offset (dy+R)*kWinW + (dx+R)
+// order32[e] = candidate index (dy+R)*33 + (dx+R) in the low half, its window offset (dx+R)*kWinH + (dy+R)
 // in the high half; 32-bit entries so the wave-uniform reads are scalar loads.
 __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     uint32_t *__restrict__ countOut, uint32_t *__restrict__ tileFlags, int flagTilesX,
     const uint32_t *__restrict__ order32) {
     __shared__ uint32_t sWin[kWinH * kWinW];                           // 38.2 KB packed RGBA8 search window
-    __shared__ float sSlab[kPNT / 64][8 * kSlabP];                     // 4 x 2.1 KB
+    __shared__ __attribute__((aligned(8))) float sSlab[kPNT / 64][4 * kSlabP];      // 4 x 2.1 KB
     __shared__ uint32_t sGiveUp;
 
     const int tid = threadIdx.x;
@@ -336,12 +340,12 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
 
     // ---- search window: prev(bx0 - R + wx, by0 - R + wy), zero outside the image (texelFetch semantics)
     for (int i = tid; i < kWinH * kWinW; i += kPNT) {
-        const int wy = i / kWinW, wx = i - wy * kWinW;
+        const int wy = i / kWinW, wx = i - wy * kWinW;                 // global reads stay row-major (coalesced)
         const int gx = bx0 - kR + wx, gy = by0 - kR + wy;
         uint32_t v = 0u;
         if (gx >= 0 && gx < W && gy >= 0 && gy < H)
             v = *reinterpret_cast<const uint32_t *>(prev + (size_t)gy * (size_t)prevPitch + (size_t)gx * 4u);
-        sWin[i] = v;
+        sWin[wx * kWinH + wy] = v;
     }
 
     // ---- this thread's 23 block positions (column bx0 + lane, rows by0 + 16 seg + j)
@@ -365,7 +369,8 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     __syncthreads();                       // window staged; the only workgroup barrier
     if (ty0 + kSeg * seg >= H) return;     // this wave's rows lie below the image
 
-    const lds_ro_u32_ptr winBase = (lds_ro_u32_ptr)(sWin + (kSeg * seg) * kWinW + lane);
+    // (lane 63 has no position column: it re-reads lane 62's texels, its sums are never used)
+    const lds_ro_u32_ptr winBase = (lds_ro_u32_ptr)(sWin + min(lane, kPTW + kB - 2) * kWinH + kSeg * seg);
     auto fetchWindow = [&](uint32_t (&p)[kSegD], uint32_t ord) {
 #if defined(LFG_EXP) && (LFG_EXP & 8)      // experiment: no window reads
 #pragma unroll
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
 #endif
         const lds_ro_u32_ptr w = winBase + (ord >> 16);
 #pragma unroll
-        for (int j = 0; j < kSegD; ++j) p[j] = w[j * kWinW];
+        for (int j = 0; j < kSegD; ++j) p[j] = w[j];
     };
     // Packed fp32 throughout (v_pk_add_f32: two adds per issue slot; a wave issues one VALU op per four
     // cycles whatever its width): position j is paired with position j + 12, so every level of the sliding
@@ -437,9 +442,8 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     // ---- row sums: rows r8 and r8 + 8 of the wave's 16, pixels tx0 + 7 q .. + 6
     const int r8 = lane & 7, q = lane >> 3;
     const int px0 = tx0 + kRun * q;
-    float *const slabW = sSlab[seg] + lane;                            // write: row j, column lane
-    float *const slabW2 = slabW + 4 * kSlabP;                          // rows 4-7 (so that row pairs fit ds_write2's offsets)
-    const lds_ro_f32_ptr slabR = (lds_ro_f32_ptr)(sSlab[seg] + r8 * kSlabP + kRun * q);
+    f32x2 *const slabW = reinterpret_cast<f32x2 *>(sSlab[seg]) + lane;               // write: rows (2a, 2a+1), column lane
+    const lds_ro_f32_ptr slabR = (lds_ro_f32_ptr)(sSlab[seg] + (r8 >> 1) * kSlabP + 2 * kRun * q + (r8 & 1));
     float thr[2][kRun];                   // kRatio * (smallest S~ so far); a candidate survives while S~ <= thr
     uint32_t cnt2[2][(kRun + 1) / 2];                                  // 16-bit counters (1089 events at most)
     // Records {S~ bits, candidate}: record k of pixel (x, y) lives at list[(y * kListK + k) * W + x] -- K planes
@@ -535,17 +539,13 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
         return;
 #endif
 #pragma unroll
-        for (int j = 0; j < 4; ++j) slabW[j * kSlabP] = v8[j];
+        for (int a = 0; a < 4; ++a) slabW[a * (kSlabP / 2)] = f32x2{v8[2 * a], v8[2 * a + 1]};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) slabW2[j * kSlabP] = v8[4 + j];
+        for (int i = 0; i < kRun; ++i) XA[i] = f32x2{slabR[2 * i], slabR[2 * (i + kRun)]};
 #pragma unroll
-        for (int i = 0; i < kRun; ++i) XA[i] = f32x2{slabR[i], slabR[i + kRun]};
+        for (int a = 0; a < 4; ++a) slabW[a * (kSlabP / 2)] = f32x2{v8[8 + 2 * a], v8[9 + 2 * a]};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) slabW[j * kSlabP] = v8[8 + j];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) slabW2[j * kSlabP] = v8[12 + j];
-#pragma unroll
-        for (int i = 0; i < kRun; ++i) XB[i] = f32x2{slabR[i], slabR[i + kRun]};
+        for (int i = 0; i < kRun; ++i) XB[i] = f32x2{slabR[2 * i], slabR[2 * (i + kRun)]};
     };
 
     auto run = [&]() -> bool {
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
         for (int e = 0; e < kCand; ++e) {
 #if defined(LFG_EXP) && (LFG_EXP & 32)     // experiment: no scalar loads of the order table
             const uint32_t eN = (uint32_t)min(e + 2, kCand - 1);
-            const uint32_t ordNN = eN | (((eN / 33u) * kWinW + eN % 33u) << 16);
+            const uint32_t ordNN = eN | (((eN % 33u) * kWinH + eN / 33u) << 16);
 #else
             const uint32_t ordNN = order32[min(e + 2, kCand - 1)];
 #endif
@@ -734,7 +734,7 @@ void motion_candidate_order(uint32_t *order32) {
     }
     for (int i = 0; i < kCand; ++i) {      // low half: candidate index, high half: its offset in the LDS window
         const uint32_t dyi = order[i] / kSide, dxi = order[i] % kSide;
-        order32[i] = order[i] | ((dyi * kWinW + dxi) << 16);
+        order32[i] = order[i] | ((dxi * kWinH + dyi) << 16);
     }
 }
 
