@@ -372,11 +372,6 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     // (lane 63 has no position column: it re-reads lane 62's texels, its sums are never used)
     const lds_ro_u32_ptr winBase = (lds_ro_u32_ptr)(sWin + min(lane, kPTW + kB - 2) * kWinH + kSeg * seg);
     auto fetchWindow = [&](uint32_t (&p)[kSegD], uint32_t ord) {
-#if defined(LFG_EXP) && (LFG_EXP & 8)      // experiment: no window reads
-#pragma unroll
-        for (int j = 0; j < kSegD; ++j) p[j] = c[j] + ord + j;
-        return;
-#endif
         const lds_ro_u32_ptr w = winBase + (ord >> 16);
 #pragma unroll
         for (int j = 0; j < kSegD; ++j) p[j] = w[j];
@@ -392,24 +387,15 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
         // 0x4B800000 + k = 2^24 + 2k (k < 2^23), so two exact fp32 operations give n as a float.
         // (No inline asm on dot results: a VALU op that reads a v_dot4 result needs 3 wait states on
         //  gfx950, which only the compiler's hazard recogniser provides.)
-#if defined(LFG_EXP) && (LFG_EXP & 16)     // experiment: no dot products
-        auto f1of = [&](int j) { return __builtin_bit_cast(float, p[j] + cc[j]); };
-        auto f2of = [&](int j) { return __builtin_bit_cast(float, p[j] & c[j]); };
-#else
         auto f1of = [&](int j) { return __builtin_bit_cast(float, __builtin_amdgcn_udot4(p[j], p[j], cc[j], false)); };        // 2^23 + |c|^2 + |p|^2
         auto f2of = [&](int j) { return __builtin_bit_cast(float, __builtin_amdgcn_udot4(c[j], p[j], 0x4B800000u, false)); };  // 2^24 + 2 c.p
-#endif
         const f32x2 kBias = {8388608.0f, 8388608.0f};
         f32x2 A[kHalf - 1];                                            // (d_j, d_{j+12}), j = 0..10
 #pragma unroll
         for (int j = 0; j < kHalf - 1; ++j) {
             const f32x2 F1 = {f1of(j), f1of(j + kHalf)}, F2 = {f2of(j), f2of(j + kHalf)};
             const f32x2 N = (F1 - F2) + kBias;
-#if defined(LFG_EXP) && (LFG_EXP & 4)      // experiment: no sqrt
-            A[j] = N;
-#else
             A[j] = f32x2{__builtin_amdgcn_sqrtf(N.x), __builtin_amdgcn_sqrtf(N.y)};
-#endif
         }
         float dMid = __builtin_amdgcn_sqrtf((f1of(kHalf - 1) - f2of(kHalf - 1)) + 8388608.0f);   // d_11
         // Border tiles only (one wave-uniform branch; the flag is laundered through an empty asm so the loop
@@ -491,11 +477,6 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
         float sv[2][kRun];
         runSums(XA, sv[0]);
         runSums(XB, sv[1]);
-#if defined(LFG_EXP) && (LFG_EXP & 1)      // experiment: no tests
-#pragma unroll
-        for (int i = 0; i < kRun; ++i) { thr[0][i] += sv[0][i]; thr[1][i] += sv[1][i]; }
-        return;
-#endif
         unsigned long long hit[2][kRun];
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
@@ -533,11 +514,6 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     };
     // slab traffic of one candidate: rows 0-7 out, their transposed runs in, rows 8-15 out, runs in
     auto transpose = [&](const float (&v8)[kSeg], f32x2 (&XA)[kRun], f32x2 (&XB)[kRun]) {
-#if defined(LFG_EXP) && (LFG_EXP & 2)      // experiment: no slab round trip
-#pragma unroll
-        for (int i = 0; i < kRun; ++i) { XA[i] = f32x2{v8[i], v8[i + 7]}; XB[i] = f32x2{v8[i + 2], v8[i + 9]}; }
-        return;
-#endif
 #pragma unroll
         for (int a = 0; a < 4; ++a) slabW[a * (kSlabP / 2)] = f32x2{v8[2 * a], v8[2 * a + 1]};
 #pragma unroll
@@ -557,12 +533,7 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
         columnSums(p, v8);
         transpose(v8, xa, xb);
         for (int e = 0; e < kCand; ++e) {
-#if defined(LFG_EXP) && (LFG_EXP & 32)     // experiment: no scalar loads of the order table
-            const uint32_t eN = (uint32_t)min(e + 2, kCand - 1);
-            const uint32_t ordNN = eN | (((eN % 33u) * kWinH + eN / 33u) << 16);
-#else
             const uint32_t ordNN = order32[min(e + 2, kCand - 1)];
-#endif
             if (e + 1 < kCand) fetchWindow(p, ordN);                   // candidate e+1: reads in flight ...
             rowSumsAndTest(xa, xb, ordE & 0xFFFFu);                    // ... while candidate e is finished
             __builtin_amdgcn_sched_barrier(0);
