@@ -113,7 +113,8 @@ void trim_axis_tables(lfg_context *ctx) {
 int ensure_motion_workspace(lfg_context *ctx, uint32_t width, uint32_t height) {
     if (ctx->motion_ws && ctx->motion_ws_w == width && ctx->motion_ws_h == height) return LFG_OK;
     lfg::MotionWorkspaceLayout layout;
-    const size_t bytes = lfg::motion_workspace_bytes(width, height, &layout);
+    if (ctx->motion_slots == 0) ctx->motion_slots = lfg::prefilter_slots();
+    const size_t bytes = lfg::motion_workspace_bytes(width, height, ctx->motion_slots, &layout);
     if (bytes > ctx->motion_ws_bytes) {
         LFG_HIP(ctx, hipStreamSynchronize(ctx->stream));          // a queued kernel may still use the old one
         if (ctx->motion_ws) (void)hipFree(ctx->motion_ws);
@@ -419,7 +420,7 @@ LFG_EXPORT int lfg_motion(lfg_context *ctx, const lfg_frame *prev, const lfg_fra
     StageTimer timer(ctx, LFG_STAGE_MOTION);
     hipError_t e;
     if (tiled && ctx->motion_mode == LFG_MOTION_PREFILTERED)
-        e = lfg::launch_motion_prefiltered_8_16(ctx->stream, *prev, *curr, *mv, ctx->motion_ws, ctx->motion_ws_layout);
+        e = lfg::launch_motion_prefiltered_8_16(ctx->stream, *prev, *curr, *mv, ctx->motion_ws, ctx->motion_ws_layout, ctx->motion_slots);
     else if (tiled) e = lfg::launch_motion_tiled_8_16(ctx->stream, *prev, *curr, *mv, nullptr);
     else e = lfg::launch_motion_generic(ctx->stream, *prev, *curr, *mv, block_size, R);
     if (e != hipSuccess) return fail_hip(ctx, e, "motion kernel launch");
@@ -452,10 +453,14 @@ LFG_EXPORT int lfg_motion_last_stats(lfg_context *ctx, uint32_t *out_tiles, uint
         const size_t px = (size_t)ctx->motion_ws_w * ctx->motion_ws_h;
         std::vector<uint32_t> cnt(px);
         LFG_HIP(ctx, hipMemcpy(cnt.data(), ctx->motion_ws + ctx->motion_ws_layout.count, px * 4, hipMemcpyDeviceToHost));
+        // (tiles whose candidates were shared between several workgroups keep their counts elsewhere: left out)
+        const lfg::PrefilterSplit sp = lfg::prefilter_split(ctx->motion_ws_w, ctx->motion_ws_h, ctx->motion_slots);
         double sum = 0; size_t n = 0;
         for (uint32_t y = 0; y < ctx->motion_ws_h; ++y)
             for (uint32_t x = 0; x < ctx->motion_ws_w; ++x)
-                if (!flags[(size_t)(y / 64u) * tx + x / 64u]) { sum += cnt[(size_t)y * ctx->motion_ws_w + x]; ++n; }
+                if (!flags[(size_t)(y / 64u) * tx + x / 64u] && (int)((y / 64u) * (uint32_t)sp.tilesX + x / 56u) < sp.fullTiles) {
+                    sum += cnt[(size_t)y * ctx->motion_ws_w + x]; ++n;
+                }
         *out_mean_recorded = n ? sum / (double)n : 0.0;
     }
     return LFG_OK;

@@ -24,7 +24,15 @@ struct AxisTable {
     float *d_weight = nullptr;    // [out_size][6]
 };
 
-struct MotionWorkspaceLayout { size_t list, listC, umin, count, tileFlags, order, total; };
+struct MotionWorkspaceLayout { size_t list, listC, umin, count, tileFlags, order, auxList, auxUmin, auxCount, total; };
+// Work units of the motion prefilter (motion.hip: prefilter_split): units [0, fullTiles) are whole 56 x 64 tiles, each
+// later tile is shared by `split` units with private lists in the aux arrays.
+struct PrefilterSplit {
+    int tilesX, fullTiles, split, units;
+    uint2 *auxList;
+    float *auxUmin;
+    uint32_t *auxCount;
+};
 
 struct ProfileSlot {
     hipEvent_t begin = nullptr, end = nullptr;
@@ -45,6 +53,7 @@ struct lfg_context {
     size_t motion_ws_bytes = 0;
     uint32_t motion_ws_w = 0, motion_ws_h = 0;
     lfg::MotionWorkspaceLayout motion_ws_layout{};
+    int motion_slots = 0;                      // prefilter workgroups resident at once on this device (0 = not queried yet)
     int motion_mode = 0;                       // 0: prefilter + exact fallback, 1: exact kernel only
     // profiling
     bool profile = false;
@@ -66,10 +75,12 @@ bool scale_2x_supported(const lfg_frame &in, const lfg_frame &out);
 hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                     const lfg_frame &mv, const uint32_t *tileFlags);
 // Prefiltered motion path (motion.hip): MotionWorkspaceLayout = byte offsets of its scratch arrays.
-size_t motion_workspace_bytes(uint32_t width, uint32_t height, MotionWorkspaceLayout *layout);
+size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, MotionWorkspaceLayout *layout);
+PrefilterSplit prefilter_split(uint32_t width, uint32_t height, int slots);
+int prefilter_slots();      // workgroups of the prefilter kernel the current device holds at once
 void motion_candidate_order(uint32_t *order32_1089);
 hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
-                                          const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &layout);
+                                          const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &layout, int slots);
 hipError_t launch_motion_generic(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                  const lfg_frame &mv, int block_size, int radius);
 hipError_t launch_interpolate(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,

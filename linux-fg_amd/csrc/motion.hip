@@ -326,7 +326,7 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int W, int H, uint2 *__restrict__ list, float *__restrict__ uminOut,
     uint32_t *__restrict__ countOut, uint32_t *__restrict__ tileFlags, int flagTilesX,
-    const uint32_t *__restrict__ order32) {
+    const uint32_t *__restrict__ order32, PrefilterSplit sp) {
     __shared__ uint32_t sWin[kWinH * kWinW];                           // 38.2 KB packed RGBA8 search window
     __shared__ __attribute__((aligned(8))) float sSlab[kPNT / 64][4 * kSlabP];      // 4 x 2.1 KB
     __shared__ uint32_t sGiveUp;
@@ -334,7 +334,16 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int seg = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave index 0..3
-    const int tx0 = blockIdx.x * kPTW, ty0 = blockIdx.y * kPTH;        // tile origin (pixels)
+    // Work units (PrefilterSplit): the first sp.fullTiles units are whole tiles; each remaining tile is shared by
+    // sp.split units that take a contiguous part of the candidate order each and write to their own lists.
+    const int unit = blockIdx.x;
+    const bool whole = unit < sp.fullTiles;
+    const int tile = whole ? unit : sp.fullTiles + (unit - sp.fullTiles) / sp.split;
+    const int chunk = whole ? 0 : (unit - sp.fullTiles) % sp.split;
+    const int perChunk = whole ? kCand : (kCand + sp.split - 1) / sp.split;
+    const int eBegin = chunk * perChunk, eEnd = min(kCand, eBegin + perChunk);
+    const int tileY = tile / sp.tilesX, tileX = tile - tileY * sp.tilesX;
+    const int tx0 = tileX * kPTW, ty0 = tileY * kPTH;                  // tile origin (pixels)
     const int bx0 = tx0 - kB / 2, by0 = ty0 - kB / 2;                  // image coords of block position (0,0)
     if (tid == 0) sGiveUp = 0u;
 
@@ -435,12 +444,18 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     // Records {S~ bits, candidate}: record k of pixel (x, y) lives at list[(y * kListK + k) * W + x] -- K planes
     // per image row, so the resolve kernel reads record k of 64 neighbouring pixels as one 512-byte line.
     // Address = wave-uniform base + 32-bit lane offset; k * W is a 24-bit multiply.
-    uint2 *const waveList = list + ((size_t)(ty0 + kSeg * seg) * (size_t)kListK * (size_t)W + (size_t)tx0);
+    // Whole tiles write into the image-shaped arrays (row stride W), shared tiles into their unit's private
+    // 56 x 64 block of the auxiliary arrays (row stride 56).
+    const int auxUnit = unit - sp.fullTiles;                           // valid when !whole
+    const uint32_t rowStride = whole ? (uint32_t)W : (uint32_t)kPTW;
+    uint2 *const waveList = whole
+        ? list + ((size_t)(ty0 + kSeg * seg) * (size_t)kListK * (size_t)W + (size_t)tx0)
+        : sp.auxList + ((size_t)auxUnit * kPTH + (size_t)(kSeg * seg)) * (size_t)kListK * (size_t)kPTW;
     uint32_t laneOff[2];
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
         const int py = ty0 + kSeg * seg + 8 * hb + r8;
-        laneOff[hb] = (uint32_t)(8 * hb + r8) * (uint32_t)(kListK * W) + (uint32_t)(kRun * q);   // < 16 K W
+        laneOff[hb] = (uint32_t)(8 * hb + r8) * ((uint32_t)kListK * rowStride) + (uint32_t)(kRun * q);   // < 16 K W
 #pragma unroll
         for (int i = 0; i < (kRun + 1) / 2; ++i) cnt2[hb][i] = 0u;
 #pragma unroll
@@ -472,7 +487,7 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     // The test is two-level: all fourteen comparisons first (VALU -> scalar masks, pipelined), then one
     // SCALAR branch per pixel column; only a taken branch (about one in five) touches EXEC.  A divergent
     // `if` per pixel costs ~6 VALU slots each in compare -> saveexec -> branch latency (tools/bench_intops.hip).
-    auto rowSumsAndTest = [&](const f32x2 (&XA)[kRun], const f32x2 (&XB)[kRun], uint32_t cand) {
+    auto rowSumsAndTest = [&](const f32x2 (&XA)[kRun], const f32x2 (&XB)[kRun], uint32_t cand, uint32_t countIt) {
         const uint32_t zeroCap = 0x00800000u + cand;                   // float bits, wave-uniform
         float sv[2][kRun];
         runSums(XA, sv[0]);
@@ -504,9 +519,9 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
                         const uint32_t n = (cnt2[hb][i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
                         // past the end of the list the last slot is overwritten; the count keeps growing and
                         // flags the tile
-                        const uint32_t at = __umul24(min(n, (uint32_t)kListK - 1u), (uint32_t)W) + laneOff[hb] + (uint32_t)i;
+                        const uint32_t at = __umul24(min(n, (uint32_t)kListK - 1u), rowStride) + laneOff[hb] + (uint32_t)i;
                         waveList[at] = uint2{__builtin_bit_cast(uint32_t, s), cand};
-                        cnt2[hb][i >> 1] += (s != 0.0f) ? (1u << (16 * (i & 1))) : 0u;
+                        cnt2[hb][i >> 1] += (s != 0.0f) ? (countIt << (16 * (i & 1))) : 0u;
                     }
                 }
             }
@@ -528,16 +543,20 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
         uint32_t p[kSegD];
         float v8[kSeg];
         f32x2 xa[kRun], xb[kRun];
-        uint32_t ordE = order32[0], ordN = order32[1];                 // candidates e, e+1 (scalar loads, one step ahead)
+        // A unit that shares its tile starts with zero motion as well (threshold only, not recorded: unit 0 owns
+        // it), so static areas close their threshold at once in every unit.
+        const int eFirst = chunk > 0 ? eBegin - 1 : eBegin;
+        auto orderAt = [&](int e) { return order32[e < eBegin ? 0 : min(e, kCand - 1)]; };
+        uint32_t ordE = orderAt(eFirst), ordN = orderAt(eFirst + 1);   // candidates e, e+1 (scalar loads, one step ahead)
         fetchWindow(p, ordE);
         columnSums(p, v8);
         transpose(v8, xa, xb);
-        for (int e = 0; e < kCand; ++e) {
-            const uint32_t ordNN = order32[min(e + 2, kCand - 1)];
-            if (e + 1 < kCand) fetchWindow(p, ordN);                   // candidate e+1: reads in flight ...
-            rowSumsAndTest(xa, xb, ordE & 0xFFFFu);                    // ... while candidate e is finished
+        for (int e = eFirst; e < eEnd; ++e) {
+            const uint32_t ordNN = orderAt(e + 2);
+            if (e + 1 < eEnd) fetchWindow(p, ordN);                    // candidate e+1: reads in flight ...
+            rowSumsAndTest(xa, xb, ordE & 0xFFFFu, e >= eBegin ? 1u : 0u);   // ... while candidate e is finished
             __builtin_amdgcn_sched_barrier(0);
-            if (e + 1 < kCand) {
+            if (e + 1 < eEnd) {
                 columnSums(p, v8);
                 transpose(v8, xa, xb);
             }
@@ -557,8 +576,8 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
         if (lane == 0) {
             sGiveUp = 1u;
             const int ex0 = tx0 / kTW, ex1 = min(tx0 + kPTW - 1, W - 1) / kTW;
-            tileFlags[blockIdx.y * flagTilesX + ex0] = 1u;
-            tileFlags[blockIdx.y * flagTilesX + ex1] = 1u;
+            tileFlags[tileY * flagTilesX + ex0] = 1u;
+            tileFlags[tileY * flagTilesX + ex1] = 1u;
         }
         return;
     }
@@ -568,9 +587,16 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
 #pragma unroll
         for (int i = 0; i < kRun; ++i) {
             if (py < H && px0 + i < W) {
-                const size_t gp = (size_t)py * (size_t)W + (size_t)(px0 + i);
-                uminOut[gp] = thr[hb][i];
-                countOut[gp] = (cnt2[hb][i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+                const uint32_t cnt = (cnt2[hb][i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+                if (whole) {
+                    const size_t gp = (size_t)py * (size_t)W + (size_t)(px0 + i);
+                    uminOut[gp] = thr[hb][i];
+                    countOut[gp] = cnt;
+                } else {
+                    const size_t ap = ((size_t)auxUnit * kPTH + (size_t)(py - ty0)) * kPTW + (size_t)(px0 + i - tx0);
+                    sp.auxUmin[ap] = thr[hb][i];
+                    sp.auxCount[ap] = cnt;
+                }
             }
         }
     }
@@ -606,47 +632,74 @@ __global__ __launch_bounds__(256) void motion_resolve_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int8_t *__restrict__ mv, int mvPitch, int W, int H, const uint2 *__restrict__ list,
     const float *__restrict__ uminIn, const uint32_t *__restrict__ countIn, const uint32_t *__restrict__ tileFlags,
-    int tilesX) {
+    int tilesX, PrefilterSplit sp) {
     const int px = blockIdx.x * 64 + (threadIdx.x & 63);
     const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (px >= W || py >= H) return;
     if (tileFlags[(py / kTH) * tilesX + px / kTW] != 0u) return;       // this tile goes through the exact kernel
-    const size_t gp = (size_t)py * (size_t)W + (size_t)px;
-    const uint2 *const rowList = list + (size_t)py * (size_t)kListK * (size_t)W + (size_t)px;   // record k: rowList[k * W]
-    const float bound = uminIn[gp];
-    const uint32_t n = min(countIn[gp], (uint32_t)kListK);
+    // Where this pixel's records live: one list in the image-shaped arrays, or sp.split lists (one per unit that
+    // shared the tile's candidates) in the auxiliary arrays.  Record k of list c: recs[c * listStride + k * recStride].
+    const int ptile = (py / kPTH) * sp.tilesX + px / kPTW;
+    const bool whole = ptile < sp.fullTiles;
+    const int nLists = whole ? 1 : sp.split;
+    const uint2 *recs;
+    const float *thrs;
+    const uint32_t *cnts;
+    size_t listStride, recStride, thrStride;
+    if (whole) {
+        recs = list + (size_t)py * (size_t)kListK * (size_t)W + (size_t)px;
+        thrs = uminIn + (size_t)py * (size_t)W + (size_t)px;
+        cnts = countIn + (size_t)py * (size_t)W + (size_t)px;
+        listStride = 0; recStride = (size_t)W; thrStride = 0;
+    } else {
+        const size_t unit0 = (size_t)(ptile - sp.fullTiles) * (size_t)sp.split;
+        const int ly = py % kPTH, lx = px % kPTW;
+        recs = sp.auxList + (unit0 * kPTH + (size_t)ly) * (size_t)kListK * kPTW + (size_t)lx;
+        thrs = sp.auxUmin + (unit0 * kPTH + (size_t)ly) * kPTW + (size_t)lx;
+        cnts = sp.auxCount + (unit0 * kPTH + (size_t)ly) * kPTW + (size_t)lx;
+        listStride = (size_t)kPTH * kListK * kPTW; recStride = kPTW; thrStride = (size_t)kPTH * kPTW;
+    }
+    float bound = __builtin_inff();        // thresholds are monotone: the tightest one holds for every list
+    for (int c = 0; c < nLists; ++c) bound = __builtin_fminf(bound, thrs[(size_t)c * thrStride]);
+    int8_t *dst = mv + (size_t)py * (size_t)mvPitch + (size_t)px * 2u;
     if (bound < 0.5f) {                    // a zero-cost candidate exists; the first one in scan order is encoded here
         const uint32_t zc = __builtin_bit_cast(uint32_t, bound) - 0x00800000u;
         const int zdy = (int)zc / kSide, zdx = (int)zc - zdy * kSide;
-        int8_t *zdst = mv + (size_t)py * (size_t)mvPitch + (size_t)px * 2u;
-        zdst[0] = (int8_t)(zdx - kR);
-        zdst[1] = (int8_t)(zdy - kR);
+        dst[0] = (int8_t)(zdx - kR);
+        dst[1] = (int8_t)(zdy - kR);
         return;
     }
     // A single survivor IS the shader's answer (the exact minimiser always survives), no evaluation needed.
-    uint32_t survivors = 0u, firstK = 0u;
-    for (uint32_t k = 0; k < n; ++k) {
-        if (__builtin_bit_cast(float, rowList[(size_t)k * (size_t)W].x) <= bound) {
-            if (survivors == 0u) firstK = k;
-            ++survivors;
+    uint32_t survivors = 0u, bestC = 0xFFFFFFFFu;
+    for (int c = 0; c < nLists; ++c) {
+        const uint32_t n = min(cnts[(size_t)c * thrStride], (uint32_t)kListK);
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint2 rec = recs[(size_t)c * listStride + (size_t)k * recStride];
+            if (__builtin_bit_cast(float, rec.x) <= bound) {
+                if (survivors == 0u) bestC = rec.y;
+                ++survivors;
+            }
         }
     }
-    uint32_t bestC = rowList[(size_t)firstK * (size_t)W].y;
     if (survivors > 1u) {
         // Several candidates within the bracket of the minimum: the literal chain decides.  Lanes find their
         // next surviving entry independently and only then meet in the expensive exact evaluation, so a wave
         // runs it max-over-lanes(survivors) times, not once per list position that holds a survivor for some lane.
         float bestV = __builtin_inff();
         bestC = 0xFFFFFFFFu;
-        uint32_t k = firstK;
+        int c = 0;
+        uint32_t k = 0, n = min(cnts[0], (uint32_t)kListK);
         for (;;) {
             uint32_t cand = 0xFFFFFFFFu;
-            while (k < n) {
-                const uint2 rec = rowList[(size_t)k * (size_t)W];
-                const float st = __builtin_bit_cast(float, rec.x);
-                const uint32_t c = rec.y;
+            for (;;) {
+                if (k >= n) {
+                    if (++c >= nLists) break;
+                    k = 0; n = min(cnts[(size_t)c * thrStride], (uint32_t)kListK);
+                    continue;
+                }
+                const uint2 rec = recs[(size_t)c * listStride + (size_t)k * recStride];
                 ++k;
-                if (st <= bound) { cand = c; break; }
+                if (__builtin_bit_cast(float, rec.x) <= bound) { cand = rec.y; break; }
             }
             if (cand == 0xFFFFFFFFu) break;
             const int dyi = (int)cand / kSide, dxi = (int)cand - dyi * kSide;
@@ -655,7 +708,6 @@ __global__ __launch_bounds__(256) void motion_resolve_kernel(
         }
     }
     const int dyi = (int)bestC / kSide, dxi = (int)bestC - dyi * kSide;
-    int8_t *dst = mv + (size_t)py * (size_t)mvPitch + (size_t)px * 2u;
     dst[0] = (int8_t)(dxi - kR);
     dst[1] = (int8_t)(dyi - kR);
 }
@@ -669,7 +721,7 @@ hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const 
     return hipGetLastError();
 }
 
-size_t motion_workspace_bytes(uint32_t width, uint32_t height, MotionWorkspaceLayout *layout) {
+size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, MotionWorkspaceLayout *layout) {
     const size_t px = (size_t)width * height;
     const size_t tiles = (size_t)((width + kTW - 1) / kTW) * ((height + kTH - 1) / kTH);
     auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -680,9 +732,39 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, MotionWorkspaceLa
     l.count = align(l.umin + px * sizeof(float));
     l.tileFlags = align(l.count + px * sizeof(uint32_t));
     l.order = align(l.tileFlags + tiles * sizeof(uint32_t));
-    l.total = align(l.order + kCand * sizeof(uint32_t));
+    // auxiliary arrays of the shared tiles (see prefilter_split): one 56 x 64 block per unit
+    const PrefilterSplit sp = prefilter_split(width, height, slots);
+    const size_t auxUnits = (size_t)(sp.units - sp.fullTiles);
+    l.auxList = align(l.order + kCand * sizeof(uint32_t));
+    l.auxUmin = align(l.auxList + auxUnits * kPTH * kPTW * kListK * sizeof(uint2));
+    l.auxCount = align(l.auxUmin + auxUnits * kPTH * kPTW * sizeof(float));
+    l.total = align(l.auxCount + auxUnits * kPTH * kPTW * sizeof(uint32_t));
     if (layout) *layout = l;
     return l.total;
+}
+
+// How the prefilter's tiles map onto `slots` concurrently resident workgroups.  All workgroups take the same time,
+// so a launch runs in rounds of `slots`; the tiles of the last, partial round are each shared by `split` workgroups
+// (contiguous parts of the candidate order, private lists, merged by the resolve kernel) so that they finish in a
+// fraction of a round instead of a whole one.
+PrefilterSplit prefilter_split(uint32_t width, uint32_t height, int slots) {
+    PrefilterSplit sp{};
+    sp.tilesX = ((int)width + kPTW - 1) / kPTW;
+    const int tiles = sp.tilesX * (((int)height + kPTH - 1) / kPTH);
+    const int rest = slots > 0 ? tiles % slots : 0;
+    sp.split = 1;
+    if (rest > 0 && rest * 2 <= slots) sp.split = min(8, slots / rest);
+    sp.fullTiles = sp.split > 1 ? tiles - rest : tiles;
+    sp.units = sp.fullTiles + (tiles - sp.fullTiles) * sp.split;
+    return sp;
+}
+
+int prefilter_slots() {
+    int dev = 0, cus = 0, perCu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, motion_prefilter_kernel, kPNT, 0) != hipSuccess) return 0;
+    return cus * perCu;
 }
 
 void motion_candidate_order(uint32_t *order32) {
@@ -710,7 +792,7 @@ void motion_candidate_order(uint32_t *order32) {
 }
 
 hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
-                                          const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &l) {
+                                          const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &l, int slots) {
     const int tilesX = ((int)curr.width + kTW - 1) / kTW, tilesY = ((int)curr.height + kTH - 1) / kTH;
     uint2 *list = reinterpret_cast<uint2 *>(workspace + l.list);
     float *umin = reinterpret_cast<float *>(workspace + l.umin);
@@ -718,16 +800,20 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
     uint32_t *flags = reinterpret_cast<uint32_t *>(workspace + l.tileFlags);
     const uint32_t *order = reinterpret_cast<const uint32_t *>(workspace + l.order);
     static_assert(kPTH == kTH, "prefilter tiles and exact tiles share their rows");
+    PrefilterSplit sp = prefilter_split(curr.width, curr.height, slots);
+    sp.auxList = reinterpret_cast<uint2 *>(workspace + l.auxList);
+    sp.auxUmin = reinterpret_cast<float *>(workspace + l.auxUmin);
+    sp.auxCount = reinterpret_cast<uint32_t *>(workspace + l.auxCount);
     hipError_t e = hipMemsetAsync(flags, 0, (size_t)tilesX * tilesY * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(motion_prefilter_kernel, dim3(((int)curr.width + kPTW - 1) / kPTW, tilesY), dim3(kPNT), 0, s,
+    hipLaunchKernelGGL(motion_prefilter_kernel, dim3(sp.units), dim3(kPNT), 0, s,
                        (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
-                       (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, order);
+                       (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, order, sp);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(motion_resolve_kernel, dim3((curr.width + 63) / 64, (curr.height + 3) / 4), dim3(256), 0, s,
                        (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
-                       (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX);
+                       (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, sp);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     return launch_motion_tiled_8_16(s, prev, curr, mv, flags);
