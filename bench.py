@@ -84,9 +84,8 @@ def pmc_traffic(kernel_prefixes):
         kernel_prefixes = [kernel_prefixes]
     vals, cur = {}, None
     for line in open(files[-1]):
-        m = re.match(r"^(?:void )?(lfg::\w+)", line)
-        if m:
-            cur = m.group(1)
+        if ": launches" in line and not line.startswith(" "):        # any kernel header line starts a new block
+            cur = line.split(": launches")[0].replace("void ", "").split("<")[0].split("(")[0].strip()
         m = re.match(r"^\s+(FETCH_SIZE|WRITE_SIZE)\s+([0-9.e+]+)", line)
         if m and cur and any(cur.startswith(k) for k in kernel_prefixes):
             vals[(cur, m.group(1))] = float(m.group(2)) * 1024.0        # the last block of a kernel wins
