@@ -137,9 +137,17 @@ int  lfg_ring_create(lfg_context *ctx, uint32_t slots, size_t slot_bytes, lfg_ri
 void lfg_ring_destroy(lfg_ring *ring);
 int  lfg_ring_acquire(lfg_ring *ring, void **out_host_ptr, uint32_t *out_slot);
 /* Upload slot -> frame (or download frame -> slot) asynchronously and mark the slot busy
- * until that transfer finishes. */
+ * until that transfer finishes.  Transfers run on the ring's own stream, next to the kernels:
+ * an upload is ordered after everything enqueued so far and before everything enqueued later;
+ * a download is ordered after everything enqueued so far only -- later kernels do not wait for it. */
 int  lfg_ring_upload(lfg_ring *ring, uint32_t slot, lfg_frame *dst);
 int  lfg_ring_download(lfg_ring *ring, uint32_t slot, const lfg_frame *src);
+/* Block the host until the slot's last transfer has finished (the vkQueueWaitIdle before the
+ * reference maps its staging buffer, src/scaler.cpp:532-536), then the slot's pixels may be read. */
+int  lfg_ring_wait(lfg_ring *ring, uint32_t slot);
+/* Make kernels enqueued from now on wait (on the device, not the host) for the slot's last transfer:
+ * call it before overwriting a frame whose download into `slot` may still be running. */
+int  lfg_ring_fence_slot(lfg_ring *ring, uint32_t slot);
 
 /* ---------------------------------------------------------------- the three stages */
 
@@ -158,11 +166,11 @@ int  lfg_motion(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *curr, 
 
 /* How lfg_motion evaluates blockSize 8 / searchRadius 16.  Both modes return bit-identical motion
  * vectors for every input; they differ in run time only.
- *   LFG_MOTION_PREFILTERED (default): a pairwise-tree approximation of every candidate's cost, whose
- *       distance from the shader's sequential fp32 sum is bounded rigorously (4.2e-6 relative), selects
- *       the few candidates that can still be the minimum; only those get the literal 64-term chain.
- *       Tiles where the filter cannot separate the candidates (flat or finely tied content) fall back to
- *       the exact kernel, so such content costs what LFG_MOTION_EXACT_ONLY costs.
+ *   LFG_MOTION_PREFILTERED (default): a cheap value that provably brackets every candidate's cost (integer
+ *       squared distances, pairwise-tree sums; within 3.6e-5 relative of the shader's sequential fp32 sum
+ *       for any data) selects the few candidates that can still be the minimum; a single survivor is the
+ *       answer, several get the literal 64-term chain.  Tiles where many candidates tie at one non-zero cost
+ *       fall back to the exact kernel, so such content costs what LFG_MOTION_EXACT_ONLY costs (plus the filter).
  *   LFG_MOTION_EXACT_ONLY: the literal chain for every (pixel, candidate); content-independent time. */
 typedef enum lfg_motion_mode { LFG_MOTION_PREFILTERED = 0, LFG_MOTION_EXACT_ONLY = 1 } lfg_motion_mode;
 int  lfg_set_motion_mode(lfg_context *ctx, int mode);

@@ -59,6 +59,8 @@ SIGNATURES = {
     "lfg_ring_acquire": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_u32)]),
     "lfg_ring_upload": (_i, [_vp, _u32, _FP]),
     "lfg_ring_download": (_i, [_vp, _u32, _FP]),
+    "lfg_ring_wait": (_i, [_vp, _u32]),
+    "lfg_ring_fence_slot": (_i, [_vp, _u32]),
     "lfg_scale": (_i, [_vp, _FP, _FP]),
     "lfg_motion": (_i, [_vp, _FP, _FP, _FP, _i, ctypes.c_float]),
     "lfg_set_motion_mode": (_i, [_vp, _i]),

@@ -174,6 +174,8 @@ struct lfg_ring {
     std::vector<hipEvent_t> done;            // last transfer touching each slot
     std::vector<uint8_t> busy;
     uint32_t next = 0;
+    hipStream_t copy = nullptr;              // transfers run here, next to the kernels on ctx->stream
+    hipEvent_t ready = nullptr;              // scratch event: "ctx->stream has reached this point"
 };
 
 // ================================================================== library / context
@@ -332,6 +334,9 @@ LFG_EXPORT int lfg_ring_create(lfg_context *ctx, uint32_t slots, size_t slot_byt
     hipError_t e = hipHostMalloc((void **)&r->base, r->slot_bytes * slots, hipHostMallocDefault);
     if (e != hipSuccess) { delete r; return fail_hip(ctx, e, "hipHostMalloc(ring)"); }
     r->done.resize(slots, nullptr); r->busy.assign(slots, 0);
+    e = hipStreamCreateWithFlags(&r->copy, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ready, hipEventDisableTiming);
+    if (e != hipSuccess) { lfg_ring_destroy(r); return fail_hip(ctx, e, "hipStreamCreate(ring)"); }
     for (uint32_t i = 0; i < slots; ++i) {
         e = hipEventCreateWithFlags(&r->done[i], hipEventDisableTiming);
         if (e != hipSuccess) { lfg_ring_destroy(r); return fail_hip(ctx, e, "hipEventCreate(ring)"); }
@@ -342,8 +347,11 @@ LFG_EXPORT int lfg_ring_create(lfg_context *ctx, uint32_t slots, size_t slot_byt
 
 LFG_EXPORT void lfg_ring_destroy(lfg_ring *ring) {
     if (!ring) return;
+    if (ring->copy) (void)hipStreamSynchronize(ring->copy);
     for (uint32_t i = 0; i < ring->slots; ++i)
         if (ring->done[i]) { if (ring->busy[i]) (void)hipEventSynchronize(ring->done[i]); (void)hipEventDestroy(ring->done[i]); }
+    if (ring->ready) (void)hipEventDestroy(ring->ready);
+    if (ring->copy) (void)hipStreamDestroy(ring->copy);
     if (ring->base) (void)hipHostFree(ring->base);
     delete ring;
 }
@@ -358,21 +366,47 @@ LFG_EXPORT int lfg_ring_acquire(lfg_ring *ring, void **out_host_ptr, uint32_t *o
     return LFG_OK;
 }
 
+// Transfers run on the ring's own stream so they overlap the kernels:
+//   upload    copy stream waits for what ctx->stream has been given so far (earlier readers of `dst`),
+//             copies, and ctx->stream then waits for the copy -- kernels enqueued next see the pixels;
+//   download  copy stream waits for what ctx->stream has been given so far (the producers of `src`) and copies;
+//             ctx->stream does NOT wait: before a kernel overwrites `src` again, call lfg_ring_fence_slot.
+static int ring_transfer(lfg_ring *ring, uint32_t slot, const lfg_frame *f, bool upload) {
+    lfg_context *ctx = ring->ctx;
+    if (!f || !f->data) return fail(ctx, LFG_ERR_INVALID, "lfg_ring transfer: NULL frame");
+    const size_t row = (size_t)f->width * bytes_per_pixel(f->format), need = row * f->height;
+    if (ring->slot_bytes < need) return fail(ctx, LFG_ERR_INVALID, "lfg_ring transfer: slot smaller than the frame");
+    LFG_HIP(ctx, hipSetDevice(ctx->device));
+    uint8_t *host = ring->base + (size_t)slot * ring->slot_bytes;
+    LFG_HIP(ctx, hipEventRecord(ring->ready, ctx->stream));
+    LFG_HIP(ctx, hipStreamWaitEvent(ring->copy, ring->ready, 0));
+    if (upload) LFG_HIP(ctx, hipMemcpy2DAsync(f->data, f->pitch, host, row, row, f->height, hipMemcpyHostToDevice, ring->copy));
+    else LFG_HIP(ctx, hipMemcpy2DAsync(host, row, f->data, f->pitch, row, f->height, hipMemcpyDeviceToHost, ring->copy));
+    LFG_HIP(ctx, hipEventRecord(ring->done[slot], ring->copy));
+    ring->busy[slot] = 1;
+    if (upload) LFG_HIP(ctx, hipStreamWaitEvent(ctx->stream, ring->done[slot], 0));
+    return LFG_OK;
+}
+
 LFG_EXPORT int lfg_ring_upload(lfg_ring *ring, uint32_t slot, lfg_frame *dst) {
     if (!ring || slot >= ring->slots) return LFG_ERR_INVALID;
-    int rc = lfg_frame_upload(ring->ctx, dst, ring->base + (size_t)slot * ring->slot_bytes, ring->slot_bytes);
-    if (rc != LFG_OK) return rc;
-    LFG_HIP(ring->ctx, hipEventRecord(ring->done[slot], ring->ctx->stream));
-    ring->busy[slot] = 1;
-    return LFG_OK;
+    return ring_transfer(ring, slot, dst, true);
 }
 
 LFG_EXPORT int lfg_ring_download(lfg_ring *ring, uint32_t slot, const lfg_frame *src) {
     if (!ring || slot >= ring->slots) return LFG_ERR_INVALID;
-    int rc = lfg_frame_download(ring->ctx, src, ring->base + (size_t)slot * ring->slot_bytes, ring->slot_bytes);
-    if (rc != LFG_OK) return rc;
-    LFG_HIP(ring->ctx, hipEventRecord(ring->done[slot], ring->ctx->stream));
-    ring->busy[slot] = 1;
+    return ring_transfer(ring, slot, src, false);
+}
+
+LFG_EXPORT int lfg_ring_wait(lfg_ring *ring, uint32_t slot) {
+    if (!ring || slot >= ring->slots) return LFG_ERR_INVALID;
+    if (ring->busy[slot]) { LFG_HIP(ring->ctx, hipEventSynchronize(ring->done[slot])); ring->busy[slot] = 0; }
+    return LFG_OK;
+}
+
+LFG_EXPORT int lfg_ring_fence_slot(lfg_ring *ring, uint32_t slot) {
+    if (!ring || slot >= ring->slots) return LFG_ERR_INVALID;
+    if (ring->busy[slot]) LFG_HIP(ring->ctx, hipStreamWaitEvent(ring->ctx->stream, ring->done[slot], 0));
     return LFG_OK;
 }
 
@@ -380,6 +414,7 @@ LFG_EXPORT int lfg_ring_download(lfg_ring *ring, uint32_t slot, const lfg_frame 
 
 LFG_EXPORT int lfg_scale(lfg_context *ctx, const lfg_frame *in, lfg_frame *out) {
     if (!ctx) return LFG_ERR_INVALID;
+    LFG_HIP(ctx, hipSetDevice(ctx->device));          // the stream belongs to this device (multi-GPU hosts)
     if (!frame_ok(in, LFG_FORMAT_RGBA8_UNORM) || !frame_ok(out, LFG_FORMAT_RGBA8_UNORM))
         return fail(ctx, LFG_ERR_INVALID, "lfg_scale: frames must be non-empty RGBA8");
     if (in->data == out->data) return fail(ctx, LFG_ERR_INVALID, "lfg_scale: in-place scaling is not supported");
@@ -401,6 +436,7 @@ LFG_EXPORT int lfg_scale(lfg_context *ctx, const lfg_frame *in, lfg_frame *out) 
 LFG_EXPORT int lfg_motion(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *curr, lfg_frame *mv,
                           int block_size, float search_radius) {
     if (!ctx) return LFG_ERR_INVALID;
+    LFG_HIP(ctx, hipSetDevice(ctx->device));          // the stream belongs to this device (multi-GPU hosts)
     if (!frame_ok(prev, LFG_FORMAT_RGBA8_UNORM) || !frame_ok(curr, LFG_FORMAT_RGBA8_UNORM) ||
         !frame_ok(mv, LFG_FORMAT_MV_S8X2))
         return fail(ctx, LFG_ERR_INVALID, "lfg_motion: prev/curr must be RGBA8 and mv MV_S8X2, all non-empty");
@@ -469,6 +505,7 @@ LFG_EXPORT int lfg_motion_last_stats(lfg_context *ctx, uint32_t *out_tiles, uint
 LFG_EXPORT int lfg_interpolate(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *curr, const lfg_frame *mv,
                                lfg_frame *out, float factor) {
     if (!ctx) return LFG_ERR_INVALID;
+    LFG_HIP(ctx, hipSetDevice(ctx->device));          // the stream belongs to this device (multi-GPU hosts)
     if (!frame_ok(prev, LFG_FORMAT_RGBA8_UNORM) || !frame_ok(curr, LFG_FORMAT_RGBA8_UNORM) ||
         !frame_ok(mv, LFG_FORMAT_MV_S8X2) || !frame_ok(out, LFG_FORMAT_RGBA8_UNORM))
         return fail(ctx, LFG_ERR_INVALID, "lfg_interpolate: bad frame (NULL, empty or wrong format)");

@@ -55,13 +55,18 @@ bool FrameManager::CopyFrameData(const Frame& source, Frame& destination) {
     return HipContext::Get().WaitIdle();                      // the reference waits idle (:143)
 }
 
-bool FrameManager::InterpolateFrames(const Frame& previous, const Frame& current, Frame& output, float factor) {
+bool FrameManager::InterpolateFramesAsync(const Frame& previous, const Frame& current, Frame& output, float factor) {
     const lfg_frame p = previous.AsAbi(), c = current.AsAbi();
     lfg_frame o = output.AsAbi();
     if (lfg_interpolate_frames(Ctx(), &p, &c, &o, factor) != LFG_OK) {
         LOG_ERROR("Failed to interpolate frames: ", lfg_last_error(Ctx()));
         return false;
     }
+    return true;
+}
+
+bool FrameManager::InterpolateFrames(const Frame& previous, const Frame& current, Frame& output, float factor) {
+    if (!InterpolateFramesAsync(previous, current, output, factor)) return false;
     return HipContext::Get().WaitIdle();                      // EndSingleTimeCommands waits idle (:183-197)
 }
 

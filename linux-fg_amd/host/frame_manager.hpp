@@ -55,6 +55,8 @@ public:
     // Frame interpolation (src/frame_manager.cpp:216-372): motion (blockSize 8, searchRadius 16) then
     // interpolate; the motion-vector image is a temporary owned by the device context.
     bool InterpolateFrames(const Frame& previous, const Frame& current, Frame& output, float factor);
+    // The same two stages enqueued without the wait (the Scaler pipelines presentation behind them).
+    bool InterpolateFramesAsync(const Frame& previous, const Frame& current, Frame& output, float factor);
 
     // Buffer management (src/frame_manager.cpp:199-214): pinned host memory instead of a
     // host-visible VkBuffer.

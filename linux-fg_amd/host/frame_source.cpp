@@ -62,3 +62,32 @@ bool SyntheticCapture::NextFrame(uint8_t* host) {
     ++m_index;
     return true;
 }
+
+bool RawFileCapture::Initialize(uint32_t width, uint32_t height) {
+    if (width == 0 || height == 0) {
+        LOG_ERROR("RawFileCapture: zero frame size");
+        return false;
+    }
+    m_width = width; m_height = height;
+    if (!m_file) m_file = m_path == "-" ? stdin : fopen(m_path.c_str(), "rb");
+    if (!m_file) {
+        LOG_ERROR("RawFileCapture: cannot open ", m_path);
+        return false;
+    }
+    return true;
+}
+
+bool RawFileCapture::NextFrame(uint8_t* host) {
+    const size_t need = (size_t)m_width * m_height * 4;
+    size_t got = 0;
+    while (m_file && got < need) {                       // pipes deliver short reads
+        const size_t n = fread(host + got, 1, need - got, m_file);
+        if (n == 0) break;
+        got += n;
+    }
+    if (got != need) {
+        LOG_ERROR("RawFileCapture: end of input (", got, " of ", need, " bytes of the next frame)");
+        return false;
+    }
+    return true;
+}

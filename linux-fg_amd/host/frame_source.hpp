@@ -5,6 +5,8 @@
 // through a pinned-host ring instead of a staging buffer allocated and freed per frame.
 #pragma once
 #include <cstdint>
+#include <cstdio>
+#include <string>
 #include <vector>
 
 #include "frame_manager.hpp"
@@ -40,4 +42,21 @@ private:
     uint32_t m_seed, m_width = 0, m_height = 0, m_index = 0;
     int m_shiftX, m_shiftY;
     std::vector<uint8_t> m_last;
+};
+
+// Raw RGBA8 frames (tightly packed, back to back) from a file or a pipe ("-" = stdin): the headless stand-in
+// for a capture device.  NextFrame fails at end of input.
+class RawFileCapture : public FrameSource {
+public:
+    explicit RawFileCapture(std::string path) : m_path(std::move(path)) {}
+    ~RawFileCapture() override { if (m_file && m_file != stdin) fclose(m_file); }
+
+    bool Initialize(uint32_t width, uint32_t height) override;
+    bool NextFrame(uint8_t* host) override;
+    bool GetSize(uint32_t& width, uint32_t& height) const override { width = m_width; height = m_height; return m_width != 0; }
+
+private:
+    std::string m_path;
+    FILE* m_file = nullptr;
+    uint32_t m_width = 0, m_height = 0;
 };

@@ -23,6 +23,9 @@ static void PrintUsage() {
               << "  --frames N               Number of input frames to process (default: 10)\n"
               << "  --device N               HIP device ordinal (default: 0)\n"
               << "  --dump-dir DIR           Write every presented frame to DIR as raw RGBA8\n"
+              << "  --input-raw FILE         Read input frames (raw RGBA8, tightly packed, back to back) from FILE, '-' = stdin\n"
+              << "  --output-raw FILE        Append every presented frame (raw RGBA8) to FILE, '-' = stdout\n"
+              << "  --sync-present           Wait for each call's own frames (reference behaviour) instead of pipelining\n"
               << "  --quiet                  Only warnings and errors\n";
 }
 
@@ -33,7 +36,8 @@ int main(int argc, char* argv[]) {
     config.targetFps = 60;
     uint32_t stream = 0;
     int frames = 10, device = 0;
-    std::string dumpDir;
+    std::string dumpDir, inputRaw, outputRaw;
+    bool syncPresent = false;
 
     for (int i = 1; i < argc; i++) {
         if (strcmp(argv[i], "--help") == 0) { PrintUsage(); return 0; }
@@ -47,6 +51,9 @@ int main(int argc, char* argv[]) {
         else if (strcmp(argv[i], "--frames") == 0 && i + 1 < argc) frames = std::atoi(argv[++i]);
         else if (strcmp(argv[i], "--device") == 0 && i + 1 < argc) device = std::atoi(argv[++i]);
         else if (strcmp(argv[i], "--dump-dir") == 0 && i + 1 < argc) dumpDir = argv[++i];
+        else if (strcmp(argv[i], "--input-raw") == 0 && i + 1 < argc) inputRaw = argv[++i];
+        else if (strcmp(argv[i], "--output-raw") == 0 && i + 1 < argc) outputRaw = argv[++i];
+        else if (strcmp(argv[i], "--sync-present") == 0) syncPresent = true;
         else if (strcmp(argv[i], "--quiet") == 0) Logger::Get().SetMinLevel(Logger::Level::WARNING);
         else {
             char* endPtr;
@@ -76,7 +83,15 @@ int main(int argc, char* argv[]) {
         HipContext::Get().Cleanup();
         return 1;
     }
-    Scaler::Get().SetFrameSource(std::make_unique<SyntheticCapture>(stream));
+    if (!inputRaw.empty()) Scaler::Get().SetFrameSource(std::make_unique<RawFileCapture>(inputRaw));
+    else Scaler::Get().SetFrameSource(std::make_unique<SyntheticCapture>(stream));
+    Scaler::Get().SetPipelined(!syncPresent);
+    FILE* rawOut = nullptr;
+    if (!outputRaw.empty()) {
+        rawOut = outputRaw == "-" ? stdout : fopen(outputRaw.c_str(), "wb");
+        if (!rawOut) { LOG_ERROR("Cannot open ", outputRaw); return 1; }
+    }
+    FILE* report = rawOut == stdout ? stderr : stdout;          // keep the pixel stream clean
     uint64_t checksum = 0, presented = 0, generated = 0;
     Scaler::Get().SetPresenter([&](const uint8_t* rgba, uint32_t w, uint32_t h, bool interpolated) {
         const size_t n = (size_t)w * h * 4;
@@ -89,6 +104,7 @@ int main(int argc, char* argv[]) {
                      interpolated ? "interp" : "real", w, h);
             if (FILE* f = fopen(name, "wb")) { fwrite(rgba, 1, n, f); fclose(f); }
         }
+        if (rawOut) fwrite(rgba, 1, n, rawOut);
         ++presented;
         generated += interpolated ? 1 : 0;
     });
@@ -102,6 +118,7 @@ int main(int argc, char* argv[]) {
     const auto t0 = std::chrono::steady_clock::now();
     bool ok = true;
     for (int i = 0; i < frames && ok; ++i) ok = Scaler::Get().ProcessFrame();
+    ok = ok && Scaler::Get().Flush();                           // the last call's frames
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
     // Teardown order as src/main.cpp:138-141.
@@ -109,9 +126,10 @@ int main(int argc, char* argv[]) {
     FrameManager::Get().Cleanup();
     HipContext::Get().Cleanup();
     if (!ok) { LOG_ERROR("ProcessFrame failed: ", Logger::Get().GetLastError()); return 1; }
-    printf("{\"input_frames\": %d, \"presented\": %llu, \"interpolated\": %llu, \"seconds\": %.4f, "
-           "\"presented_fps\": %.2f, \"checksum\": %llu, \"note\": \"includes host frame synthesis, PCIe upload and readback\"}\n",
+    if (rawOut && rawOut != stdout) fclose(rawOut);
+    fprintf(report, "{\"input_frames\": %d, \"presented\": %llu, \"interpolated\": %llu, \"seconds\": %.4f, "
+           "\"presented_fps\": %.2f, \"checksum\": %llu, \"pipelined\": %s, \"note\": \"includes host frame synthesis, PCIe upload and readback\"}\n",
            frames, (unsigned long long)presented, (unsigned long long)generated, sec, presented / sec,
-           (unsigned long long)checksum);
+           (unsigned long long)checksum, syncPresent ? "false" : "true");
     return 0;
 }

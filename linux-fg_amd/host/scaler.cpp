@@ -23,7 +23,7 @@ bool Scaler::Initialize(const ScalerConfig& config) {
     const size_t inBytes = (size_t)config.inputWidth * config.inputHeight * 4;
     const size_t outBytes = (size_t)config.outputWidth * config.outputHeight * 4;
     if (lfg_ring_create(Ctx(), 3, inBytes, &m_uploadRing) != LFG_OK ||
-        lfg_ring_create(Ctx(), 4, outBytes, &m_readbackRing) != LFG_OK) {
+        lfg_ring_create(Ctx(), 6, outBytes, &m_readbackRing) != LFG_OK) {       // two calls' worth of frames + margin
         LOG_ERROR("Failed to create pinned frame rings: ", lfg_last_error(Ctx()));
         Cleanup();
         return false;
@@ -95,7 +95,8 @@ bool Scaler::ScaleFrame(const Frame& input, Frame& output) {
     return true;      // enqueued; ProcessFrame waits where it needs the pixels
 }
 
-bool Scaler::Present(const Frame& frame, bool interpolated) {
+// Enqueue the read-back of `frame` into a ring slot (copy stream) and remember it for presentation.
+bool Scaler::QueueReadback(Frame& frame, bool interpolated) {
     void* host = nullptr;
     uint32_t slot = 0;
     const lfg_frame f = frame.AsAbi();
@@ -103,11 +104,27 @@ bool Scaler::Present(const Frame& frame, bool interpolated) {
         LOG_ERROR("Failed to read back frame: ", lfg_last_error(Ctx()));
         return false;
     }
-    if (!HipContext::Get().WaitIdle()) return false;
-    if (m_presenter) m_presenter(static_cast<const uint8_t*>(host), frame.width, frame.height, interpolated);
-    ++m_presented;
+    m_lastReadback[frame.data] = slot;
+    m_pending.push_back(Pending{host, slot, frame.width, frame.height, interpolated});
     return true;
 }
+
+// Present the oldest read-backs until only `keep` are left in flight.
+bool Scaler::PresentPending(size_t keep) {
+    while (m_pending.size() > keep) {
+        const Pending p = m_pending.front();
+        m_pending.pop_front();
+        if (lfg_ring_wait(m_readbackRing, p.slot) != LFG_OK) {               // the reference's wait-idle before mapping
+            LOG_ERROR("Failed to wait for a read-back: ", lfg_last_error(Ctx()));
+            return false;
+        }
+        if (m_presenter) m_presenter(static_cast<const uint8_t*>(p.host), p.width, p.height, p.interpolated);
+        ++m_presented;
+    }
+    return true;
+}
+
+bool Scaler::Flush() { return m_readbackRing ? PresentPending(0) : true; }
 
 bool Scaler::ProcessFrame() {
     if (!m_initialized) {
@@ -129,19 +146,31 @@ bool Scaler::ProcessFrame() {
         LOG_ERROR("Failed to capture frame");
         return false;
     }
+    // A frame about to be overwritten may still be on its way to the host (pipelined presentation): the
+    // kernels wait for that transfer on the device.
+    auto fenceBeforeWrite = [&](const Frame& f) {
+        const auto it = m_lastReadback.find(f.data);
+        if (it != m_lastReadback.end()) lfg_ring_fence_slot(m_readbackRing, it->second);
+    };
+    fenceBeforeWrite(m_outputFrame);
     if (!ScaleFrame(m_currentFrame, m_outputFrame)) {
         LOG_ERROR("Failed to scale frame");
         return false;
     }
+    const size_t inFlightBefore = m_pending.size();
     if (m_config.enableInterpolation && m_havePrevious) {
-        if (!FrameManager::Get().InterpolateFrames(m_previousOutput, m_outputFrame, m_interpolatedFrame,
-                                                   m_config.interpolationFactor)) {
+        fenceBeforeWrite(m_interpolatedFrame);
+        auto& fm = FrameManager::Get();
+        if (!(m_pipelined ? fm.InterpolateFramesAsync(m_previousOutput, m_outputFrame, m_interpolatedFrame, m_config.interpolationFactor)
+                          : fm.InterpolateFrames(m_previousOutput, m_outputFrame, m_interpolatedFrame, m_config.interpolationFactor))) {
             LOG_ERROR("Failed to interpolate frame");
             return false;
         }
-        if (!Present(m_interpolatedFrame, true)) return false;       // generated frame first, then the real one
+        if (!QueueReadback(m_interpolatedFrame, true)) return false;     // generated frame first, then the real one
     }
-    if (!Present(m_outputFrame, false)) return false;
+    if (!QueueReadback(m_outputFrame, false)) return false;
+    // Pipelined: present what the previous call queued while this call's work runs; otherwise everything now.
+    if (!PresentPending(m_pipelined ? m_pending.size() - inFlightBefore : 0)) return false;
 
     if (m_config.enableInterpolation) {
         // previous <- current: swap the handles instead of copying the image (src/scaler.cpp:616-621).
@@ -153,6 +182,9 @@ bool Scaler::ProcessFrame() {
 }
 
 void Scaler::Cleanup() {
+    if (m_initialized) Flush();
+    m_pending.clear();
+    m_lastReadback.clear();
     if (Ctx()) HipContext::Get().WaitIdle();
     if (m_uploadRing) { lfg_ring_destroy(m_uploadRing); m_uploadRing = nullptr; }
     if (m_readbackRing) { lfg_ring_destroy(m_readbackRing); m_readbackRing = nullptr; }
