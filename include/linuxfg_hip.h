@@ -179,6 +179,16 @@ int  lfg_set_motion_mode(lfg_context *ctx, int mode);
 int  lfg_motion_last_stats(lfg_context *ctx, uint32_t *out_tiles, uint32_t *out_fallback_tiles,
                            double *out_mean_recorded);
 
+/* Which arithmetic lfg_motion and lfg_interpolate follow.  No reference counterpart: SURVEY.md 8(f) rank 4.
+ *   LFG_SEMANTICS_REFERENCE (default, the parity contract): the shaders as written -- equal block-match costs
+ *       resolve to the first candidate in scan order, so flat areas report (-16,-16) (shaders/motion.comp:27-28,49;
+ *       F6), and the pixel-unit motion vector is added to normalised uv unscaled (shaders/interpolate.comp:17,34-35; F5).
+ *   LFG_SEMANTICS_INTENDED (opt-in): equal costs resolve to the shortest vector (then scan order), so flat areas
+ *       report (0,0); interpolate divides the vector by the image size before adding it to uv, so it displaces
+ *       by pixels.  Everything else (costs, sampling, signs, rounding) is unchanged; the oracle has the same switch. */
+typedef enum lfg_semantics { LFG_SEMANTICS_REFERENCE = 0, LFG_SEMANTICS_INTENDED = 1 } lfg_semantics;
+int  lfg_set_semantics(lfg_context *ctx, int semantics);
+
 /* shaders/interpolate.comp (src/frame_manager.cpp:351-366): MV-displaced bilinear fetch of prev
  * and curr, blended by `factor`.  Literal reference semantics (MV in pixels added to normalised
  * UV). */

@@ -18,6 +18,7 @@ FORMAT_RGBA8 = 0
 FORMAT_MV_S8X2 = 1
 STAGE_SCALE, STAGE_MOTION, STAGE_INTERPOLATE = 0, 1, 2
 MOTION_PREFILTERED, MOTION_EXACT_ONLY = 0, 1
+SEMANTICS_REFERENCE, SEMANTICS_INTENDED = 0, 1
 _BPP = {FORMAT_RGBA8: 4, FORMAT_MV_S8X2: 2}
 
 
@@ -65,6 +66,7 @@ SIGNATURES = {
     "lfg_motion": (_i, [_vp, _FP, _FP, _FP, _i, ctypes.c_float]),
     "lfg_set_motion_mode": (_i, [_vp, _i]),
     "lfg_motion_last_stats": (_i, [_vp, ctypes.POINTER(_u32), ctypes.POINTER(_u32), ctypes.POINTER(ctypes.c_double)]),
+    "lfg_set_semantics": (_i, [_vp, _i]),
     "lfg_interpolate": (_i, [_vp, _FP, _FP, _FP, _FP, ctypes.c_float]),
     "lfg_interpolate_frames": (_i, [_vp, _FP, _FP, _FP, ctypes.c_float]),
     "lfg_mv_export_rgba32f": (_i, [_vp, _FP, _vp]),
@@ -189,6 +191,10 @@ class Context:
     def set_motion_mode(self, mode: int):
         """0 = prefiltered (default), 1 = exact kernel only; results are identical."""
         self._check(self.lib.lfg_set_motion_mode(self.h, mode), "lfg_set_motion_mode")
+
+    def set_semantics(self, semantics: int):
+        """0 = the shaders as written (parity contract), 1 = opt-in "intended" tie-break and motion-vector units."""
+        self._check(self.lib.lfg_set_semantics(self.h, semantics), "lfg_set_semantics")
 
     def motion_last_stats(self):
         """(tiles, tiles that fell back to the exact kernel, mean candidates recorded per pixel elsewhere)."""

@@ -63,6 +63,9 @@ __device__ __forceinline__ V4 sample_with_motion(const uint8_t *__restrict__ img
 
 __device__ __forceinline__ float mixf(float x, float y, float a) { return x * (1.0f - a) + y * a; }
 
+// INTENDED = false: interpolate.comp as written.  INTENDED = true (opt-in, lfg_set_semantics):
+// the motion vector is divided by the image size before it is added to uv, so it displaces by pixels.
+template <bool INTENDED>
 __global__ __launch_bounds__(256) void interpolate_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     const int8_t *__restrict__ mv, int mvPitch, uint8_t *__restrict__ out, int outPitch,
@@ -96,7 +99,8 @@ __global__ __launch_bounds__(256) void interpolate_kernel(
     for (int i = 0; i < 4; ++i) {
         const int px = px0 + i;
         const float uvx = ((float)px + 0.5f) / (float)W;
-        const float mx = (float)m[2 * i], my = (float)m[2 * i + 1];
+        float mx = (float)m[2 * i], my = (float)m[2 * i + 1];
+        if (INTENDED) { mx = mx / (float)W; my = my / (float)H; }
         const V4 p = sample_with_motion(prev, W, H, prevPitch, uvx, uvy, mx, my, -t);
         const V4 c = sample_with_motion(curr, W, H, currPitch, uvx, uvy, mx, my, 1.0f - t);
         o[i] = pack_rgba8_unorm(mixf(p.x, c.x, t), mixf(p.y, c.y, t), mixf(p.z, c.z, t), mixf(p.w, c.w, t));
@@ -110,13 +114,19 @@ __global__ __launch_bounds__(256) void interpolate_kernel(
 }
 
 hipError_t launch_interpolate(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
-                              const lfg_frame &mv, const lfg_frame &out, float factor) {
+                              const lfg_frame &mv, const lfg_frame &out, float factor, bool intended) {
     const int quads = ((int)out.width + 3) / 4;
     dim3 grid((quads + 63) / 64, (out.height + 3) / 4);
-    hipLaunchKernelGGL(interpolate_kernel, grid, dim3(256), 0, s,
-                       (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
-                       (const int8_t *)mv.data, (int)mv.pitch, (uint8_t *)out.data, (int)out.pitch,
-                       (int)out.width, (int)out.height, factor);
+    if (intended)
+        hipLaunchKernelGGL(interpolate_kernel<true>, grid, dim3(256), 0, s,
+                           (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
+                           (const int8_t *)mv.data, (int)mv.pitch, (uint8_t *)out.data, (int)out.pitch,
+                           (int)out.width, (int)out.height, factor);
+    else
+        hipLaunchKernelGGL(interpolate_kernel<false>, grid, dim3(256), 0, s,
+                           (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
+                           (const int8_t *)mv.data, (int)mv.pitch, (uint8_t *)out.data, (int)out.pitch,
+                           (int)out.width, (int)out.height, factor);
     return hipGetLastError();
 }
 

@@ -108,6 +108,19 @@ void trim_axis_tables(lfg_context *ctx) {
     }
 }
 
+// ---- candidate tables of the 8/16 motion paths, both tie-break rules (tiny; built at the first lfg_motion)
+
+int ensure_motion_tables(lfg_context *ctx) {
+    if (ctx->motion_tables) return LFG_OK;
+    std::vector<uint32_t> host(4 * lfg::kMotionTableWords, 0u);
+    for (int sem = 0; sem < 2; ++sem)
+        lfg::motion_tables(sem != 0, host.data() + (2 * sem) * lfg::kMotionTableWords,
+                           host.data() + (2 * sem + 1) * lfg::kMotionTableWords);
+    LFG_HIP(ctx, hipMalloc((void **)&ctx->motion_tables, host.size() * sizeof(uint32_t)));
+    LFG_HIP(ctx, hipMemcpy(ctx->motion_tables, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return LFG_OK;
+}
+
 // ---- scratch of the prefiltered motion path (per frame size; kept between calls)
 
 int ensure_motion_workspace(lfg_context *ctx, uint32_t width, uint32_t height) {
@@ -124,9 +137,6 @@ int ensure_motion_workspace(lfg_context *ctx, uint32_t width, uint32_t height) {
     } else {
         LFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    uint32_t order[33 * 33];
-    lfg::motion_candidate_order(order);
-    LFG_HIP(ctx, hipMemcpy(ctx->motion_ws + layout.order, order, sizeof order, hipMemcpyHostToDevice));
     ctx->motion_ws_layout = layout;
     ctx->motion_ws_w = width; ctx->motion_ws_h = height;
     return LFG_OK;
@@ -220,6 +230,7 @@ LFG_EXPORT void lfg_context_destroy(lfg_context *ctx) {
     for (auto &p : ctx->prof_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto &t : ctx->tables) { (void)hipFree(t.d_start); (void)hipFree(t.d_weight); }
     if (ctx->mv_tmp.data && ctx->mv_tmp.owned) (void)hipFree(ctx->mv_tmp.data);
+    if (ctx->motion_tables) (void)hipFree(ctx->motion_tables);
     if (ctx->motion_ws) (void)hipFree(ctx->motion_ws);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -449,6 +460,13 @@ LFG_EXPORT int lfg_motion(lfg_context *ctx, const lfg_frame *prev, const lfg_fra
         return fail(ctx, LFG_ERR_INVALID, "lfg_motion: RGBA8 frames must be 4-byte aligned");
     const int R = (int)search_radius;
     const bool tiled = block_size == 8 && R == 16;
+    const uint32_t *rank2scan = nullptr, *order32 = nullptr;
+    if (tiled) {
+        int rc = ensure_motion_tables(ctx);
+        if (rc != LFG_OK) return rc;
+        rank2scan = ctx->motion_tables + (2 * ctx->semantics) * lfg::kMotionTableWords;
+        order32 = rank2scan + lfg::kMotionTableWords;
+    }
     if (tiled && ctx->motion_mode == LFG_MOTION_PREFILTERED) {
         int rc = ensure_motion_workspace(ctx, curr->width, curr->height);
         if (rc != LFG_OK) return rc;
@@ -456,10 +474,18 @@ LFG_EXPORT int lfg_motion(lfg_context *ctx, const lfg_frame *prev, const lfg_fra
     StageTimer timer(ctx, LFG_STAGE_MOTION);
     hipError_t e;
     if (tiled && ctx->motion_mode == LFG_MOTION_PREFILTERED)
-        e = lfg::launch_motion_prefiltered_8_16(ctx->stream, *prev, *curr, *mv, ctx->motion_ws, ctx->motion_ws_layout, ctx->motion_slots);
-    else if (tiled) e = lfg::launch_motion_tiled_8_16(ctx->stream, *prev, *curr, *mv, nullptr);
-    else e = lfg::launch_motion_generic(ctx->stream, *prev, *curr, *mv, block_size, R);
+        e = lfg::launch_motion_prefiltered_8_16(ctx->stream, *prev, *curr, *mv, ctx->motion_ws, ctx->motion_ws_layout, ctx->motion_slots,
+                                                rank2scan, order32);
+    else if (tiled) e = lfg::launch_motion_tiled_8_16(ctx->stream, *prev, *curr, *mv, nullptr, rank2scan);
+    else e = lfg::launch_motion_generic(ctx->stream, *prev, *curr, *mv, block_size, R, ctx->semantics != 0);
     if (e != hipSuccess) return fail_hip(ctx, e, "motion kernel launch");
+    return LFG_OK;
+}
+
+LFG_EXPORT int lfg_set_semantics(lfg_context *ctx, int semantics) {
+    if (!ctx || (semantics != LFG_SEMANTICS_REFERENCE && semantics != LFG_SEMANTICS_INTENDED))
+        return fail(ctx, LFG_ERR_INVALID, "lfg_set_semantics: unknown semantics");
+    ctx->semantics = semantics;
     return LFG_OK;
 }
 
@@ -516,7 +542,7 @@ LFG_EXPORT int lfg_interpolate(lfg_context *ctx, const lfg_frame *prev, const lf
     if (out->data == prev->data || out->data == curr->data)
         return fail(ctx, LFG_ERR_INVALID, "lfg_interpolate: output aliases an input");
     StageTimer timer(ctx, LFG_STAGE_INTERPOLATE);
-    hipError_t e = lfg::launch_interpolate(ctx->stream, *prev, *curr, *mv, *out, factor);
+    hipError_t e = lfg::launch_interpolate(ctx->stream, *prev, *curr, *mv, *out, factor, ctx->semantics != 0);
     if (e != hipSuccess) return fail_hip(ctx, e, "interpolate kernel launch");
     return LFG_OK;
 }

@@ -55,6 +55,8 @@ struct lfg_context {
     lfg::MotionWorkspaceLayout motion_ws_layout{};
     int motion_slots = 0;                      // prefilter workgroups resident at once on this device (0 = not queried yet)
     int motion_mode = 0;                       // 0: prefilter + exact fallback, 1: exact kernel only
+    int semantics = 0;                         // 0: the shaders as written, 1: "intended" (lfg_set_semantics)
+    uint32_t *motion_tables = nullptr;         // device: [semantics][rank2scan | order32], kMotionTableWords each
     // profiling
     bool profile = false;
     std::vector<lfg::ProfileSlot> prof_pending;
@@ -73,18 +75,21 @@ hipError_t launch_scale_2x(hipStream_t s, const lfg_frame &in, const lfg_frame &
                            const AxisTable &tx, const AxisTable &ty);
 bool scale_2x_supported(const lfg_frame &in, const lfg_frame &out);
 hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
-                                    const lfg_frame &mv, const uint32_t *tileFlags);
+                                    const lfg_frame &mv, const uint32_t *tileFlags, const uint32_t *rank2scan);
+// Candidate tables of the blockSize 8 / searchRadius 16 paths for one tie-break rule (motion.hip: motion_tables).
+constexpr int kMotionTableWords = 1092;     // 33 * 33 candidates + the sentinel, padded to a multiple of 4
+void motion_tables(bool intended, uint32_t *rank2scan, uint32_t *order32);
 // Prefiltered motion path (motion.hip): MotionWorkspaceLayout = byte offsets of its scratch arrays.
 size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, MotionWorkspaceLayout *layout);
 PrefilterSplit prefilter_split(uint32_t width, uint32_t height, int slots);
 int prefilter_slots();      // workgroups of the prefilter kernel the current device holds at once
-void motion_candidate_order(uint32_t *order32_1089);
 hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
-                                          const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &layout, int slots);
+                                          const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &layout, int slots,
+                                          const uint32_t *rank2scan, const uint32_t *order32);
 hipError_t launch_motion_generic(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
-                                 const lfg_frame &mv, int block_size, int radius);
+                                 const lfg_frame &mv, int block_size, int radius, bool intended);
 hipError_t launch_interpolate(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
-                              const lfg_frame &mv, const lfg_frame &out, float factor);
+                              const lfg_frame &mv, const lfg_frame &out, float factor, bool intended);
 hipError_t launch_mv_export(hipStream_t s, const lfg_frame &mv, float *rgba32f);
 hipError_t launch_sqrt_selftest(hipStream_t s, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *d_mismatch);
 

@@ -33,6 +33,8 @@
 #include "lfg_device.hpp"
 #include "lfg_internal.hpp"
 
+#include <algorithm>
+
 namespace lfg {
 
 // Correctly rounded sqrtf for the inputs this kernel produces: x = 0, or a sum of four squares in
@@ -86,7 +88,11 @@ static_assert(kNT / 64 * kMainRows >= kDH && kExtra <= kNT, "phase-A map covers 
 
 __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
-    int8_t *__restrict__ mv, int mvPitch, int W, int H, const uint32_t *__restrict__ tileFlags) {
+    int8_t *__restrict__ mv, int mvPitch, int W, int H, const uint32_t *__restrict__ tileFlags,
+    const uint32_t *__restrict__ rank2scan) {
+    // Candidates are visited in TIE ORDER: rank2scan[r] is the scan index (dy+R)*33 + (dx+R) of the r-th candidate
+    // and the first strict minimum wins, so the table decides between equal costs.  Reference semantics: the
+    // identity (motion.comp's scan order).  Entry kCand is a sentinel (scan index kCand, one row below the window).
     __shared__ __attribute__((aligned(16))) float sD[2][kDH * kDS];    // 2 x 21 KB
 
     // Second pass of the prefiltered path: only the tiles the prefilter gave up on (flag != 0).
@@ -133,7 +139,8 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
 
     // ---- phase A: D(c) = distance(curr(c), prev(c + m)) for one candidate, 0 for c outside the image.
     auto phaseA = [&](int cand, int buf) {
-        const int dyi = cand / kSide, dxi = cand - dyi * kSide;       // dy + R, dx + R (wave-uniform)
+        const int scan = (int)rank2scan[cand];
+        const int dyi = scan / kSide, dxi = scan - dyi * kSide;       // dy + R, dx + R (wave-uniform)
         const int candOff = dyi * prevPitch + dxi * 4;
         int o[kPos];
         if (interior) {
@@ -226,7 +233,8 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
         uint32_t o[4] = {0u, 0u, 0u, 0u};                             // 8 x (int8 dx, int8 dy)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int dyi = bestCand[i] / kSide, dxi = bestCand[i] - dyi * kSide;
+            const int scan = (int)rank2scan[bestCand[i]];
+            const int dyi = scan / kSide, dxi = scan - dyi * kSide;
             const uint32_t v = (uint32_t)(uint8_t)(int8_t)(dxi - kR) | ((uint32_t)(uint8_t)(int8_t)(dyi - kR) << 8);
             o[i >> 1] |= v << (16 * (i & 1));
         }
@@ -320,8 +328,8 @@ static_assert(kPTW + kB - 1 <= 64 && kWinW >= kPTW + kB - 1 + 2 * kR, "one lane 
 typedef const __attribute__((address_space(3))) uint32_t *lds_ro_u32_ptr;
 typedef const __attribute__((address_space(3))) float *lds_ro_f32_ptr;
 
-// order32[e] = candidate index (dy+R)*33 + (dx+R) in the low half, its window offset (dx+R)*kWinH + (dy+R)
-// in the high half; 32-bit entries so the wave-uniform reads are scalar loads.
+// order32[e] = the candidate's rank in the tie order (motion_tables) in the low half, its window offset
+// (dx+R)*kWinH + (dy+R) in the high half; 32-bit entries so the wave-uniform reads are scalar loads.
 __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int W, int H, uint2 *__restrict__ list, float *__restrict__ uminOut,
@@ -632,7 +640,9 @@ __global__ __launch_bounds__(256) void motion_resolve_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int8_t *__restrict__ mv, int mvPitch, int W, int H, const uint2 *__restrict__ list,
     const float *__restrict__ uminIn, const uint32_t *__restrict__ countIn, const uint32_t *__restrict__ tileFlags,
-    int tilesX, PrefilterSplit sp) {
+    int tilesX, PrefilterSplit sp, const uint32_t *__restrict__ rank2scan) {
+    // Candidates are identified by their RANK in the tie order everywhere in the prefiltered path (lists, the
+    // zero-cost encoding), so "smallest rank among equal costs" is the tie-break; rank2scan turns it into (dx, dy).
     const int px = blockIdx.x * 64 + (threadIdx.x & 63);
     const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (px >= W || py >= H) return;
@@ -663,7 +673,7 @@ __global__ __launch_bounds__(256) void motion_resolve_kernel(
     for (int c = 0; c < nLists; ++c) bound = __builtin_fminf(bound, thrs[(size_t)c * thrStride]);
     int8_t *dst = mv + (size_t)py * (size_t)mvPitch + (size_t)px * 2u;
     if (bound < 0.5f) {                    // a zero-cost candidate exists; the first one in scan order is encoded here
-        const uint32_t zc = __builtin_bit_cast(uint32_t, bound) - 0x00800000u;
+        const uint32_t zc = rank2scan[__builtin_bit_cast(uint32_t, bound) - 0x00800000u];
         const int zdy = (int)zc / kSide, zdx = (int)zc - zdy * kSide;
         dst[0] = (int8_t)(zdx - kR);
         dst[1] = (int8_t)(zdy - kR);
@@ -702,22 +712,24 @@ __global__ __launch_bounds__(256) void motion_resolve_kernel(
                 if (__builtin_bit_cast(float, rec.x) <= bound) { cand = rec.y; break; }
             }
             if (cand == 0xFFFFFFFFu) break;
-            const int dyi = (int)cand / kSide, dxi = (int)cand - dyi * kSide;
+            const int cscan = (int)rank2scan[cand];
+            const int dyi = cscan / kSide, dxi = cscan - dyi * kSide;
             const float v = exact_cost(prev, prevPitch, curr, currPitch, W, H, px, py, dxi - kR, dyi - kR);
             if (v < bestV || (v == bestV && cand < bestC)) { bestV = v; bestC = cand; }
         }
     }
-    const int dyi = (int)bestC / kSide, dxi = (int)bestC - dyi * kSide;
+    const int bscan = (int)rank2scan[bestC];
+    const int dyi = bscan / kSide, dxi = bscan - dyi * kSide;
     dst[0] = (int8_t)(dxi - kR);
     dst[1] = (int8_t)(dyi - kR);
 }
 
 hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
-                                    const lfg_frame &mv, const uint32_t *tileFlags) {
+                                    const lfg_frame &mv, const uint32_t *tileFlags, const uint32_t *rank2scan) {
     dim3 grid((curr.width + kTW - 1) / kTW, (curr.height + kTH - 1) / kTH);
     hipLaunchKernelGGL(motion_tiled_8_16_kernel, grid, dim3(kNT), 0, s,
                        (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
-                       (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, tileFlags);
+                       (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, tileFlags, rank2scan);
     return hipGetLastError();
 }
 
@@ -731,11 +743,11 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, Motion
     l.umin = align(l.list + px * kListK * sizeof(uint2));
     l.count = align(l.umin + px * sizeof(float));
     l.tileFlags = align(l.count + px * sizeof(uint32_t));
-    l.order = align(l.tileFlags + tiles * sizeof(uint32_t));
+    l.order = align(l.tileFlags + tiles * sizeof(uint32_t));          // (unused: the tables live on the context)
     // auxiliary arrays of the shared tiles (see prefilter_split): one 56 x 64 block per unit
     const PrefilterSplit sp = prefilter_split(width, height, slots);
     const size_t auxUnits = (size_t)(sp.units - sp.fullTiles);
-    l.auxList = align(l.order + kCand * sizeof(uint32_t));
+    l.auxList = l.order;
     l.auxUmin = align(l.auxList + auxUnits * kPTH * kPTW * kListK * sizeof(uint2));
     l.auxCount = align(l.auxUmin + auxUnits * kPTH * kPTW * sizeof(float));
     l.total = align(l.auxCount + auxUnits * kPTH * kPTW * sizeof(uint32_t));
@@ -767,12 +779,27 @@ int prefilter_slots() {
     return cus * perCu;
 }
 
-void motion_candidate_order(uint32_t *order32) {
-    uint16_t order[kCand];
-    // A fixed pseudo-random permutation (Fisher-Yates driven by a 32-bit LCG).  Visiting the candidates in
-    // an order unrelated to their position makes the sequence of costs behave like a random sample, so a
-    // pixel sees only ~ln(1089) running minima -- for smooth content and for image borders alike, where a
+// Tables of the 8/16 motion paths for one tie-break rule (kMotionTableWords uint32 each, see lfg_internal.hpp):
+//   rank2scan[r], r = 0..kCand   scan index (dy+R)*33 + (dx+R) of the candidate with rank r in the tie order;
+//                                reference semantics: r itself (motion.comp's scan, first strict minimum wins);
+//                                intended semantics: candidates sorted by dx*dx + dy*dy, then scan order, so equal
+//                                costs resolve to the shortest vector.  Entry kCand is the sentinel kCand.
+//   order32[e], e = 0..kCand-1   the prefilter's visiting order: rank in the low half, offset of the candidate in
+//                                the LDS window, (dx+R)*kWinH + (dy+R), in the high half.
+void motion_tables(bool intended, uint32_t *rank2scan, uint32_t *order32) {
+    uint16_t byRank[kCand], rankOf[kCand];
+    for (int i = 0; i < kCand; ++i) byRank[i] = (uint16_t)i;
+    if (intended) {
+        auto d2 = [](int scan) { const int dy = scan / kSide - kR, dx = scan % kSide - kR; return dx * dx + dy * dy; };
+        std::stable_sort(byRank, byRank + kCand, [&](uint16_t a, uint16_t b) { return d2(a) < d2(b); });
+    }
+    for (int r = 0; r < kCand; ++r) { rank2scan[r] = byRank[r]; rankOf[byRank[r]] = (uint16_t)r; }
+    rank2scan[kCand] = kCand;
+    // A fixed pseudo-random permutation of the scan indices (Fisher-Yates driven by a 32-bit LCG).  Visiting the
+    // candidates in an order unrelated to their position makes the sequence of costs behave like a random sample, so
+    // a pixel sees only ~ln(1089) running minima -- for smooth content and for image borders alike, where a
     // spatially ordered walk would keep finding slightly better candidates and overflow the lists.
+    uint16_t order[kCand];
     for (int i = 0; i < kCand; ++i) order[i] = (uint16_t)i;
     uint32_t state = 0x9E3779B9u;
     for (int i = kCand - 1; i > 0; --i) {
@@ -785,20 +812,20 @@ void motion_candidate_order(uint32_t *order32) {
     for (int i = 0; i < kCand; ++i) {
         if (order[i] == kR * kSide + kR) { order[i] = order[0]; order[0] = (uint16_t)(kR * kSide + kR); break; }
     }
-    for (int i = 0; i < kCand; ++i) {      // low half: candidate index, high half: its offset in the LDS window
+    for (int i = 0; i < kCand; ++i) {
         const uint32_t dyi = order[i] / kSide, dxi = order[i] % kSide;
-        order32[i] = order[i] | ((dxi * kWinH + dyi) << 16);
+        order32[i] = rankOf[order[i]] | ((dxi * kWinH + dyi) << 16);
     }
 }
 
 hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
-                                          const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &l, int slots) {
+                                          const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &l, int slots,
+                                          const uint32_t *rank2scan, const uint32_t *order) {
     const int tilesX = ((int)curr.width + kTW - 1) / kTW, tilesY = ((int)curr.height + kTH - 1) / kTH;
     uint2 *list = reinterpret_cast<uint2 *>(workspace + l.list);
     float *umin = reinterpret_cast<float *>(workspace + l.umin);
     uint32_t *count = reinterpret_cast<uint32_t *>(workspace + l.count);
     uint32_t *flags = reinterpret_cast<uint32_t *>(workspace + l.tileFlags);
-    const uint32_t *order = reinterpret_cast<const uint32_t *>(workspace + l.order);
     static_assert(kPTH == kTH, "prefilter tiles and exact tiles share their rows");
     PrefilterSplit sp = prefilter_split(curr.width, curr.height, slots);
     sp.auxList = reinterpret_cast<uint2 *>(workspace + l.auxList);
@@ -813,10 +840,10 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(motion_resolve_kernel, dim3((curr.width + 63) / 64, (curr.height + 3) / 4), dim3(256), 0, s,
                        (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
-                       (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, sp);
+                       (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, sp, rank2scan);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return launch_motion_tiled_8_16(s, prev, curr, mv, flags);
+    return launch_motion_tiled_8_16(s, prev, curr, mv, flags, rank2scan);
 }
 
 // Diagnostic: compares exact_sqrt with __builtin_sqrtf for every float whose bit pattern lies in
@@ -839,6 +866,7 @@ hipError_t launch_sqrt_selftest(hipStream_t s, uint32_t lo, uint32_t hi, unsigne
 
 // ------------------------------------------------------------------------------ generic (literal)
 
+template <bool INTENDED>     // tie-break: false = motion.comp (first in scan order), true = shortest vector, then scan order
 __global__ __launch_bounds__(256) void motion_generic_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int8_t *__restrict__ mv, int mvPitch, int W, int H, int B, int R) {
@@ -847,7 +875,7 @@ __global__ __launch_bounds__(256) void motion_generic_kernel(
     if (px >= W || py >= H) return;
     const int bsx = px - B / 2, bsy = py - B / 2;
     float minDiff = 1e10f;
-    int bx = 0, by = 0;
+    int bx = 0, by = 0, bestD2 = 0x7FFFFFFF;
     for (int dy = -R; dy <= R; ++dy) {
         for (int dx = -R; dx <= R; ++dx) {
             float diff = 0.0f;
@@ -869,7 +897,10 @@ __global__ __launch_bounds__(256) void motion_generic_kernel(
                     diff += dist4<false>(cc, pp);
                 }
             }
-            if (diff < minDiff) { minDiff = diff; bx = dx; by = dy; }
+            if (INTENDED) {
+                const int d2 = dx * dx + dy * dy;
+                if (diff < minDiff || (diff == minDiff && d2 < bestD2)) { minDiff = diff; bestD2 = d2; bx = dx; by = dy; }
+            } else if (diff < minDiff) { minDiff = diff; bx = dx; by = dy; }
         }
     }
     int8_t *dst = mv + (size_t)py * (size_t)mvPitch + (size_t)px * 2u;
@@ -877,11 +908,16 @@ __global__ __launch_bounds__(256) void motion_generic_kernel(
 }
 
 hipError_t launch_motion_generic(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
-                                 const lfg_frame &mv, int block_size, int radius) {
+                                 const lfg_frame &mv, int block_size, int radius, bool intended) {
     dim3 grid((curr.width + 63) / 64, (curr.height + 3) / 4);
-    hipLaunchKernelGGL(motion_generic_kernel, grid, dim3(256), 0, s,
-                       (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
-                       (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, block_size, radius);
+    if (intended)
+        hipLaunchKernelGGL(motion_generic_kernel<true>, grid, dim3(256), 0, s,
+                           (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
+                           (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, block_size, radius);
+    else
+        hipLaunchKernelGGL(motion_generic_kernel<false>, grid, dim3(256), 0, s,
+                           (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
+                           (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, block_size, radius);
     return hipGetLastError();
 }
 

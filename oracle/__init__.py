@@ -44,6 +44,10 @@ def lib() -> ctypes.CDLL:
         L.lfg_oracle_motion.restype = i
         L.lfg_oracle_interpolate.argtypes = [_u8p, _u8p, _f32p, i, i, ctypes.c_float, _u8p, i, i, i, i, i]
         L.lfg_oracle_interpolate.restype = i
+        L.lfg_oracle_motion_ex.argtypes = [_u8p, _u8p, i, i, i, ctypes.c_float, _f32p, i, i, i, i, i, i]
+        L.lfg_oracle_motion_ex.restype = i
+        L.lfg_oracle_interpolate_ex.argtypes = [_u8p, _u8p, _f32p, i, i, ctypes.c_float, _u8p, i, i, i, i, i, i]
+        L.lfg_oracle_interpolate_ex.restype = i
         L.lfg_oracle_lanczos_taps.argtypes = [i, i, i, _f32p]
         L.lfg_oracle_lanczos_taps.restype = i
         _lib = L
@@ -83,26 +87,31 @@ def scale(frame: np.ndarray, out_w: int, out_h: int, roi=None, threads: int | No
     return out
 
 
+REFERENCE, INTENDED = 0, 1      # semantics: the shaders as written / the opt-in "intended" variant (not the parity contract)
+
+
 def motion(prev: np.ndarray, curr: np.ndarray, block_size: int = 8, search_radius: float = 16.0,
-           roi=None, threads: int | None = None) -> np.ndarray:
-    """shaders/motion.comp.  Returns (H, W, 2) float32 motion vectors (x, y); 0 outside ``roi``."""
+           roi=None, threads: int | None = None, semantics: int = REFERENCE) -> np.ndarray:
+    """shaders/motion.comp.  Returns (H, W, 2) float32 motion vectors (x, y); 0 outside ``roi``.
+    ``semantics=INTENDED``: equal costs are broken towards the shortest vector (flat areas give (0,0))."""
     p, c = _frame(prev, "prev"), _frame(curr, "curr")
     if p.shape != c.shape:
         raise ValueError("prev and curr differ in size")
     H, W = p.shape[:2]
     mv = np.zeros((H, W, 2), np.float32)
     x0, y0, x1, y1 = _roi(roi, W, H)
-    rc = lib().lfg_oracle_motion(p.ctypes.data_as(_u8p), c.ctypes.data_as(_u8p), W, H, int(block_size),
-                                 float(search_radius), mv.ctypes.data_as(_f32p), x0, y0, x1, y1,
-                                 threads or default_threads())
+    rc = lib().lfg_oracle_motion_ex(p.ctypes.data_as(_u8p), c.ctypes.data_as(_u8p), W, H, int(block_size),
+                                    float(search_radius), mv.ctypes.data_as(_f32p), x0, y0, x1, y1,
+                                    threads or default_threads(), int(semantics))
     if rc != 0:
         raise ValueError("lfg_oracle_motion: bad arguments")
     return mv
 
 
 def interpolate(prev: np.ndarray, curr: np.ndarray, mv: np.ndarray, factor: float = 0.5,
-                roi=None, threads: int | None = None) -> np.ndarray:
-    """shaders/interpolate.comp.  ``mv`` is (H, W, 2) float32 in whole pixels (literal semantics, F5)."""
+                roi=None, threads: int | None = None, semantics: int = REFERENCE) -> np.ndarray:
+    """shaders/interpolate.comp.  ``mv`` is (H, W, 2) float32 in whole pixels (literal semantics, F5).
+    ``semantics=INTENDED``: the vector is divided by the image size before it is added to uv."""
     p, c = _frame(prev, "prev"), _frame(curr, "curr")
     if p.shape != c.shape:
         raise ValueError("prev and curr differ in size")
@@ -112,9 +121,9 @@ def interpolate(prev: np.ndarray, curr: np.ndarray, mv: np.ndarray, factor: floa
         raise ValueError(f"mv: expected {(H, W, 2)}, got {m.shape}")
     out = np.zeros((H, W, 4), np.uint8)
     x0, y0, x1, y1 = _roi(roi, W, H)
-    rc = lib().lfg_oracle_interpolate(p.ctypes.data_as(_u8p), c.ctypes.data_as(_u8p), m.ctypes.data_as(_f32p),
-                                      W, H, float(factor), out.ctypes.data_as(_u8p), x0, y0, x1, y1,
-                                      threads or default_threads())
+    rc = lib().lfg_oracle_interpolate_ex(p.ctypes.data_as(_u8p), c.ctypes.data_as(_u8p), m.ctypes.data_as(_f32p),
+                                         W, H, float(factor), out.ctypes.data_as(_u8p), x0, y0, x1, y1,
+                                         threads or default_threads(), int(semantics))
     if rc != 0:
         raise ValueError("lfg_oracle_interpolate: bad arguments")
     return out

@@ -135,6 +135,7 @@ typedef struct {
     float *mv_out;
     int inW, inH, W, H;          /* W,H = output / image size */
     int blockSize; float searchRadius, factor;
+    int semantics;               /* 0 = the shaders as written; 1 = "intended" (opt-in, see lfg_oracle_*_ex) */
     int x0, y0, x1, y1;
     int row_next;                /* work counter, protected by mu */
     pthread_mutex_t mu;
@@ -164,7 +165,7 @@ static void motion_row(const job_t *j, int py) {
     for (int px = j->x0; px < j->x1; px++) {             /* motion.comp:16-57 */
         int bsx = px - bs / 2, bsy = py - bs / 2;
         float bestx = 0.0f, besty = 0.0f;
-        float minDiff = 1e10f;
+        float minDiff = 1e10f, bestD2 = 3.0e38f;
         for (float dy = -R; dy <= R; dy += 1.0f) {
             for (float dx = -R; dx <= R; dx += 1.0f) {
                 int mx = (int)dx, my = (int)dy;          /* ivec2(motion): truncation */
@@ -180,7 +181,13 @@ static void motion_row(const job_t *j, int py) {
                         diff += distance4(cc, pc);
                     }
                 }
-                if (diff < minDiff) { minDiff = diff; bestx = dx; besty = dy; }
+                if (j->semantics == 0) {
+                    if (diff < minDiff) { minDiff = diff; bestx = dx; besty = dy; }         /* motion.comp:49-52 */
+                } else {
+                    /* intended: among equal costs the shortest vector wins, then scan order */
+                    float d2 = dx * dx + dy * dy;
+                    if (diff < minDiff || (diff == minDiff && d2 < bestD2)) { minDiff = diff; bestD2 = d2; bestx = dx; besty = dy; }
+                }
             }
         }
         float *o = j->mv_out + ((size_t)py * (size_t)W + (size_t)px) * 2u;
@@ -207,8 +214,10 @@ static void interpolate_row(const job_t *j, int py) {
         float uvx = ((float)px + 0.5f) / (float)W;
         float uvy = ((float)py + 0.5f) / (float)H;
         const float *m = j->mv_in + ((size_t)py * (size_t)W + (size_t)px) * 2u;  /* choice (8) */
-        vec4 p = sample_with_motion(j->a, W, H, uvx, uvy, m[0], m[1], -t);
-        vec4 c = sample_with_motion(j->b, W, H, uvx, uvy, m[0], m[1], 1.0f - t);
+        float mx = m[0], my = m[1];
+        if (j->semantics != 0) { mx = mx / (float)W; my = my / (float)H; }       /* intended: pixels -> uv units */
+        vec4 p = sample_with_motion(j->a, W, H, uvx, uvy, mx, my, -t);
+        vec4 c = sample_with_motion(j->b, W, H, uvx, uvy, mx, my, 1.0f - t);
         uint8_t *o = j->out8 + ((size_t)py * (size_t)W + (size_t)px) * 4u;
         o[0] = float_to_unorm8(mixf(p.x, c.x, t)); o[1] = float_to_unorm8(mixf(p.y, c.y, t));
         o[2] = float_to_unorm8(mixf(p.z, c.z, t)); o[3] = float_to_unorm8(mixf(p.w, c.w, t));
@@ -261,13 +270,35 @@ LFG_EXPORT int lfg_oracle_scale(const uint8_t *in, int inW, int inH, uint8_t *ou
     return run(&j, nthreads);
 }
 
-LFG_EXPORT int lfg_oracle_motion(const uint8_t *prev, const uint8_t *curr, int W, int H,
-                                 int blockSize, float searchRadius, float *mv_xy,
-                                 int x0, int y0, int x1, int y1, int nthreads) {
+/* semantics 0: motion.comp as written.  semantics 1 ("intended"; NOT the parity contract):
+ * among candidates of equal cost the one with the smallest dx*dx + dy*dy wins, scan order breaking what is left,
+ * so flat areas report (0,0) instead of (-R,-R) (F6). */
+LFG_EXPORT int lfg_oracle_motion_ex(const uint8_t *prev, const uint8_t *curr, int W, int H,
+                                    int blockSize, float searchRadius, float *mv_xy,
+                                    int x0, int y0, int x1, int y1, int nthreads, int semantics) {
     if (!prev || !curr || !mv_xy || W <= 0 || H <= 0 || blockSize < 0 || !(searchRadius >= 0.0f)) return -1;
     job_t j; memset(&j, 0, sizeof j);
     j.kind = 1; j.a = prev; j.b = curr; j.mv_out = mv_xy; j.W = W; j.H = H;
-    j.blockSize = blockSize; j.searchRadius = searchRadius;
+    j.blockSize = blockSize; j.searchRadius = searchRadius; j.semantics = semantics;
+    j.x0 = x0; j.y0 = y0; j.x1 = x1; j.y1 = y1;
+    return run(&j, nthreads);
+}
+
+LFG_EXPORT int lfg_oracle_motion(const uint8_t *prev, const uint8_t *curr, int W, int H,
+                                 int blockSize, float searchRadius, float *mv_xy,
+                                 int x0, int y0, int x1, int y1, int nthreads) {
+    return lfg_oracle_motion_ex(prev, curr, W, H, blockSize, searchRadius, mv_xy, x0, y0, x1, y1, nthreads, 0);
+}
+
+/* semantics 0: interpolate.comp as written (pixel-unit motion added to normalised uv, F5).  semantics 1
+ * ("intended"): the motion vector is divided by the image size first, so it displaces by pixels. */
+LFG_EXPORT int lfg_oracle_interpolate_ex(const uint8_t *prev, const uint8_t *curr, const float *mv_xy,
+                                         int W, int H, float factor, uint8_t *out,
+                                         int x0, int y0, int x1, int y1, int nthreads, int semantics) {
+    if (!prev || !curr || !mv_xy || !out || W <= 0 || H <= 0) return -1;
+    job_t j; memset(&j, 0, sizeof j);
+    j.kind = 2; j.a = prev; j.b = curr; j.mv_in = mv_xy; j.out8 = out; j.W = W; j.H = H;
+    j.factor = factor; j.semantics = semantics;
     j.x0 = x0; j.y0 = y0; j.x1 = x1; j.y1 = y1;
     return run(&j, nthreads);
 }
@@ -275,12 +306,7 @@ LFG_EXPORT int lfg_oracle_motion(const uint8_t *prev, const uint8_t *curr, int W
 LFG_EXPORT int lfg_oracle_interpolate(const uint8_t *prev, const uint8_t *curr, const float *mv_xy,
                                       int W, int H, float factor, uint8_t *out,
                                       int x0, int y0, int x1, int y1, int nthreads) {
-    if (!prev || !curr || !mv_xy || !out || W <= 0 || H <= 0) return -1;
-    job_t j; memset(&j, 0, sizeof j);
-    j.kind = 2; j.a = prev; j.b = curr; j.mv_in = mv_xy; j.out8 = out; j.W = W; j.H = H;
-    j.factor = factor;
-    j.x0 = x0; j.y0 = y0; j.x1 = x1; j.y1 = y1;
-    return run(&j, nthreads);
+    return lfg_oracle_interpolate_ex(prev, curr, mv_xy, W, H, factor, out, x0, y0, x1, y1, nthreads, 0);
 }
 
 /* Per-axis raw Lanczos weights for one output coordinate, as scale.comp:24-41 computes

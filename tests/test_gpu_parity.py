@@ -474,3 +474,65 @@ def test_argument_validation_on_device(ctx):
         ctx._check(ctx.lib.lfg_frame_upload(ctx.h, a, np.zeros(8, np.uint8).ctypes.data, 8), "lfg_frame_upload")
     for f in (a, b, m):
         ctx.destroy_frame(f)
+
+
+# ------------------------------------------------------------------ opt-in "intended" semantics
+
+@pytest.fixture()
+def intended(ctx):
+    from linux_fg_amd import capi
+    ctx.set_semantics(capi.SEMANTICS_INTENDED)
+    yield ctx
+    ctx.set_semantics(capi.SEMANTICS_REFERENCE)
+
+
+def test_intended_motion_kats(intended, oracle):
+    """Zero and flat frames report (0,0) instead of (-16,-16); a pure translation still reports -t."""
+    from linux_fg_amd import capi
+    z = np.zeros((40, 72, 4), np.uint8)
+    f = np.empty((70, 130, 4), np.uint8); f[...] = (40, 90, 200, 255)
+    for mode in (capi.MOTION_PREFILTERED, capi.MOTION_EXACT_ONLY):
+        assert (run_motion_mode(intended, z, z, mode)[0] == 0).all()
+        assert (run_motion_mode(intended, f, f, mode)[0] == 0).all()
+    prev = synth.make_prev(160, 90, seed=9)
+    curr = synth.translate(prev, (5, -3), seed=9)
+    got, _ = run_motion_mode(intended, prev, curr, capi.MOTION_PREFILTERED)
+    assert (got[24:-24, 24:-24, 0] == -5).all() and (got[24:-24, 24:-24, 1] == 3).all()
+
+
+@pytest.mark.parametrize("name", ["noise", "periodic", "flat + noise", "static with flat areas"])
+def test_intended_motion_matches_oracle(intended, oracle, name):
+    """Both 8/16 paths against the oracle's intended mode on the tie-heavy adversarial frames; the two modes
+    differ from the reference exactly where costs tie."""
+    from linux_fg_amd import capi
+    prev, curr = _adversarial_pairs()[name]
+    want = as_int(oracle.motion(prev, curr, semantics=oracle.INTENDED))
+    for mode in (capi.MOTION_PREFILTERED, capi.MOTION_EXACT_ONLY):
+        got, _ = run_motion_mode(intended, prev, curr, mode)
+        assert (got == want).all(), f"{(got != want).any(-1).sum()} pixels differ ({name}, mode {mode})"
+    if name in ("flat + noise", "static with flat areas"):
+        assert (want != as_int(oracle.motion(prev, curr))).any()
+
+
+def test_intended_motion_generic_parameters(intended, oracle):
+    prev = synth.make_prev(50, 34, seed=21)
+    prev[10:30, 5:40] = (7, 7, 7, 255)                                   # a flat patch: ties
+    curr = prev.copy()
+    for bs, R in [(4, 3.0), (8, 2.0), (5, 4.0)]:
+        got = run_motion(intended, prev, curr, bs, R)
+        assert (got == as_int(oracle.motion(prev, curr, bs, R, semantics=oracle.INTENDED))).all()
+
+
+@pytest.mark.parametrize("t", [0.25, 0.5, 0.75])
+def test_intended_interpolate_matches_oracle(intended, oracle, t):
+    """Motion vectors now displace by pixels: fractional sample positions, the bilinear path for real."""
+    w, h = 90, 52
+    prev, curr = rand_frame(w, h), rand_frame(w, h)
+    mv = RNG.integers(-16, 17, size=(h, w, 2)).astype(np.int8)
+    got = run_interpolate(intended, prev, curr, mv, t)
+    want = oracle.interpolate(prev, curr, mv.astype(np.float32), t, semantics=oracle.INTENDED)
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    assert d.max() <= 1, f"max diff {d.max()}"
+    assert (d != 0).mean() < 1e-3                                         # in practice identical
+    lit = oracle.interpolate(prev, curr, mv.astype(np.float32), t)
+    assert (want != lit).any()

@@ -178,3 +178,37 @@ def test_i_literal_pixel_units_in_uv(oracle):
     x = 4                                     # prev out of range, curr at texel 20
     want = c[:, x + W // 2].astype(np.float64) * 0.5
     assert (np.abs(out[:, x] - want) <= 0.5 + 1e-3).all()
+
+
+# ---- opt-in "intended" semantics of the oracle: never the parity default
+
+def test_intended_motion_prefers_the_shortest_vector_among_equal_costs():
+    import oracle
+    z = np.zeros((24, 40, 4), np.uint8)
+    assert (oracle.motion(z, z, semantics=oracle.INTENDED) == 0).all()            # reference: (-16,-16) (M-KAT1)
+    f = np.empty((30, 44, 4), np.uint8); f[...] = (9, 99, 199, 255)
+    assert (oracle.motion(f, f, semantics=oracle.INTENDED) == 0).all()            # even at the borders: (0,0) costs 0
+    rng = np.random.default_rng(3)
+    prev = rng.integers(0, 256, size=(40, 56, 4), dtype=np.uint8)
+    curr = np.roll(prev, (2, -3), (0, 1))
+    a = oracle.motion(prev, curr, roi=(20, 18, 36, 24))[18:24, 20:36]
+    b = oracle.motion(prev, curr, roi=(20, 18, 36, 24), semantics=oracle.INTENDED)[18:24, 20:36]
+    assert (a == b).all() and (a[..., 0] == 3).all() and (a[..., 1] == -2).all()  # unique minimum: both agree
+
+
+def test_intended_interpolate_displaces_by_pixels():
+    """MV = (dx, dy) pixels: prev is sampled at p - MV*t, curr at p + MV*(1-t) (the shader's own signs); with
+    MV*t integral the samples are exact texels."""
+    import oracle
+    rng = np.random.default_rng(4)
+    h, w = 20, 32
+    prev = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    curr = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    mv = np.zeros((h, w, 2), np.float32); mv[..., 0] = 4.0; mv[..., 1] = -2.0
+    out = oracle.interpolate(prev, curr, mv, 0.5, semantics=oracle.INTENDED)
+    y, x = 10, 16
+    want = np.round((prev[y + 1, x - 2].astype(np.float64) + curr[y - 1, x + 2]) / 2.0 - 1e-9)   # .5 ties: half-even
+    got = out[y, x].astype(np.float64)
+    assert (np.abs(got - (prev[y + 1, x - 2].astype(np.float64) + curr[y - 1, x + 2]) / 2.0) <= 0.5).all(), (got, want)
+    lit = oracle.interpolate(prev, curr, mv, 0.5)
+    assert (lit[y, x] == 0).all()            # reference semantics: both samples leave [0,1] (I-KAT2's mechanism)
