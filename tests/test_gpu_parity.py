@@ -260,6 +260,24 @@ def test_motion_prefilter_equals_exact_kernel_on_ragged_sizes(ctx, wh):
     assert (a == b).all()
 
 
+def test_motion_4k_modes_agree_on_noise_and_translation(ctx):
+    """BASELINE config 3 size, every tile and every shared-tile work unit: the prefiltered path against the
+    literal kernel on uncorrelated noise (nothing ties, ~7 records per pixel) and on the translated pair."""
+    from linux_fg_amd import capi
+    W, H = 3840, 2160
+    noise_a = synth.noise_bytes(W, H, 111)
+    noise_b = synth.noise_bytes(W, H, 222)
+    a, stats = run_motion_mode(ctx, noise_a, noise_b, capi.MOTION_PREFILTERED)
+    b, _ = run_motion_mode(ctx, noise_a, noise_b, capi.MOTION_EXACT_ONLY)
+    assert (a == b).all(), f"{(a != b).any(-1).sum()} pixels differ"
+    assert stats[1] == 0 and 5.0 < stats[2] < 10.0, stats
+    prev = synth.make_prev(W, H, seed=synth.BASE_SEED)
+    curr = synth.translate(prev, (-7, 11), synth.BASE_SEED)
+    a, _ = run_motion_mode(ctx, prev, curr, capi.MOTION_PREFILTERED)
+    b, _ = run_motion_mode(ctx, prev, curr, capi.MOTION_EXACT_ONLY)
+    assert (a == b).all()
+
+
 def test_exact_sqrt_exhaustive(ctx):
     """csrc/motion.hip: exact_sqrt (one Newton step on v_rsq_f32) against the compiler's IEEE sqrtf for
     every float from 2^-21 to 8 (the motion kernel feeds it sums of four squares in [0, 4], the
