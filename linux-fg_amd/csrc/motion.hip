@@ -297,8 +297,8 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
 //   * transposition through a wave-private LDS slab, eight rows at a time, rows interleaved in pairs (writes:
 //     lane = column, one ds_write_b64 per row pair; reads: lane = (row lane&7, 7-pixel run lane>>3), one
 //     ds_read2_b32 per input pair, all 32 banks distinct);
-//   * row sums, per lane two runs of 7 pixels (rows r and r+8): 13 values -> shared pairwise tree (29 adds) ->
-//     7 S~, threshold test, list append.
+//   * row sums, per lane two runs of 7 pixels (rows r and r+8) packed side by side: 14 input pairs -> shared
+//     pairwise tree (31 packed adds) -> 7 + 7 S~, threshold test, list append.
 //   LDS: 38.2 KB window + 4 x 2.1 KB slabs = 46.9 KB -> three workgroups (12 waves) per CU.  DS operations of
 //   one wave execute in order, so a slab needs neither double buffering nor barriers.  Loop order per
 //   candidate e: window reads(e+1) issued | row sums + test(e) | column sums(e+1) | slab write/read(e+1);
@@ -322,7 +322,7 @@ constexpr int kListK = 32;              // recorded candidates per pixel.  A pse
                                         // P(> 32) ~ 1e-11 per pixel, so only genuinely tied content overflows
 constexpr float kRatio = 1.00008f;      // >= (1 + 3.6e-5) / (1 - 3.6e-5) with room for the product's rounding ("Bracket")
 static_assert(kPNT / 64 * kSeg == kPTH && 8 * kRun == kPTW && kPTH == kTH, "stage maps cover the tile");
-static_assert(kRunIn == 2 * kRun, "row-sum inputs pair up as (x_i, x_{i+7})");
+
 static_assert(kPTW + kB - 1 <= 64 && kWinW >= kPTW + kB - 1 + 2 * kR, "one lane per position column");
 
 typedef const __attribute__((address_space(3))) uint32_t *lds_ro_u32_ptr;
@@ -480,26 +480,27 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
         }
         return (any & 0x80008000u) != 0u;
     };
-    // One run of 14 inputs -> 7 sums, inputs paired (x_i, x_{i+7}) as the slab reads deliver them.
-    auto runSums = [&](const f32x2 (&X)[kRun], float (&sOut)[kRun]) {
-        f32x2 H2[kRun - 1], H4[kRun - 3];
+    // Row sums of both runs of a lane at once: X[i] = (row r8, row r8 + 8) at input column i, so every level of
+    // the sliding tree is one packed add per entry (13 + 11 + 7) and s2[i] = (S~ of pixel i in row r8, in row r8+8).
+    auto runSums = [&](const f32x2 (&X)[kRunIn], f32x2 (&s2)[kRun]) {
+        f32x2 h2[kRunIn - 1], h4[kRunIn - 3];
 #pragma unroll
-        for (int i = 0; i < kRun - 1; ++i) H2[i] = X[i] + X[i + 1];    // (h2_i, h2_{i+7}), i = 0..5
-        const float h2_6 = X[6].x + X[0].y;
+        for (int i = 0; i < kRunIn - 1; ++i) h2[i] = X[i] + X[i + 1];
 #pragma unroll
-        for (int i = 0; i < kRun - 3; ++i) H4[i] = H2[i] + H2[i + 2];  // (h4_i, h4_{i+7}), i = 0..3
-        const float h4_4 = H2[4].x + h2_6, h4_5 = H2[5].x + H2[0].y, h4_6 = h2_6 + H2[1].y;
-        sOut[0] = H4[0].x + h4_4;   sOut[1] = H4[1].x + h4_5;   sOut[2] = H4[2].x + h4_6;
-        sOut[3] = H4[3].x + H4[0].y; sOut[4] = h4_4 + H4[1].y;  sOut[5] = h4_5 + H4[2].y;  sOut[6] = h4_6 + H4[3].y;
+        for (int i = 0; i < kRunIn - 3; ++i) h4[i] = h2[i] + h2[i + 2];
+#pragma unroll
+        for (int i = 0; i < kRun; ++i) s2[i] = h4[i] + h4[i + 4];
     };
     // The test is two-level: all fourteen comparisons first (VALU -> scalar masks, pipelined), then one
     // SCALAR branch per pixel column; only a taken branch (about one in five) touches EXEC.  A divergent
     // `if` per pixel costs ~6 VALU slots each in compare -> saveexec -> branch latency (tools/bench_intops.hip).
-    auto rowSumsAndTest = [&](const f32x2 (&XA)[kRun], const f32x2 (&XB)[kRun], uint32_t cand, uint32_t countIt) {
+    auto rowSumsAndTest = [&](const f32x2 (&X)[kRunIn], uint32_t cand, uint32_t countIt) {
         const uint32_t zeroCap = 0x00800000u + cand;                   // float bits, wave-uniform
+        f32x2 s2[kRun];
+        runSums(X, s2);
         float sv[2][kRun];
-        runSums(XA, sv[0]);
-        runSums(XB, sv[1]);
+#pragma unroll
+        for (int i = 0; i < kRun; ++i) { sv[0][i] = s2[i].x; sv[1][i] = s2[i].y; }
         unsigned long long hit[2][kRun];
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
@@ -536,21 +537,21 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
         }
     };
     // slab traffic of one candidate: rows 0-7 out, their transposed runs in, rows 8-15 out, runs in
-    auto transpose = [&](const float (&v8)[kSeg], f32x2 (&XA)[kRun], f32x2 (&XB)[kRun]) {
+    auto transpose = [&](const float (&v8)[kSeg], f32x2 (&X)[kRunIn]) {
 #pragma unroll
         for (int a = 0; a < 4; ++a) slabW[a * (kSlabP / 2)] = f32x2{v8[2 * a], v8[2 * a + 1]};
 #pragma unroll
-        for (int i = 0; i < kRun; ++i) XA[i] = f32x2{slabR[2 * i], slabR[2 * (i + kRun)]};
+        for (int i = 0; i < kRunIn; ++i) X[i].x = slabR[2 * i];
 #pragma unroll
         for (int a = 0; a < 4; ++a) slabW[a * (kSlabP / 2)] = f32x2{v8[8 + 2 * a], v8[9 + 2 * a]};
 #pragma unroll
-        for (int i = 0; i < kRun; ++i) XB[i] = f32x2{slabR[2 * i], slabR[2 * (i + kRun)]};
+        for (int i = 0; i < kRunIn; ++i) X[i].y = slabR[2 * i];
     };
 
     auto run = [&]() -> bool {
         uint32_t p[kSegD];
         float v8[kSeg];
-        f32x2 xa[kRun], xb[kRun];
+        f32x2 x[kRunIn];
         // A unit that shares its tile starts with zero motion as well (threshold only, not recorded: unit 0 owns
         // it), so static areas close their threshold at once in every unit.
         const int eFirst = chunk > 0 ? eBegin - 1 : eBegin;
@@ -558,15 +559,15 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
         uint32_t ordE = orderAt(eFirst), ordN = orderAt(eFirst + 1);   // candidates e, e+1 (scalar loads, one step ahead)
         fetchWindow(p, ordE);
         columnSums(p, v8);
-        transpose(v8, xa, xb);
+        transpose(v8, x);
         for (int e = eFirst; e < eEnd; ++e) {
             const uint32_t ordNN = orderAt(e + 2);
             if (e + 1 < eEnd) fetchWindow(p, ordN);                    // candidate e+1: reads in flight ...
-            rowSumsAndTest(xa, xb, ordE & 0xFFFFu, e >= eBegin ? 1u : 0u);   // ... while candidate e is finished
+            rowSumsAndTest(x, ordE & 0xFFFFu, e >= eBegin ? 1u : 0u);   // ... while candidate e is finished
             __builtin_amdgcn_sched_barrier(0);
             if (e + 1 < eEnd) {
                 columnSums(p, v8);
-                transpose(v8, xa, xb);
+                transpose(v8, x);
             }
             ordE = ordN; ordN = ordNN;
             if ((e & 15) == 15) {                                      // lists full somewhere in the tile: stop early
