@@ -112,10 +112,11 @@ void trim_axis_tables(lfg_context *ctx) {
 
 int ensure_motion_tables(lfg_context *ctx) {
     if (ctx->motion_tables) return LFG_OK;
-    std::vector<uint32_t> host(4 * lfg::kMotionTableWords, 0u);
+    std::vector<uint32_t> host(7 * lfg::kMotionTableWords, 0u);
     for (int sem = 0; sem < 2; ++sem)
-        lfg::motion_tables(sem != 0, host.data() + (2 * sem) * lfg::kMotionTableWords,
-                           host.data() + (2 * sem + 1) * lfg::kMotionTableWords);
+        lfg::motion_tables(sem != 0, host.data() + (3 * sem) * lfg::kMotionTableWords,
+                           host.data() + (3 * sem + 1) * lfg::kMotionTableWords,
+                           host.data() + (3 * sem + 2) * lfg::kMotionTableWords, host.data() + 6 * lfg::kMotionTableWords);
     LFG_HIP(ctx, hipMalloc((void **)&ctx->motion_tables, host.size() * sizeof(uint32_t)));
     LFG_HIP(ctx, hipMemcpy(ctx->motion_tables, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     return LFG_OK;
@@ -216,6 +217,7 @@ LFG_EXPORT int lfg_context_create(int device_ordinal, lfg_context **out_ctx) {
     if (e != hipSuccess) { delete ctx; return fail_hip(nullptr, e, "hipStreamCreate"); }
     ctx->stream = ctx->own_stream;
     ctx->tables.reserve(17);                 // AxisTable pointers handed out stay valid
+    if (const char *m = getenv("LFG_MOTION_HINTS")) ctx->motion_hints = atoi(m) != 0;
     if (const char *m = getenv("LFG_MOTION_MODE")) ctx->motion_mode = atoi(m) == 1 ? LFG_MOTION_EXACT_ONLY : LFG_MOTION_PREFILTERED;
     *out_ctx = ctx;
     return LFG_OK;
@@ -464,7 +466,7 @@ LFG_EXPORT int lfg_motion(lfg_context *ctx, const lfg_frame *prev, const lfg_fra
     if (tiled) {
         int rc = ensure_motion_tables(ctx);
         if (rc != LFG_OK) return rc;
-        rank2scan = ctx->motion_tables + (2 * ctx->semantics) * lfg::kMotionTableWords;
+        rank2scan = ctx->motion_tables + (3 * ctx->semantics) * lfg::kMotionTableWords;
         order32 = rank2scan + lfg::kMotionTableWords;
     }
     if (tiled && ctx->motion_mode == LFG_MOTION_PREFILTERED) {
@@ -475,7 +477,8 @@ LFG_EXPORT int lfg_motion(lfg_context *ctx, const lfg_frame *prev, const lfg_fra
     hipError_t e;
     if (tiled && ctx->motion_mode == LFG_MOTION_PREFILTERED)
         e = lfg::launch_motion_prefiltered_8_16(ctx->stream, *prev, *curr, *mv, ctx->motion_ws, ctx->motion_ws_layout, ctx->motion_slots,
-                                                rank2scan, order32);
+                                                rank2scan, order32, order32 + lfg::kMotionTableWords,
+                                                ctx->motion_tables + 6 * lfg::kMotionTableWords, ctx->motion_hints);
     else if (tiled) e = lfg::launch_motion_tiled_8_16(ctx->stream, *prev, *curr, *mv, nullptr, rank2scan);
     else e = lfg::launch_motion_generic(ctx->stream, *prev, *curr, *mv, block_size, R, ctx->semantics != 0);
     if (e != hipSuccess) return fail_hip(ctx, e, "motion kernel launch");

@@ -56,7 +56,8 @@ struct lfg_context {
     int motion_slots = 0;                      // prefilter workgroups resident at once on this device (0 = not queried yet)
     int motion_mode = 0;                       // 0: prefilter + exact fallback, 1: exact kernel only
     int semantics = 0;                         // 0: the shaders as written, 1: "intended" (lfg_set_semantics)
-    uint32_t *motion_tables = nullptr;         // device: [semantics][rank2scan | order32], kMotionTableWords each
+    uint32_t *motion_tables = nullptr;         // device: [semantics][rank2scan | order32 | entryOfScan], then baseScan
+    bool motion_hints = true;                  // per-call visiting order from sample-block hints (LFG_MOTION_HINTS=0: off)
     // profiling
     bool profile = false;
     std::vector<lfg::ProfileSlot> prof_pending;
@@ -78,14 +79,15 @@ hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const 
                                     const lfg_frame &mv, const uint32_t *tileFlags, const uint32_t *rank2scan);
 // Candidate tables of the blockSize 8 / searchRadius 16 paths for one tie-break rule (motion.hip: motion_tables).
 constexpr int kMotionTableWords = 1092;     // 33 * 33 candidates + the sentinel, padded to a multiple of 4
-void motion_tables(bool intended, uint32_t *rank2scan, uint32_t *order32);
+void motion_tables(bool intended, uint32_t *rank2scan, uint32_t *order32, uint32_t *entryOfScan, uint32_t *baseScan);
 // Prefiltered motion path (motion.hip): MotionWorkspaceLayout = byte offsets of its scratch arrays.
 size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, MotionWorkspaceLayout *layout);
 PrefilterSplit prefilter_split(uint32_t width, uint32_t height, int slots);
 int prefilter_slots();      // workgroups of the prefilter kernel the current device holds at once
 hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                           const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &layout, int slots,
-                                          const uint32_t *rank2scan, const uint32_t *order32);
+                                          const uint32_t *rank2scan, const uint32_t *order32,
+                                          const uint32_t *entryOfScan, const uint32_t *baseScan, bool useHints);
 hipError_t launch_motion_generic(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                  const lfg_frame &mv, int block_size, int radius, bool intended);
 hipError_t launch_interpolate(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,

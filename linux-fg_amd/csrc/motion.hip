@@ -317,6 +317,7 @@ constexpr int kSlabP = 136;                       // slab pitch of a ROW PAIR (f
                                                   // transposed reads on 32 distinct banks
 constexpr int kRun = 7;                           // pixels per row-sum run: 8 runs x 7 = 56
 constexpr int kRunIn = kRun + kB - 1;             // 13
+constexpr int kHintGrid = 16, kHints = kHintGrid * kHintGrid;      // sample blocks of the per-call visiting order
 constexpr int kListK = 32;              // recorded candidates per pixel.  A pseudo-random visiting order makes the
                                         // number of running minima ~Poisson(ln 1089 = 7.6) whatever the content:
                                         // P(> 32) ~ 1e-11 per pixel, so only genuinely tied content overflows
@@ -744,11 +745,11 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, Motion
     l.umin = align(l.list + px * kListK * sizeof(uint2));
     l.count = align(l.umin + px * sizeof(float));
     l.tileFlags = align(l.count + px * sizeof(uint32_t));
-    l.order = align(l.tileFlags + tiles * sizeof(uint32_t));          // (unused: the tables live on the context)
+    l.order = align(l.tileFlags + tiles * sizeof(uint32_t));          // this call's hints and visiting order
     // auxiliary arrays of the shared tiles (see prefilter_split): one 56 x 64 block per unit
     const PrefilterSplit sp = prefilter_split(width, height, slots);
     const size_t auxUnits = (size_t)(sp.units - sp.fullTiles);
-    l.auxList = l.order;
+    l.auxList = align(l.order + (kHints + kCand + 3) * sizeof(uint32_t));
     l.auxUmin = align(l.auxList + auxUnits * kPTH * kPTW * kListK * sizeof(uint2));
     l.auxCount = align(l.auxUmin + auxUnits * kPTH * kPTW * sizeof(float));
     l.total = align(l.auxCount + auxUnits * kPTH * kPTW * sizeof(uint32_t));
@@ -787,7 +788,7 @@ int prefilter_slots() {
 //                                costs resolve to the shortest vector.  Entry kCand is the sentinel kCand.
 //   order32[e], e = 0..kCand-1   the prefilter's visiting order: rank in the low half, offset of the candidate in
 //                                the LDS window, (dx+R)*kWinH + (dy+R), in the high half.
-void motion_tables(bool intended, uint32_t *rank2scan, uint32_t *order32) {
+void motion_tables(bool intended, uint32_t *rank2scan, uint32_t *order32, uint32_t *entryOfScan, uint32_t *baseScan) {
     uint16_t byRank[kCand], rankOf[kCand];
     for (int i = 0; i < kCand; ++i) byRank[i] = (uint16_t)i;
     if (intended) {
@@ -813,15 +814,105 @@ void motion_tables(bool intended, uint32_t *rank2scan, uint32_t *order32) {
     for (int i = 0; i < kCand; ++i) {
         if (order[i] == kR * kSide + kR) { order[i] = order[0]; order[0] = (uint16_t)(kR * kSide + kR); break; }
     }
+    for (int scan = 0; scan < kCand; ++scan) {
+        const uint32_t dyi = scan / kSide, dxi = scan % kSide;
+        entryOfScan[scan] = rankOf[scan] | ((dxi * kWinH + dyi) << 16);
+    }
     for (int i = 0; i < kCand; ++i) {
-        const uint32_t dyi = order[i] / kSide, dxi = order[i] % kSide;
-        order32[i] = rankOf[order[i]] | ((dxi * kWinH + dyi) << 16);
+        baseScan[i] = order[i];
+        order32[i] = entryOfScan[order[i]];
+    }
+}
+
+// ------------------------------------------------------------------------------ per-call visiting order
+//
+// The fewer running minima a pixel sees, the less the prefilter records.  Two tiny kernels put the candidates
+// that are likely to be the answer at the front of the visiting order of THIS call: motion_hint_kernel block-matches
+// 256 sample blocks (a 16 x 16 grid over the frame) with a plain SAD over all 1089 candidates and reports each
+// block's best; motion_order_kernel emits zero motion, then the distinct hints, then the rest of the fixed
+// pseudo-random order.  With a few dominant motions in the frame (a pan, a handful of objects) most pixels meet
+// their minimum within the first few candidates and close their thresholds at once.  The order only changes what
+// is recorded along the way: every candidate is still evaluated for every pixel and the results are identical.
+
+constexpr int kHintWin = kB + 2 * kR;                // 40 x 40 texels of prev around a sample block
+
+__global__ __launch_bounds__(256) void motion_hint_kernel(
+    const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
+    int W, int H, uint32_t *__restrict__ hints) {
+    __shared__ uint32_t sP[kHintWin * kHintWin];
+    __shared__ uint32_t sC[kB * kB], sValid[kB * kB];
+    __shared__ uint32_t sBest;
+    const int tid = threadIdx.x;
+    const int gx = blockIdx.x % kHintGrid, gy = blockIdx.x / kHintGrid;
+    const int bx = (2 * gx + 1) * W / (2 * kHintGrid) - kB / 2, by = (2 * gy + 1) * H / (2 * kHintGrid) - kB / 2;
+    if (tid == 0) sBest = 0xFFFFFFFFu;
+    for (int i = tid; i < kHintWin * kHintWin; i += 256) {
+        const int x = bx - kR + i % kHintWin, y = by - kR + i / kHintWin;
+        sP[i] = (x >= 0 && x < W && y >= 0 && y < H)
+                    ? *reinterpret_cast<const uint32_t *>(prev + (size_t)y * (size_t)prevPitch + (size_t)x * 4u) : 0u;
+    }
+    if (tid < kB * kB) {
+        const int x = bx + tid % kB, y = by + tid / kB;
+        const bool ok = x >= 0 && x < W && y >= 0 && y < H;
+        sC[tid] = ok ? *reinterpret_cast<const uint32_t *>(curr + (size_t)y * (size_t)currPitch + (size_t)x * 4u) : 0u;
+        sValid[tid] = ok ? 1u : 0u;
+    }
+    __syncthreads();
+    uint32_t best = 0xFFFFFFFFu;
+    for (int cand = tid; cand < kCand; cand += 256) {
+        const int dyi = cand / kSide, dxi = cand - dyi * kSide;
+        uint32_t sad = 0u;
+        for (int p = 0; p < kB * kB; ++p) {
+            const uint32_t q = sP[(p / kB + dyi) * kHintWin + p % kB + dxi];
+            sad += sValid[p] ? __builtin_amdgcn_sad_u8(sC[p], q, 0u) : 0u;
+        }
+        best = min(best, (sad << 11) | (uint32_t)cand);                // <= 64 * 1020 < 2^16, cand < 2^11
+    }
+    atomicMin(&sBest, best);
+    __syncthreads();
+    if (tid == 0) hints[blockIdx.x] = sBest & 0x7FFu;
+}
+
+__global__ __launch_bounds__(256) void motion_order_kernel(
+    const uint32_t *__restrict__ hints, const uint32_t *__restrict__ baseScan,
+    const uint32_t *__restrict__ entryOfScan, uint32_t *__restrict__ order32) {
+    __shared__ uint32_t sOwner[kCand];               // lowest hint index that proposes this candidate
+    __shared__ uint32_t sWaveSum[4];
+    __shared__ uint32_t sRunning;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t zero = baseScan[0];               // zero motion: always first
+    for (int i = tid; i < kCand; i += 256) sOwner[i] = 0xFFFFFFFFu;
+    if (tid == 0) sRunning = 1u;
+    __syncthreads();
+    const uint32_t mine = hints[tid];
+    if (mine != zero) atomicMin(&sOwner[mine], (uint32_t)tid);
+    if (tid == 0) order32[0] = entryOfScan[zero];
+    __syncthreads();
+    // block-wide exclusive scan of one flag per thread, appended at sRunning
+    auto append = [&](bool keep, uint32_t scan) {
+        const unsigned long long m = __ballot(keep);
+        const uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) sWaveSum[wv] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t base = sRunning;
+        for (int w = 0; w < wv; ++w) base += sWaveSum[w];
+        if (keep) order32[base + before] = entryOfScan[scan];
+        __syncthreads();
+        if (tid == 0) sRunning += sWaveSum[0] + sWaveSum[1] + sWaveSum[2] + sWaveSum[3];
+        __syncthreads();
+    };
+    append(mine != zero && sOwner[mine] == (uint32_t)tid, mine);       // distinct hints, in sample-block order
+    for (int e0 = 1; e0 < kCand; e0 += 256) {                          // then everything no hint proposed
+        const int e = e0 + tid;
+        const uint32_t scan = e < kCand ? baseScan[e] : 0u;
+        append(e < kCand && sOwner[scan] == 0xFFFFFFFFu, scan);
     }
 }
 
 hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                           const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &l, int slots,
-                                          const uint32_t *rank2scan, const uint32_t *order) {
+                                          const uint32_t *rank2scan, const uint32_t *order,
+                                          const uint32_t *entryOfScan, const uint32_t *baseScan, bool useHints) {
     const int tilesX = ((int)curr.width + kTW - 1) / kTW, tilesY = ((int)curr.height + kTH - 1) / kTH;
     uint2 *list = reinterpret_cast<uint2 *>(workspace + l.list);
     float *umin = reinterpret_cast<float *>(workspace + l.umin);
@@ -834,6 +925,17 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
     sp.auxCount = reinterpret_cast<uint32_t *>(workspace + l.auxCount);
     hipError_t e = hipMemsetAsync(flags, 0, (size_t)tilesX * tilesY * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
+    if (useHints && curr.width >= 64u && curr.height >= 64u) {         // this call's visiting order
+        uint32_t *hints = reinterpret_cast<uint32_t *>(workspace + l.order);
+        uint32_t *callOrder = hints + kHints;
+        hipLaunchKernelGGL(motion_hint_kernel, dim3(kHints), dim3(256), 0, s,
+                           (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
+                           (int)curr.width, (int)curr.height, hints);
+        hipLaunchKernelGGL(motion_order_kernel, dim3(1), dim3(256), 0, s, hints, baseScan, entryOfScan, callOrder);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        order = callOrder;
+    }
     hipLaunchKernelGGL(motion_prefilter_kernel, dim3(sp.units), dim3(kPNT), 0, s,
                        (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
                        (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, order, sp);
