@@ -645,85 +645,116 @@ __global__ __launch_bounds__(256) void motion_resolve_kernel(
     int tilesX, PrefilterSplit sp, const uint32_t *__restrict__ rank2scan) {
     // Candidates are identified by their RANK in the tie order everywhere in the prefiltered path (lists, the
     // zero-cost encoding), so "smallest rank among equal costs" is the tie-break; rank2scan turns it into (dx, dy).
-    const int px = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (px >= W || py >= H) return;
-    if (tileFlags[(py / kTH) * tilesX + px / kTW] != 0u) return;       // this tile goes through the exact kernel
+    __shared__ float sDist[4][kB * kB];    // one block of distances per wave (cooperative exact evaluation)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int px = blockIdx.x * 64 + lane;
+    const int py = blockIdx.y * 4 + wv;
+    // No early exits: every lane stays for the cooperative part below.  `live` = this lane owns a pixel to resolve
+    // (inside the image and not in a tile that goes through the exact kernel).
+    const bool inside = px < W && py < H;
+    const bool live = inside && tileFlags[(py / kTH) * tilesX + px / kTW] == 0u;
     // Where this pixel's records live: one list in the image-shaped arrays, or sp.split lists (one per unit that
     // shared the tile's candidates) in the auxiliary arrays.  Record k of list c: recs[c * listStride + k * recStride].
-    const int ptile = (py / kPTH) * sp.tilesX + px / kPTW;
+    const int cpx = min(px, W - 1), cpy = min(py, H - 1);
+    const int ptile = (cpy / kPTH) * sp.tilesX + cpx / kPTW;
     const bool whole = ptile < sp.fullTiles;
     const int nLists = whole ? 1 : sp.split;
     const uint2 *recs;
     const float *thrs;
     const uint32_t *cnts;
-    size_t listStride, recStride, thrStride;
+    uint32_t listStride, recStride, thrStride;
     if (whole) {
-        recs = list + (size_t)py * (size_t)kListK * (size_t)W + (size_t)px;
-        thrs = uminIn + (size_t)py * (size_t)W + (size_t)px;
-        cnts = countIn + (size_t)py * (size_t)W + (size_t)px;
-        listStride = 0; recStride = (size_t)W; thrStride = 0;
+        recs = list + (size_t)cpy * (size_t)kListK * (size_t)W + (size_t)cpx;
+        thrs = uminIn + (size_t)cpy * (size_t)W + (size_t)cpx;
+        cnts = countIn + (size_t)cpy * (size_t)W + (size_t)cpx;
+        listStride = 0u; recStride = (uint32_t)W; thrStride = 0u;
     } else {
         const size_t unit0 = (size_t)(ptile - sp.fullTiles) * (size_t)sp.split;
-        const int ly = py % kPTH, lx = px % kPTW;
+        const int ly = cpy % kPTH, lx = cpx % kPTW;
         recs = sp.auxList + (unit0 * kPTH + (size_t)ly) * (size_t)kListK * kPTW + (size_t)lx;
         thrs = sp.auxUmin + (unit0 * kPTH + (size_t)ly) * kPTW + (size_t)lx;
         cnts = sp.auxCount + (unit0 * kPTH + (size_t)ly) * kPTW + (size_t)lx;
-        listStride = (size_t)kPTH * kListK * kPTW; recStride = kPTW; thrStride = (size_t)kPTH * kPTW;
+        listStride = (uint32_t)(kPTH * kListK * kPTW); recStride = kPTW; thrStride = (uint32_t)(kPTH * kPTW);
     }
     float bound = __builtin_inff();        // thresholds are monotone: the tightest one holds for every list
-    for (int c = 0; c < nLists; ++c) bound = __builtin_fminf(bound, thrs[(size_t)c * thrStride]);
-    int8_t *dst = mv + (size_t)py * (size_t)mvPitch + (size_t)px * 2u;
-    if (bound < 0.5f) {                    // a zero-cost candidate exists; the first one in scan order is encoded here
-        const uint32_t zc = rank2scan[__builtin_bit_cast(uint32_t, bound) - 0x00800000u];
-        const int zdy = (int)zc / kSide, zdx = (int)zc - zdy * kSide;
-        dst[0] = (int8_t)(zdx - kR);
-        dst[1] = (int8_t)(zdy - kR);
-        return;
-    }
-    // A single survivor IS the shader's answer (the exact minimiser always survives), no evaluation needed.
-    uint32_t survivors = 0u, bestC = 0xFFFFFFFFu;
-    for (int c = 0; c < nLists; ++c) {
-        const uint32_t n = min(cnts[(size_t)c * thrStride], (uint32_t)kListK);
-        for (uint32_t k = 0; k < n; ++k) {
-            const uint2 rec = recs[(size_t)c * listStride + (size_t)k * recStride];
-            if (__builtin_bit_cast(float, rec.x) <= bound) {
-                if (survivors == 0u) bestC = rec.y;
-                ++survivors;
-            }
-        }
-    }
-    if (survivors > 1u) {
-        // Several candidates within the bracket of the minimum: the literal chain decides.  Lanes find their
-        // next surviving entry independently and only then meet in the expensive exact evaluation, so a wave
-        // runs it max-over-lanes(survivors) times, not once per list position that holds a survivor for some lane.
-        float bestV = __builtin_inff();
-        bestC = 0xFFFFFFFFu;
-        int c = 0;
-        uint32_t k = 0, n = min(cnts[0], (uint32_t)kListK);
-        for (;;) {
-            uint32_t cand = 0xFFFFFFFFu;
-            for (;;) {
-                if (k >= n) {
-                    if (++c >= nLists) break;
-                    k = 0; n = min(cnts[(size_t)c * thrStride], (uint32_t)kListK);
-                    continue;
+    uint32_t survivors = 0u, bestC = 0u;
+    if (live) {
+        for (int c = 0; c < nLists; ++c) bound = __builtin_fminf(bound, thrs[(size_t)c * thrStride]);
+        if (bound < 0.5f) {                // a zero-cost candidate exists; the first one in tie order is encoded here
+            bestC = __builtin_bit_cast(uint32_t, bound) - 0x00800000u;
+        } else {
+            // A single survivor IS the shader's answer (the exact minimiser always survives): no evaluation.
+            for (int c = 0; c < nLists; ++c) {
+                const uint32_t n = min(cnts[(size_t)c * thrStride], (uint32_t)kListK);
+                for (uint32_t k = 0; k < n; ++k) {
+                    const uint2 rec = recs[(size_t)c * listStride + (size_t)k * recStride];
+                    if (__builtin_bit_cast(float, rec.x) <= bound) {
+                        if (survivors == 0u) bestC = rec.y;
+                        ++survivors;
+                    }
                 }
-                const uint2 rec = recs[(size_t)c * listStride + (size_t)k * recStride];
-                ++k;
-                if (__builtin_bit_cast(float, rec.x) <= bound) { cand = rec.y; break; }
             }
-            if (cand == 0xFFFFFFFFu) break;
-            const int cscan = (int)rank2scan[cand];
-            const int dyi = cscan / kSide, dxi = cscan - dyi * kSide;
-            const float v = exact_cost(prev, prevPitch, curr, currPitch, W, H, px, py, dxi - kR, dyi - kR);
-            if (v < bestV || (v == bestV && cand < bestC)) { bestV = v; bestC = cand; }
         }
     }
-    const int bscan = (int)rank2scan[bestC];
-    const int dyi = bscan / kSide, dxi = bscan - dyi * kSide;
-    dst[0] = (int8_t)(dxi - kR);
-    dst[1] = (int8_t)(dyi - kR);
+    // Several candidates within the bracket of the minimum (a few percent of the pixels on smooth content): the
+    // literal chain of motion.comp:33-47 decides.  The wave takes such pixels one at a time and evaluates each
+    // surviving candidate TOGETHER: lane j computes the distance of block position j (row-major, as the shader
+    // walks it), the 64 distances go through LDS and every lane adds them in the shader's order -- 64 loads and
+    // distances per lane and candidate would otherwise run with one or two lanes active.
+    unsigned long long todo = __ballot(survivors > 1u);
+    while (todo != 0ull) {
+        const int L = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const int qx = __shfl(px, L), qy = __shfl(py, L);
+        const float qBound = __shfl(bound, L);
+        const int qLists = __shfl(nLists, L);
+        const uint32_t qListStride = __shfl(listStride, L), qRecStride = __shfl(recStride, L), qThrStride = __shfl(thrStride, L);
+        const uint2 *qRecs = reinterpret_cast<const uint2 *>(
+            ((unsigned long long)__shfl((uint32_t)((unsigned long long)recs >> 32), L) << 32) |
+            (unsigned long long)__shfl((uint32_t)(unsigned long long)recs, L));
+        const uint32_t *qCnts = reinterpret_cast<const uint32_t *>(
+            ((unsigned long long)__shfl((uint32_t)((unsigned long long)cnts >> 32), L) << 32) |
+            (unsigned long long)__shfl((uint32_t)(unsigned long long)cnts, L));
+        // this lane's block position and its curr texel
+        const int cx = qx - kB / 2 + (lane & 7), cy = qy - kB / 2 + (lane >> 3);
+        const bool posIn = cx >= 0 && cx < W && cy >= 0 && cy < H;
+        const uint32_t ctex = posIn ? *reinterpret_cast<const uint32_t *>(curr + (size_t)cy * (size_t)currPitch + (size_t)cx * 4u) : 0u;
+        const float cc[4] = {unorm8_to_float(byte0(ctex)), unorm8_to_float(byte1(ctex)),
+                             unorm8_to_float(byte2(ctex)), unorm8_to_float(byte3(ctex))};
+        float bestV = __builtin_inff();
+        uint32_t bestR = 0xFFFFFFFFu;
+        for (int c = 0; c < qLists; ++c) {
+            const uint32_t n = min(qCnts[(size_t)c * qThrStride], (uint32_t)kListK);
+            for (uint32_t k = 0; k < n; ++k) {
+                const uint2 rec = qRecs[(size_t)c * qListStride + (size_t)k * qRecStride];    // same address in every lane
+                if (!(__builtin_bit_cast(float, rec.x) <= qBound)) continue;
+                const int cscan = (int)rank2scan[rec.y];
+                const int dy = cscan / kSide - kR, dx = cscan % kSide - kR;
+                const int sx = cx + dx, sy = cy + dy;
+                uint32_t ptex = 0u;
+                if (posIn && sx >= 0 && sy >= 0 && sx < W && sy < H)
+                    ptex = *reinterpret_cast<const uint32_t *>(prev + (size_t)sy * (size_t)prevPitch + (size_t)sx * 4u);
+                const f32x4 pp = {unorm8_to_float(byte0(ptex)), unorm8_to_float(byte1(ptex)),
+                                  unorm8_to_float(byte2(ptex)), unorm8_to_float(byte3(ptex))};
+                // positions outside the image are skipped by the shader; adding +0.0f leaves its sum unchanged
+                sDist[wv][lane] = posIn ? dist4<true>(cc, pp) : 0.0f;
+                wave_lds_sync();
+                float v = 0.0f;
+#pragma unroll
+                for (int i = 0; i < kB * kB; ++i) v += sDist[wv][i];
+                wave_lds_sync();
+                if (v < bestV || (v == bestV && rec.y < bestR)) { bestV = v; bestR = rec.y; }
+            }
+        }
+        if (lane == L) bestC = bestR;
+    }
+    if (live) {
+        const int bscan = (int)rank2scan[bestC];
+        const int dyi = bscan / kSide, dxi = bscan - dyi * kSide;
+        int8_t *dst = mv + (size_t)py * (size_t)mvPitch + (size_t)px * 2u;
+        dst[0] = (int8_t)(dxi - kR);
+        dst[1] = (int8_t)(dyi - kR);
+    }
 }
 
 hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
