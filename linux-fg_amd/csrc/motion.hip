@@ -889,14 +889,18 @@ __global__ __launch_bounds__(256) void motion_hint_kernel(
         sValid[tid] = ok ? 1u : 0u;
     }
     __syncthreads();
+    // the 64 curr texels and their in-image masks stay in registers; per candidate 64 LDS reads and 64 v_sad_u8
+    uint32_t c[kB * kB], m[kB * kB];
+#pragma unroll
+    for (int p = 0; p < kB * kB; ++p) { c[p] = sC[p]; m[p] = sValid[p] ? 0xFFFFFFFFu : 0u; }
     uint32_t best = 0xFFFFFFFFu;
     for (int cand = tid; cand < kCand; cand += 256) {
         const int dyi = cand / kSide, dxi = cand - dyi * kSide;
+        const uint32_t *w = sP + dyi * kHintWin + dxi;
         uint32_t sad = 0u;
-        for (int p = 0; p < kB * kB; ++p) {
-            const uint32_t q = sP[(p / kB + dyi) * kHintWin + p % kB + dxi];
-            sad += sValid[p] ? __builtin_amdgcn_sad_u8(sC[p], q, 0u) : 0u;
-        }
+#pragma unroll
+        for (int p = 0; p < kB * kB; ++p)       // a position outside the image has c = 0 and a masked-out prev texel
+            sad = __builtin_amdgcn_sad_u8(c[p], w[(p / kB) * kHintWin + p % kB] & m[p], sad);
         best = min(best, (sad << 11) | (uint32_t)cand);                // <= 64 * 1020 < 2^16, cand < 2^11
     }
     atomicMin(&sBest, best);
