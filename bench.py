@@ -288,7 +288,7 @@ def main():
             tf = fl / (stage_ms["motion"] * 1e-3) / 1e12
             exact_only = os.environ.get("LFG_MOTION_MODE", "0") == "1"
             roofline = {"kernel": ("motion_tiled_8_16_kernel" if exact_only else
-                                   "motion_prefilter_kernel (+ motion_resolve_kernel + motion_tiled_8_16_kernel on flagged tiles)"),
+                                   "motion_prefilter_kernel (+ motion_hint/order_kernel, motion_resolve_kernel, motion_tiled_8_16_kernel on flagged tiles)"),
                         "bound": "valu", "achieved": round(tf, 2),
                         "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_VALU_PEAK_TFLOPS, 4),
                         "traffic": None,
@@ -312,7 +312,7 @@ def main():
                         "frac": s["hbm_frac"], "traffic": None}
         size_name = {"540p": "540p->1080p", "1080p": "1080p->4K", "4k": "4K->8K", "8k": "8K->16K"}[args.input]
         if args.input == "1080p" and not in_res:
-            t, src = pmc_traffic(["lfg::motion_tiled", "lfg::motion_prefilter", "lfg::motion_resolve"] if dominant == "motion"
+            t, src = pmc_traffic(["lfg::motion_tiled", "lfg::motion_prefilter", "lfg::motion_resolve", "lfg::motion_hint", "lfg::motion_order"] if dominant == "motion"
                                  else {"scale_2x_kernel": "lfg::scale_2x", "interpolate_kernel": "lfg::interpolate"}[roofline["kernel"]])
             if t is not None:
                 roofline["traffic"] = t
