@@ -448,7 +448,8 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     const int px0 = tx0 + kRun * q;
     f32x2 *const slabW = reinterpret_cast<f32x2 *>(sSlab[seg]) + lane;               // write: rows (2a, 2a+1), column lane
     const lds_ro_f32_ptr slabR = (lds_ro_f32_ptr)(sSlab[seg] + (r8 >> 1) * kSlabP + 2 * kRun * q + (r8 & 1));
-    float thr[2][kRun];                   // kRatio * (smallest S~ so far); a candidate survives while S~ <= thr
+    f32x2 thr2[kRun];                     // (row r8, row r8 + 8): kRatio * (smallest S~ so far); a candidate survives
+                                          // while S~ <= thr
     uint32_t cnt2[2][(kRun + 1) / 2];                                  // 16-bit counters (1089 events at most)
     // Records {S~ bits, candidate}: record k of pixel (x, y) lives at list[(y * kListK + k) * W + x] -- K planes
     // per image row, so the resolve kernel reads record k of 64 neighbouring pixels as one 512-byte line.
@@ -469,7 +470,10 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
         for (int i = 0; i < (kRun + 1) / 2; ++i) cnt2[hb][i] = 0u;
 #pragma unroll
         for (int i = 0; i < kRun; ++i)    // pixels outside the image never pass the test (S~ >= 0 > -inf)
-            thr[hb][i] = (py < H && px0 + i < W) ? __builtin_inff() : -__builtin_inff();
+        {
+            const float t0 = (py < H && px0 + i < W) ? __builtin_inff() : -__builtin_inff();
+            if (hb) thr2[i].y = t0; else thr2[i].x = t0;
+        }
     }
     // some pixel of this lane has more than kListK records: bit 15 of a 16-bit counter biased by 0x7FFF - kListK
     auto listsOverflowed = [&]() -> bool {
@@ -492,16 +496,28 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
 #pragma unroll
         for (int i = 0; i < kRun; ++i) s2[i] = h4[i] + h4[i + 4];
     };
-    // The test is two-level: all fourteen comparisons first (VALU -> scalar masks, pipelined), then one
-    // SCALAR branch per pixel column; only a taken branch (about one in five) touches EXEC.  A divergent
+    // The test has levels: a packed "does anything pass" check (level 0, below), then all fourteen comparisons
+    // (VALU -> scalar masks, pipelined) and one SCALAR branch per pixel; only a taken branch touches EXEC.  A divergent
     // `if` per pixel costs ~6 VALU slots each in compare -> saveexec -> branch latency (tools/bench_intops.hip).
     auto rowSumsAndTest = [&](const f32x2 (&X)[kRunIn], uint32_t cand, uint32_t countIt) {
         const uint32_t zeroCap = 0x00800000u + cand;                   // float bits, wave-uniform
         f32x2 s2[kRun];
         runSums(X, s2);
-        float sv[2][kRun];
+        // Level 0: does ANY of the lane's 14 pixels pass (thr - S~ >= 0 for some of them)?  Seven packed
+        // subtractions and a max tree instead of fourteen compares and scalar branches; with the hints in front,
+        // most candidates end here.  (inf - S~ = inf passes, -inf never does; a difference flushed to zero can
+        // only send us into the exact per-pixel test below for nothing.)
+        f32x2 dm = thr2[0] - s2[0];
+        float top = __builtin_fmaxf(dm.x, dm.y);
 #pragma unroll
-        for (int i = 0; i < kRun; ++i) { sv[0][i] = s2[i].x; sv[1][i] = s2[i].y; }
+        for (int i = 1; i < kRun; ++i) {
+            dm = thr2[i] - s2[i];
+            top = __builtin_fmaxf(top, __builtin_fmaxf(dm.x, dm.y));                     // v_max3_f32
+        }
+        if (__builtin_amdgcn_readfirstlane(__ballot(top >= 0.0f) == 0ull)) return;
+        float sv[2][kRun], thr[2][kRun];
+#pragma unroll
+        for (int i = 0; i < kRun; ++i) { sv[0][i] = s2[i].x; sv[1][i] = s2[i].y; thr[0][i] = thr2[i].x; thr[1][i] = thr2[i].y; }
         unsigned long long hit[2][kRun];
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
@@ -525,7 +541,7 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
                         float cap, t;
                         asm("v_max_f32 %0, %2, %1" : "=v"(cap) : "v"(s * kRatio), "s"(zeroCap));   // no NaNs here
                         asm("v_min_f32 %0, %1, %2" : "=v"(t) : "v"(thr[hb][i]), "v"(cap));
-                        thr[hb][i] = t;
+                        if (hb) thr2[i].y = t; else thr2[i].x = t;
                         const uint32_t n = (cnt2[hb][i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
                         // past the end of the list the last slot is overwritten; the count keeps growing and
                         // flags the tile
@@ -600,11 +616,11 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
                 const uint32_t cnt = (cnt2[hb][i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
                 if (whole) {
                     const size_t gp = (size_t)py * (size_t)W + (size_t)(px0 + i);
-                    uminOut[gp] = thr[hb][i];
+                    uminOut[gp] = hb ? thr2[i].y : thr2[i].x;
                     countOut[gp] = cnt;
                 } else {
                     const size_t ap = ((size_t)auxUnit * kPTH + (size_t)(py - ty0)) * kPTW + (size_t)(px0 + i - tx0);
-                    sp.auxUmin[ap] = thr[hb][i];
+                    sp.auxUmin[ap] = hb ? thr2[i].y : thr2[i].x;
                     sp.auxCount[ap] = cnt;
                 }
             }
