@@ -322,6 +322,7 @@ constexpr int kListK = 32;              // recorded candidates per pixel.  A pse
                                         // number of running minima ~Poisson(ln 1089 = 7.6) whatever the content:
                                         // P(> 32) ~ 1e-11 per pixel, so only genuinely tied content overflows
 constexpr float kRatio = 1.00008f;      // >= (1 + 3.6e-5) / (1 - 3.6e-5) with room for the product's rounding ("Bracket")
+static_assert((kHints & (kHints - 1)) == 0 && kHints == 256, "one hint per thread of the order kernel, scrambled by an odd multiplier");
 static_assert(kPNT / 64 * kSeg == kPTH && 8 * kRun == kPTW && kPTH == kTH, "stage maps cover the tile");
 
 static_assert(kPTW + kB - 1 <= 64 && kWinW >= kPTW + kB - 1 + 2 * kR, "one lane per position column");
@@ -935,7 +936,10 @@ __global__ __launch_bounds__(256) void motion_order_kernel(
     for (int i = tid; i < kCand; i += 256) sOwner[i] = 0xFFFFFFFFu;
     if (tid == 0) sRunning = 1u;
     __syncthreads();
-    const uint32_t mine = hints[tid];
+    // Hints are taken in a scrambled order of the sample blocks: under a zoom or a rotation the hints vary smoothly
+    // across the frame, and in raster order a pixel would see them approach its own motion -- one running minimum
+    // after the other -- which is exactly what fills the lists.
+    const uint32_t mine = hints[(tid * 97 + 13) & (kHints - 1)];
     if (mine != zero) atomicMin(&sOwner[mine], (uint32_t)tid);
     if (tid == 0) order32[0] = entryOfScan[zero];
     __syncthreads();
@@ -952,7 +956,7 @@ __global__ __launch_bounds__(256) void motion_order_kernel(
         if (tid == 0) sRunning += sWaveSum[0] + sWaveSum[1] + sWaveSum[2] + sWaveSum[3];
         __syncthreads();
     };
-    append(mine != zero && sOwner[mine] == (uint32_t)tid, mine);       // distinct hints, in sample-block order
+    append(mine != zero && sOwner[mine] == (uint32_t)tid, mine);       // distinct hints
     for (int e0 = 1; e0 < kCand; e0 += 256) {                          // then everything no hint proposed
         const int e = e0 + tid;
         const uint32_t scan = e < kCand ? baseScan[e] : 0u;
