@@ -278,6 +278,29 @@ def test_motion_4k_modes_agree_on_noise_and_translation(ctx):
     assert (a == b).all()
 
 
+def test_motion_zoom_and_rotation_fields(ctx):
+    """Smoothly varying motion (a 4 % zoom, a 1.5 degree rotation of a noise texture): the per-call hints differ from
+    block to block, the lists must not overflow, and both modes must agree."""
+    from linux_fg_amd import capi
+    w, h = 640, 384
+    rng = np.random.default_rng(123)
+    tex = rng.integers(0, 256, size=(h + 64, w + 64, 4), dtype=np.uint8)
+    prev = tex[32:32 + h, 32:32 + w].copy()
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    cx, cy = w / 2.0, h / 2.0
+    fields = {"zoom": ((xx - cx) / 1.04 + cx, (yy - cy) / 1.04 + cy)}
+    a = np.deg2rad(1.5)
+    fields["rotation"] = ((xx - cx) * np.cos(a) - (yy - cy) * np.sin(a) + cx, (xx - cx) * np.sin(a) + (yy - cy) * np.cos(a) + cy)
+    for name, (sx, sy) in fields.items():
+        ix = np.clip(np.rint(sx).astype(np.int64) + 32, 0, w + 63)
+        iy = np.clip(np.rint(sy).astype(np.int64) + 32, 0, h + 63)
+        curr = tex[iy, ix]
+        got, stats = run_motion_mode(ctx, prev, curr, capi.MOTION_PREFILTERED)
+        want, _ = run_motion_mode(ctx, prev, curr, capi.MOTION_EXACT_ONLY)
+        assert (got == want).all(), name
+        assert stats[1] == 0, (name, stats)
+
+
 def test_exact_sqrt_exhaustive(ctx):
     """csrc/motion.hip: exact_sqrt (one Newton step on v_rsq_f32) against the compiler's IEEE sqrtf for
     every float from 2^-21 to 8 (the motion kernel feeds it sums of four squares in [0, 4], the
