@@ -53,7 +53,10 @@ def parse_args():
     ap.add_argument("--workload", choices=["pipeline", "scale", "pipeline_input_res"], default="pipeline")
     ap.add_argument("--input", choices=list(SIZES), default="1080p", help="input size; output is 2x")
     ap.add_argument("--factors", default="0.5", help="comma-separated interpolation factors per pair")
-    ap.add_argument("--content", choices=["translated", "uncorrelated"], default="translated")
+    ap.add_argument("--content", choices=["translated", "uncorrelated", "static", "fade"], default="translated",
+                    help="translated (default: curr = prev shifted by (3,-2)), uncorrelated (independent noise frames), "
+                         "static (curr = prev), fade (flat grey frames one level apart: every candidate ties at a "
+                         "non-zero cost, the prefilter's worst case -- all tiles fall back to the literal kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -193,8 +196,13 @@ def main():
     prev_in = synth.make_prev(w_in, h_in, synth.BASE_SEED)
     if args.content == "translated":
         curr_in = synth.translate(prev_in, (3 + rank, -2), synth.BASE_SEED + rank)
-    else:
+    elif args.content == "uncorrelated":
         curr_in = synth.noise_bytes(w_in, h_in, (synth.BASE_SEED + 7919 * (rank + 1)) & 0xFFFFFFFF)
+    elif args.content == "static":
+        curr_in = prev_in.copy()
+    else:                                                   # fade
+        prev_in = np.full((h_in, w_in, 4), 100, np.uint8)
+        curr_in = np.full((h_in, w_in, 4), 101, np.uint8)
     t_prev_in, f_prev_in = dev_frame(prev_in)
     t_curr_in, f_curr_in = dev_frame(curr_in)
     t_curr4, f_curr4 = empty_frame(w, h)
