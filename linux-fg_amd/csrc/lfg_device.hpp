@@ -49,6 +49,7 @@ __device__ __forceinline__ uint32_t pack_rgba8_unorm(float r, float g, float b, 
 // 256 byte values, i.e. oracle choice (1), at zero VALU cost.  hipcc exposes no builtin for the format
 // loads, so they are issued from inline asm; the compiler does not track them, hence the explicit
 // s_waitcnt that takes every loaded register as an in/out operand (uses cannot be scheduled above it).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
@@ -66,41 +67,9 @@ __device__ __forceinline__ i32x4 make_rgba8_rsrc(const void *base, uint32_t byte
     return r;
 }
 
-// Load RGBA8 texels at byte offsets `o*` as float4 each.  Issue and wait live in ONE asm statement:
+// Load ten RGBA8 texels at byte offsets `o[]` as float4 each.  Issue and wait live in ONE asm statement:
 // the outputs are only defined once the statement ends, so the compiler can never copy or spill a
 // register that a load is still writing (it does not track these loads).
-#define LFG_TBUF "tbuffer_load_format_xyzw %0, %1, %2, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen"
-__device__ __forceinline__ void load_rgba8_unorm_x3(f32x4 &a, f32x4 &b, f32x4 &c, int oa, int ob, int oc, i32x4 rsrc) {
-    asm volatile(
-        "tbuffer_load_format_xyzw %0, %3, %6, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
-        "tbuffer_load_format_xyzw %1, %4, %6, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
-        "tbuffer_load_format_xyzw %2, %5, %6, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
-        "s_waitcnt vmcnt(0)"
-        : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(oa), "v"(ob), "v"(oc), "s"(rsrc) : "memory");
-}
-__device__ __forceinline__ void load_rgba8_unorm_x4(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d,
-                                                    int oa, int ob, int oc, int od, i32x4 rsrc) {
-    asm volatile(
-        "tbuffer_load_format_xyzw %0, %4, %8, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
-        "tbuffer_load_format_xyzw %1, %5, %8, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
-        "tbuffer_load_format_xyzw %2, %6, %8, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
-        "tbuffer_load_format_xyzw %3, %7, %8, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
-        "s_waitcnt vmcnt(0)"
-        : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(oa), "v"(ob), "v"(oc), "v"(od), "s"(rsrc) : "memory");
-}
-#undef LFG_TBUF
-__device__ __forceinline__ void load_rgba8_unorm_x5(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d, f32x4 &e,
-                                                    int oa, int ob, int oc, int od, int oe, i32x4 rsrc) {
-    asm volatile(
-        "tbuffer_load_format_xyzw %0, %5, %10, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
-        "tbuffer_load_format_xyzw %1, %6, %10, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
-        "tbuffer_load_format_xyzw %2, %7, %10, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
-        "tbuffer_load_format_xyzw %3, %8, %10, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
-        "tbuffer_load_format_xyzw %4, %9, %10, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
-        "s_waitcnt vmcnt(0)"
-        : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e)
-        : "v"(oa), "v"(ob), "v"(oc), "v"(od), "v"(oe), "s"(rsrc) : "memory");
-}
 __device__ __forceinline__ void load_rgba8_unorm_x10(f32x4 (&p)[10], const int (&o)[10], i32x4 rsrc) {
     asm volatile(
         "tbuffer_load_format_xyzw %0, %10, %20, 0 format:[BUF_DATA_FORMAT_8_8_8_8,BUF_NUM_FORMAT_UNORM] offen\n\t"
@@ -119,28 +88,6 @@ __device__ __forceinline__ void load_rgba8_unorm_x10(f32x4 (&p)[10], const int (
         : "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(o[4]), "v"(o[5]), "v"(o[6]), "v"(o[7]), "v"(o[8]), "v"(o[9]),
           "s"(rsrc)
         : "memory");
-}
-
-// Sixteen consecutive floats from LDS as eight ds_read_b64 (never merged into ds_read2_b64 / split into
-// dword reads by the compiler, whose banking differs), issue and wait in one statement.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void lds_read_16f_b64(float (&e)[16], const float *lds_ptr) {
-    const uint32_t a = (uint32_t)(uintptr_t)lds_ptr;     // LDS byte address (low 32 bits of the generic pointer)
-    f32x2 q0, q1, q2, q3, q4, q5, q6, q7;
-    asm volatile(
-        "ds_read_b64 %0, %8\n\t"
-        "ds_read_b64 %1, %8 offset:8\n\t"
-        "ds_read_b64 %2, %8 offset:16\n\t"
-        "ds_read_b64 %3, %8 offset:24\n\t"
-        "ds_read_b64 %4, %8 offset:32\n\t"
-        "ds_read_b64 %5, %8 offset:40\n\t"
-        "ds_read_b64 %6, %8 offset:48\n\t"
-        "ds_read_b64 %7, %8 offset:56\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5), "=&v"(q6), "=&v"(q7)
-        : "v"(a) : "memory");
-    e[0] = q0.x; e[1] = q0.y; e[2] = q1.x; e[3] = q1.y; e[4] = q2.x; e[5] = q2.y; e[6] = q3.x; e[7] = q3.y;
-    e[8] = q4.x; e[9] = q4.y; e[10] = q5.x; e[11] = q5.y; e[12] = q6.x; e[13] = q6.y; e[14] = q7.x; e[15] = q7.y;
 }
 
 // Orders this wave's LDS traffic for cross-lane exchange inside ONE wave: a wavefront-scope fence

@@ -24,7 +24,7 @@ struct AxisTable {
     float *d_weight = nullptr;    // [out_size][6]
 };
 
-struct MotionWorkspaceLayout { size_t list, listC, umin, count, tileFlags, order, auxList, auxUmin, auxCount, total; };
+struct MotionWorkspaceLayout { size_t list, umin, count, tileFlags, order, auxList, auxUmin, auxCount, total; };
 // Work units of the motion prefilter (motion.hip: prefilter_split): units [0, fullTiles) are whole 56 x 64 tiles, each
 // later tile is shared by `split` units with private lists in the aux arrays.
 struct PrefilterSplit {

@@ -789,7 +789,6 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, Motion
     auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
     MotionWorkspaceLayout l;
     l.list = 0;
-    l.listC = 0;                                                      // (unused: records carry their candidate)
     l.umin = align(l.list + px * kListK * sizeof(uint2));
     l.count = align(l.umin + px * sizeof(float));
     l.tileFlags = align(l.count + px * sizeof(uint32_t));
