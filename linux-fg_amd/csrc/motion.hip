@@ -555,15 +555,23 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
         }
     };
     // slab traffic of one candidate: rows 0-7 out, their transposed runs in, rows 8-15 out, runs in
+    // (The wave-scope fences are for the compiler only: writes go through an f32x2 pointer, reads through a float
+    //  LDS pointer, and nothing else tells it that the reads of a pass must stay between that pass's writes and
+    //  the next pass's.  The hardware executes one wave's DS operations in order.)
     auto transpose = [&](const float (&v8)[kSeg], f32x2 (&X)[kRunIn]) {
+        wave_lds_sync();
 #pragma unroll
         for (int a = 0; a < 4; ++a) slabW[a * (kSlabP / 2)] = f32x2{v8[2 * a], v8[2 * a + 1]};
+        wave_lds_sync();
 #pragma unroll
         for (int i = 0; i < kRunIn; ++i) X[i].x = slabR[2 * i];
+        wave_lds_sync();
 #pragma unroll
         for (int a = 0; a < 4; ++a) slabW[a * (kSlabP / 2)] = f32x2{v8[8 + 2 * a], v8[9 + 2 * a]};
+        wave_lds_sync();
 #pragma unroll
         for (int i = 0; i < kRunIn; ++i) X[i].y = slabR[2 * i];
+        wave_lds_sync();
     };
 
     auto run = [&]() -> bool {
@@ -575,22 +583,46 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
         const int eFirst = chunk > 0 ? eBegin - 1 : eBegin;
         auto orderAt = [&](int e) { return order32[e < eBegin ? 0 : min(e, kCand - 1)]; };
         uint32_t ordE = orderAt(eFirst), ordN = orderAt(eFirst + 1);   // candidates e, e+1 (scalar loads, one step ahead)
+        // Once EVERY pixel of this wave owns a zero-cost candidate, a candidate can only still matter if it comes
+        // earlier in the tie order than the latest of those: zeroBound = that rank (none: 0xFFFFFFFF), refreshed
+        // every 16 candidates.  Later-ranked candidates are skipped outright -- static areas and exact
+        // translations end the search early, exactly as "stop at cost 0" would, without changing any result.
+        uint32_t zeroBound = 0xFFFFFFFFu;
+        auto refreshZeroBound = [&]() {
+            uint32_t k = 0u;
+#pragma unroll
+            for (int i = 0; i < kRun; ++i) {
+                // (through named floats: __builtin_bit_cast applied to the vector-element lvalue thr2[i].y yields
+                //  the bits of .x with this compiler)
+                const float fx = thr2[i].x, fy = thr2[i].y;
+                const uint32_t b0 = __builtin_bit_cast(uint32_t, fx), b1 = __builtin_bit_cast(uint32_t, fy);
+                k = max(k, b0 == 0xFF800000u ? 0u : b0);               // -inf: a pixel outside the image
+                k = max(k, b1 == 0xFF800000u ? 0u : b1);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) k = max(k, (uint32_t)__shfl_xor((int)k, off));
+            k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+            zeroBound = k < 0x00800000u + (uint32_t)kCand ? (k >= 0x00800000u ? k - 0x00800000u : 0u) : 0xFFFFFFFFu;
+        };
+        bool skipE = false;                                            // candidate e was skipped (no sums in x)
         fetchWindow(p, ordE);
         columnSums(p, v8);
         transpose(v8, x);
         for (int e = eFirst; e < eEnd; ++e) {
             const uint32_t ordNN = orderAt(e + 2);
-            if (e + 1 < eEnd) fetchWindow(p, ordN);                    // candidate e+1: reads in flight ...
-            rowSumsAndTest(x, ordE & 0xFFFFu, e >= eBegin ? 1u : 0u);   // ... while candidate e is finished
+            const bool skipN = e + 1 >= eEnd || (ordN & 0xFFFFu) >= zeroBound;
+            if (!skipN) fetchWindow(p, ordN);                          // candidate e+1: reads in flight ...
+            if (!skipE) rowSumsAndTest(x, ordE & 0xFFFFu, e >= eBegin ? 1u : 0u);   // ... while candidate e is finished
             __builtin_amdgcn_sched_barrier(0);
-            if (e + 1 < eEnd) {
+            if (!skipN) {
                 columnSums(p, v8);
                 transpose(v8, x);
             }
-            ordE = ordN; ordN = ordNN;
+            ordE = ordN; ordN = ordNN; skipE = skipN;
             if ((e & 15) == 15) {                                      // lists full somewhere in the tile: stop early
                 if (__builtin_amdgcn_readfirstlane(__ballot(listsOverflowed()) != 0ull)) sGiveUp = 1u;
                 if (__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)&sGiveUp) != 0) return true;   // keeps the loop uniform
+                refreshZeroBound();
             }
         }
         return __builtin_amdgcn_readfirstlane(__ballot(listsOverflowed()) != 0ull);
