@@ -10,8 +10,11 @@ sys.path.insert(0, '$R')
 from linux_fg_amd import capi, synth
 ctx = capi.Context(0)
 W, H = 3840, 2160
-prev = synth.make_prev(W, H, seed=synth.BASE_SEED); curr = synth.translate(prev, (3, -2), synth.BASE_SEED)
-P, C = ctx.frame_from(prev), ctx.frame_from(curr); M = ctx.create_frame(W, H, capi.FORMAT_MV_S8X2)
+# the benchmark's frames: a translated 1080p pair, both upscaled on the device
+pin = synth.make_prev(W // 2, H // 2, seed=synth.BASE_SEED); cin = synth.translate(pin, (3, -2), synth.BASE_SEED)
+Pin, Cin = ctx.frame_from(pin), ctx.frame_from(cin)
+P, C = ctx.create_frame(W, H), ctx.create_frame(W, H); M = ctx.create_frame(W, H, capi.FORMAT_MV_S8X2)
+ctx.scale(Pin, P); ctx.scale(Cin, C)
 ctx.motion(P, C, M); ctx.sync()
 ctx.profile_enable(True); ctx.profile_reset()
 for _ in range(20): ctx.motion(P, C, M)
