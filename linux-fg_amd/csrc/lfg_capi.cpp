@@ -138,6 +138,14 @@ int ensure_motion_workspace(lfg_context *ctx, uint32_t width, uint32_t height) {
     } else {
         LFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+    // work-unit tables of this frame size: unitMap | unitAux | tileMap
+    const lfg::PrefilterPlanHost plan = lfg::prefilter_plan(width, height, ctx->motion_slots);
+    std::vector<uint32_t> tables;
+    tables.insert(tables.end(), plan.unitMap.begin(), plan.unitMap.end());
+    tables.insert(tables.end(), plan.unitAux.begin(), plan.unitAux.end());
+    tables.insert(tables.end(), plan.tileMap.begin(), plan.tileMap.end());
+    LFG_HIP(ctx, hipMemcpy(ctx->motion_ws + layout.plan, tables.data(), tables.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    ctx->motion_units = plan.units;
     ctx->motion_ws_layout = layout;
     ctx->motion_ws_w = width; ctx->motion_ws_h = height;
     return LFG_OK;
@@ -476,7 +484,7 @@ LFG_EXPORT int lfg_motion(lfg_context *ctx, const lfg_frame *prev, const lfg_fra
     StageTimer timer(ctx, LFG_STAGE_MOTION);
     hipError_t e;
     if (tiled && ctx->motion_mode == LFG_MOTION_PREFILTERED)
-        e = lfg::launch_motion_prefiltered_8_16(ctx->stream, *prev, *curr, *mv, ctx->motion_ws, ctx->motion_ws_layout, ctx->motion_slots,
+        e = lfg::launch_motion_prefiltered_8_16(ctx->stream, *prev, *curr, *mv, ctx->motion_ws, ctx->motion_ws_layout, ctx->motion_units,
                                                 rank2scan, order32, order32 + lfg::kMotionTableWords,
                                                 ctx->motion_tables + 6 * lfg::kMotionTableWords, ctx->motion_hints);
     else if (tiled) e = lfg::launch_motion_tiled_8_16(ctx->stream, *prev, *curr, *mv, nullptr, rank2scan);
@@ -519,11 +527,11 @@ LFG_EXPORT int lfg_motion_last_stats(lfg_context *ctx, uint32_t *out_tiles, uint
         std::vector<uint32_t> cnt(px);
         LFG_HIP(ctx, hipMemcpy(cnt.data(), ctx->motion_ws + ctx->motion_ws_layout.count, px * 4, hipMemcpyDeviceToHost));
         // (tiles whose candidates were shared between several workgroups keep their counts elsewhere: left out)
-        const lfg::PrefilterSplit sp = lfg::prefilter_split(ctx->motion_ws_w, ctx->motion_ws_h, ctx->motion_slots);
+        const lfg::PrefilterPlanHost plan = lfg::prefilter_plan(ctx->motion_ws_w, ctx->motion_ws_h, ctx->motion_slots);
         double sum = 0; size_t n = 0;
         for (uint32_t y = 0; y < ctx->motion_ws_h; ++y)
             for (uint32_t x = 0; x < ctx->motion_ws_w; ++x)
-                if (!flags[(size_t)(y / 64u) * tx + x / 64u] && (int)((y / 64u) * (uint32_t)sp.tilesX + x / 56u) < sp.fullTiles) {
+                if (!flags[(size_t)(y / 64u) * tx + x / 64u] && plan.tileMap[(size_t)(y / 64u) * (size_t)plan.tilesX + x / 56u] == 0xFFFFFFFFu) {
                     sum += cnt[(size_t)y * ctx->motion_ws_w + x]; ++n;
                 }
         *out_mean_recorded = n ? sum / (double)n : 0.0;

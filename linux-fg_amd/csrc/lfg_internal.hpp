@@ -24,14 +24,21 @@ struct AxisTable {
     float *d_weight = nullptr;    // [out_size][6]
 };
 
-struct MotionWorkspaceLayout { size_t list, umin, count, tileFlags, order, auxList, auxUmin, auxCount, total; };
-// Work units of the motion prefilter (motion.hip: prefilter_split): units [0, fullTiles) are whole 56 x 64 tiles, each
-// later tile is shared by `split` units with private lists in the aux arrays.
-struct PrefilterSplit {
-    int tilesX, fullTiles, split, units;
+struct MotionWorkspaceLayout { size_t list, umin, count, tileFlags, order, plan, auxList, auxUmin, auxCount, total; };
+// Work units of the motion prefilter (motion.hip: prefilter_plan).  A unit is a 56 x 64 tile, or one of nChunks
+// contiguous parts of a tile's candidate order with private lists in the aux arrays (merged by the resolve kernel).
+struct PrefilterPlan {               // passed by value to the kernels
+    int tilesX, units;
+    const uint32_t *unitMap;         // per unit: tile | chunk << 20 | nChunks << 24
+    const uint32_t *unitAux;         // per unit: index of its 56 x 64 block in the aux arrays (whole tiles: 0xFFFFFFFF)
+    const uint32_t *tileMap;         // per tile: 0xFFFFFFFF (whole) or first aux index | nChunks << 24
     uint2 *auxList;
     float *auxUmin;
     uint32_t *auxCount;
+};
+struct PrefilterPlanHost {
+    int tilesX = 0, tiles = 0, units = 0, auxUnits = 0;
+    std::vector<uint32_t> unitMap, unitAux, tileMap;
 };
 
 struct ProfileSlot {
@@ -53,6 +60,7 @@ struct lfg_context {
     size_t motion_ws_bytes = 0;
     uint32_t motion_ws_w = 0, motion_ws_h = 0;
     lfg::MotionWorkspaceLayout motion_ws_layout{};
+    int motion_units = 0;                      // work units of the prefilter for the current workspace size
     int motion_slots = 0;                      // prefilter workgroups resident at once on this device (0 = not queried yet)
     int motion_mode = 0;                       // 0: prefilter + exact fallback, 1: exact kernel only
     int semantics = 0;                         // 0: the shaders as written, 1: "intended" (lfg_set_semantics)
@@ -82,10 +90,10 @@ constexpr int kMotionTableWords = 1092;     // 33 * 33 candidates + the sentinel
 void motion_tables(bool intended, uint32_t *rank2scan, uint32_t *order32, uint32_t *entryOfScan, uint32_t *baseScan);
 // Prefiltered motion path (motion.hip): MotionWorkspaceLayout = byte offsets of its scratch arrays.
 size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, MotionWorkspaceLayout *layout);
-PrefilterSplit prefilter_split(uint32_t width, uint32_t height, int slots);
+PrefilterPlanHost prefilter_plan(uint32_t width, uint32_t height, int slots);
 int prefilter_slots();      // workgroups of the prefilter kernel the current device holds at once
 hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
-                                          const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &layout, int slots,
+                                          const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &layout, int units,
                                           const uint32_t *rank2scan, const uint32_t *order32,
                                           const uint32_t *entryOfScan, const uint32_t *baseScan, bool useHints);
 hipError_t launch_motion_generic(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,

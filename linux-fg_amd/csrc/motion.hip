@@ -336,7 +336,7 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int W, int H, uint2 *__restrict__ list, float *__restrict__ uminOut,
     uint32_t *__restrict__ countOut, uint32_t *__restrict__ tileFlags, int flagTilesX,
-    const uint32_t *__restrict__ order32, PrefilterSplit sp) {
+    const uint32_t *__restrict__ order32, PrefilterPlan sp) {
     __shared__ uint32_t sWin[kWinH * kWinW];                           // 38.2 KB packed RGBA8 search window
     __shared__ __attribute__((aligned(8))) float sSlab[kPNT / 64][4 * kSlabP];      // 4 x 2.1 KB
     __shared__ uint32_t sGiveUp;
@@ -344,13 +344,13 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int seg = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave index 0..3
-    // Work units (PrefilterSplit): the first sp.fullTiles units are whole tiles; each remaining tile is shared by
-    // sp.split units that take a contiguous part of the candidate order each and write to their own lists.
+    // Work units (PrefilterPlan): a whole tile, or one of nChunks contiguous parts of a tile's candidate order
+    // with private lists.
     const int unit = blockIdx.x;
-    const bool whole = unit < sp.fullTiles;
-    const int tile = whole ? unit : sp.fullTiles + (unit - sp.fullTiles) / sp.split;
-    const int chunk = whole ? 0 : (unit - sp.fullTiles) % sp.split;
-    const int perChunk = whole ? kCand : (kCand + sp.split - 1) / sp.split;
+    const uint32_t um = sp.unitMap[unit];
+    const int tile = (int)(um & 0xFFFFFu), chunk = (int)((um >> 20) & 0xFu), nChunks = (int)(um >> 24);
+    const bool whole = nChunks == 1;
+    const int perChunk = (kCand + nChunks - 1) / nChunks;
     const int eBegin = chunk * perChunk, eEnd = min(kCand, eBegin + perChunk);
     const int tileY = tile / sp.tilesX, tileX = tile - tileY * sp.tilesX;
     const int tx0 = tileX * kPTW, ty0 = tileY * kPTH;                  // tile origin (pixels)
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     // Address = wave-uniform base + 32-bit lane offset; k * W is a 24-bit multiply.
     // Whole tiles write into the image-shaped arrays (row stride W), shared tiles into their unit's private
     // 56 x 64 block of the auxiliary arrays (row stride 56).
-    const int auxUnit = unit - sp.fullTiles;                           // valid when !whole
+    const int auxUnit = whole ? 0 : (int)sp.unitAux[unit];
     const uint32_t rowStride = whole ? (uint32_t)W : (uint32_t)kPTW;
     uint2 *const waveList = whole
         ? list + ((size_t)(ty0 + kSeg * seg) * (size_t)kListK * (size_t)W + (size_t)tx0)
@@ -578,16 +578,20 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
         uint32_t p[kSegD];
         float v8[kSeg];
         f32x2 x[kRunIn];
-        // A unit that shares its tile starts with zero motion as well (threshold only, not recorded: unit 0 owns
-        // it), so static areas close their threshold at once in every unit.
-        const int eFirst = chunk > 0 ? eBegin - 1 : eBegin;
-        auto orderAt = [&](int e) { return order32[e < eBegin ? 0 : min(e, kCand - 1)]; };
+        // A unit that shares its tile first runs the head of the order -- zero motion and the first hints -- for the
+        // thresholds only (not recorded: the unit that owns those entries records them).  Without it a unit whose part
+        // of the order holds no good candidate records every member of a plateau of equal costs (e.g. all the
+        // candidates that sample nothing but out-of-image zeros at the rim) and overflows its lists.
+        constexpr int kHead = 16;
+        const int eFirst = chunk > 0 ? eBegin - kHead : eBegin;
+        auto orderAt = [&](int e) { return order32[e < eBegin ? e - eFirst : min(e, kCand - 1)]; };
         uint32_t ordE = orderAt(eFirst), ordN = orderAt(eFirst + 1);   // candidates e, e+1 (scalar loads, one step ahead)
         // Once EVERY pixel of this wave owns a zero-cost candidate, a candidate can only still matter if it comes
         // earlier in the tie order than the latest of those: zeroBound = that rank (none: 0xFFFFFFFF), refreshed
         // every 16 candidates.  Later-ranked candidates are skipped outright -- static areas and exact
         // translations end the search early, exactly as "stop at cost 0" would, without changing any result.
         uint32_t zeroBound = 0xFFFFFFFFu;
+        float waveThr = __builtin_inff();
         auto refreshZeroBound = [&]() {
             uint32_t k = 0u;
 #pragma unroll
@@ -603,14 +607,57 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
             for (int off = 32; off > 0; off >>= 1) k = max(k, (uint32_t)__shfl_xor((int)k, off));
             k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
             zeroBound = k < 0x00800000u + (uint32_t)kCand ? (k >= 0x00800000u ? k - 0x00800000u : 0u) : 0xFFFFFFFFu;
+            waveThr = __builtin_bit_cast(float, k);                    // largest threshold of the wave's pixels (+inf: none yet)
+        };
+        // Partial-distortion test.  S~ is a sum of non-negative distances, and a rounded fp32 sum of non-negative
+        // terms is never below any of its terms, so S~(p, m) >= D_m(c) for every position c of p's block.  A lattice
+        // of positions that puts a point into every pixel's 8 x 8 block therefore certifies the whole wave: if the
+        // candidate's distance exceeds waveThr at all of them, no pixel can pass its own (smaller) threshold and the
+        // candidate is dropped after a handful of its 23 x 63 distances.
+        //   interior tiles: rows 3|11|19, columns = 3 mod 8 -- exactly one point per block, 24 in all;
+        //   border tiles:   rows 4|8|12|16, columns = 0 mod 4 in 4..56 -- the point (4*floor(x/4), 4*floor(y/4)) of
+        //                   pixel (x, y) lies in its block and inside the image whenever the pixel does, so
+        //                   positions outside the image are simply left out.
+        // The lattice texels of candidate e+2 are read while e+1 is decided.
+        uint32_t lat[4];
+        const bool latticeLane = borderTile ? ((lane & 3) == 0 && lane >= 4 && lane <= kPTW)
+                                            : ((lane & 7) == 3 && lane < kPTW + kB - 1);
+        auto fetchLattice = [&](uint32_t ord) {
+            const lds_ro_u32_ptr w = winBase + (ord >> 16);
+            if (borderTile) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) lat[t] = w[4 + 4 * t];
+            } else {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) lat[t] = w[3 + 8 * t];
+            }
+        };
+        auto latticeDistance = [&](int j, uint32_t texel) {                         // same arithmetic as columnSums
+            const float f1 = __builtin_bit_cast(float, __builtin_amdgcn_udot4(texel, texel, cc[j], false));
+            const float f2 = __builtin_bit_cast(float, __builtin_amdgcn_udot4(c[j], texel, 0x4B800000u, false));
+            return __builtin_amdgcn_sqrtf((f1 - f2) + 8388608.0f);
+        };
+        auto latticeRejects = [&]() -> bool {
+            bool pass = true;              // every lattice distance of this lane exceeds waveThr
+            if (borderTile) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    pass = pass && (((valid >> (4 + 4 * t)) & 1u) == 0u || latticeDistance(4 + 4 * t, lat[t]) > waveThr);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) pass = pass && latticeDistance(3 + 8 * t, lat[t]) > waveThr;
+            }
+            return __builtin_amdgcn_readfirstlane(__ballot(latticeLane && !pass) == 0ull);
         };
         bool skipE = false;                                            // candidate e was skipped (no sums in x)
         fetchWindow(p, ordE);
+        fetchLattice(ordN);
         columnSums(p, v8);
         transpose(v8, x);
         for (int e = eFirst; e < eEnd; ++e) {
             const uint32_t ordNN = orderAt(e + 2);
-            const bool skipN = e + 1 >= eEnd || (ordN & 0xFFFFu) >= zeroBound;
+            const bool skipN = e + 1 >= eEnd || (ordN & 0xFFFFu) >= zeroBound || latticeRejects();
+            fetchLattice(ordNN);
             if (!skipN) fetchWindow(p, ordN);                          // candidate e+1: reads in flight ...
             if (!skipE) rowSumsAndTest(x, ordE & 0xFFFFu, e >= eBegin ? 1u : 0u);   // ... while candidate e is finished
             __builtin_amdgcn_sched_barrier(0);
@@ -691,7 +738,7 @@ __global__ __launch_bounds__(256) void motion_resolve_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int8_t *__restrict__ mv, int mvPitch, int W, int H, const uint2 *__restrict__ list,
     const float *__restrict__ uminIn, const uint32_t *__restrict__ countIn, const uint32_t *__restrict__ tileFlags,
-    int tilesX, PrefilterSplit sp, const uint32_t *__restrict__ rank2scan) {
+    int tilesX, PrefilterPlan sp, const uint32_t *__restrict__ rank2scan) {
     // Candidates are identified by their RANK in the tie order everywhere in the prefiltered path (lists, the
     // zero-cost encoding), so "smallest rank among equal costs" is the tie-break; rank2scan turns it into (dx, dy).
     __shared__ float sDist[4][kB * kB];    // one block of distances per wave (cooperative exact evaluation)
@@ -702,12 +749,13 @@ __global__ __launch_bounds__(256) void motion_resolve_kernel(
     // (inside the image and not in a tile that goes through the exact kernel).
     const bool inside = px < W && py < H;
     const bool live = inside && tileFlags[(py / kTH) * tilesX + px / kTW] == 0u;
-    // Where this pixel's records live: one list in the image-shaped arrays, or sp.split lists (one per unit that
+    // Where this pixel's records live: one list in the image-shaped arrays, or several lists (one per unit that
     // shared the tile's candidates) in the auxiliary arrays.  Record k of list c: recs[c * listStride + k * recStride].
     const int cpx = min(px, W - 1), cpy = min(py, H - 1);
     const int ptile = (cpy / kPTH) * sp.tilesX + cpx / kPTW;
-    const bool whole = ptile < sp.fullTiles;
-    const int nLists = whole ? 1 : sp.split;
+    const uint32_t tm = sp.tileMap[ptile];
+    const bool whole = tm == 0xFFFFFFFFu;
+    const int nLists = whole ? 1 : (int)(tm >> 24);
     const uint2 *recs;
     const float *thrs;
     const uint32_t *cnts;
@@ -718,7 +766,7 @@ __global__ __launch_bounds__(256) void motion_resolve_kernel(
         cnts = countIn + (size_t)cpy * (size_t)W + (size_t)cpx;
         listStride = 0u; recStride = (uint32_t)W; thrStride = 0u;
     } else {
-        const size_t unit0 = (size_t)(ptile - sp.fullTiles) * (size_t)sp.split;
+        const size_t unit0 = (size_t)(tm & 0xFFFFFFu);
         const int ly = cpy % kPTH, lx = cpx % kPTW;
         recs = sp.auxList + (unit0 * kPTH + (size_t)ly) * (size_t)kListK * kPTW + (size_t)lx;
         thrs = sp.auxUmin + (unit0 * kPTH + (size_t)ly) * kPTW + (size_t)lx;
@@ -825,10 +873,11 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, Motion
     l.count = align(l.umin + px * sizeof(float));
     l.tileFlags = align(l.count + px * sizeof(uint32_t));
     l.order = align(l.tileFlags + tiles * sizeof(uint32_t));          // this call's hints and visiting order
-    // auxiliary arrays of the shared tiles (see prefilter_split): one 56 x 64 block per unit
-    const PrefilterSplit sp = prefilter_split(width, height, slots);
-    const size_t auxUnits = (size_t)(sp.units - sp.fullTiles);
-    l.auxList = align(l.order + (kHints + kCand + 3) * sizeof(uint32_t));
+    // work-unit tables and the auxiliary arrays of the shared tiles (see prefilter_plan): one 56 x 64 block per unit
+    const PrefilterPlanHost plan = prefilter_plan(width, height, slots);
+    const size_t auxUnits = (size_t)plan.auxUnits;
+    l.plan = align(l.order + (kHints + kCand + 3) * sizeof(uint32_t));
+    l.auxList = align(l.plan + (size_t)(2 * plan.units + plan.tiles) * sizeof(uint32_t));
     l.auxUmin = align(l.auxList + auxUnits * kPTH * kPTW * kListK * sizeof(uint2));
     l.auxCount = align(l.auxUmin + auxUnits * kPTH * kPTW * sizeof(float));
     l.total = align(l.auxCount + auxUnits * kPTH * kPTW * sizeof(uint32_t));
@@ -836,20 +885,37 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, Motion
     return l.total;
 }
 
-// How the prefilter's tiles map onto `slots` concurrently resident workgroups.  All workgroups take the same time,
-// so a launch runs in rounds of `slots`; the tiles of the last, partial round are each shared by `split` workgroups
-// (contiguous parts of the candidate order, private lists, merged by the resolve kernel) so that they finish in a
-// fraction of a round instead of a whole one.
-PrefilterSplit prefilter_split(uint32_t width, uint32_t height, int slots) {
-    PrefilterSplit sp{};
-    sp.tilesX = ((int)width + kPTW - 1) / kPTW;
-    const int tiles = sp.tilesX * (((int)height + kPTH - 1) / kPTH);
-    const int rest = slots > 0 ? tiles % slots : 0;
-    sp.split = 1;
-    if (rest > 0 && rest * 2 <= slots) sp.split = min(8, slots / rest);
-    sp.fullTiles = sp.split > 1 ? tiles - rest : tiles;
-    sp.units = sp.fullTiles + (tiles - sp.fullTiles) * sp.split;
-    return sp;
+// How the prefilter's tiles become work units for `slots` concurrently resident workgroups.
+//   * Tiles on the rim of the image (some block position outside it) often hold pixels without a good match -- the
+//     band a moving camera exposes -- so their partial-distortion test rarely fires and they run the full search,
+//     many times longer than an interior tile: they are dispatched first, so the short interior tiles fill in
+//     around them instead of waiting for them at the end.
+//   * A frame with fewer tiles than half the slots is split by candidates throughout (contiguous parts of the
+//     candidate order per unit, private lists, merged by the resolve kernel), to fill the chip.
+PrefilterPlanHost prefilter_plan(uint32_t width, uint32_t height, int slots) {
+    PrefilterPlanHost p;
+    const int W = (int)width, H = (int)height;
+    p.tilesX = (W + kPTW - 1) / kPTW;
+    const int tilesY = (H + kPTH - 1) / kPTH;
+    p.tiles = p.tilesX * tilesY;
+    p.tileMap.assign((size_t)p.tiles, 0xFFFFFFFFu);
+    const int n = (slots > 0 && p.tiles * 2 <= slots) ? std::max(2, std::min(8, slots / std::max(p.tiles, 1))) : 1;
+    for (int pass = 0; pass < 2; ++pass) {                 // pass 0: rim tiles, pass 1: interior tiles
+        for (int t = 0; t < p.tiles; ++t) {
+            const int ty = t / p.tilesX, tx = t - ty * p.tilesX;
+            const int bx0 = tx * kPTW - kB / 2, by0 = ty * kPTH - kB / 2;
+            const bool rim = !((bx0 >= 0) && (bx0 + kPTW + kB - 2 < W) && (by0 >= 0) && (by0 + kPTH + kB - 2 < H));
+            if (rim != (pass == 0)) continue;
+            if (n == 1) { p.unitMap.push_back((uint32_t)t | (1u << 24)); p.unitAux.push_back(0xFFFFFFFFu); continue; }
+            p.tileMap[(size_t)t] = (uint32_t)p.auxUnits | ((uint32_t)n << 24);
+            for (int c = 0; c < n; ++c) {
+                p.unitMap.push_back((uint32_t)t | ((uint32_t)c << 20) | ((uint32_t)n << 24));
+                p.unitAux.push_back((uint32_t)p.auxUnits++);
+            }
+        }
+    }
+    p.units = (int)p.unitMap.size();
+    return p;
 }
 
 int prefilter_slots() {
@@ -996,7 +1062,7 @@ __global__ __launch_bounds__(256) void motion_order_kernel(
 }
 
 hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
-                                          const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &l, int slots,
+                                          const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &l, int units,
                                           const uint32_t *rank2scan, const uint32_t *order,
                                           const uint32_t *entryOfScan, const uint32_t *baseScan, bool useHints) {
     const int tilesX = ((int)curr.width + kTW - 1) / kTW, tilesY = ((int)curr.height + kTH - 1) / kTH;
@@ -1005,7 +1071,12 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
     uint32_t *count = reinterpret_cast<uint32_t *>(workspace + l.count);
     uint32_t *flags = reinterpret_cast<uint32_t *>(workspace + l.tileFlags);
     static_assert(kPTH == kTH, "prefilter tiles and exact tiles share their rows");
-    PrefilterSplit sp = prefilter_split(curr.width, curr.height, slots);
+    PrefilterPlan sp{};
+    sp.tilesX = ((int)curr.width + kPTW - 1) / kPTW;
+    sp.units = units;
+    sp.unitMap = reinterpret_cast<const uint32_t *>(workspace + l.plan);
+    sp.unitAux = sp.unitMap + units;
+    sp.tileMap = sp.unitAux + units;
     sp.auxList = reinterpret_cast<uint2 *>(workspace + l.auxList);
     sp.auxUmin = reinterpret_cast<float *>(workspace + l.auxUmin);
     sp.auxCount = reinterpret_cast<uint32_t *>(workspace + l.auxCount);
