@@ -327,8 +327,20 @@ static_assert(kPNT / 64 * kSeg == kPTH && 8 * kRun == kPTW && kPTH == kTH, "stag
 
 static_assert(kPTW + kB - 1 <= 64 && kWinW >= kPTW + kB - 1 + 2 * kR, "one lane per position column");
 
+// Candidates whose whole shifted block lies outside prev on one axis sample nothing but out-of-image zeros, so for
+// a given pixel they all cost exactly the same (the same sequence of |curr texel| distances): a plateau of up to a few
+// hundred tied candidates next to the left/right/top/bottom edge.  Only the first of them in tie order can win, so the
+// prefilter records ONE member of the plateau per pixel and the resolve kernel replaces it by the first in tie order.
+__device__ __forceinline__ bool block_leaves_prev(int px, int py, int dx, int dy, int W, int H) {
+    return (px + kB / 2 - 1 + dx < 0) | (px - kB / 2 + dx >= W) | (py + kB / 2 - 1 + dy < 0) | (py - kB / 2 + dy >= H);
+}
+
 typedef const __attribute__((address_space(3))) uint32_t *lds_ro_u32_ptr;
 typedef const __attribute__((address_space(3))) float *lds_ro_f32_ptr;
+
+#ifdef LFG_MOTION_STAMPS   // diagnostic build (tools/build_variant.sh stamps -DLFG_MOTION_STAMPS): per-wave timing and counts
+__device__ unsigned long long gMotionStamps[8192 * 4 * 4];
+#endif
 
 // order32[e] = the candidate's rank in the tie order (motion_tables) in the low half, its window offset
 // (dx+R)*kWinH + (dy+R) in the high half; 32-bit entries so the wave-uniform reads are scalar loads.
@@ -339,11 +351,16 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     const uint32_t *__restrict__ order32, PrefilterPlan sp) {
     __shared__ uint32_t sWin[kWinH * kWinW];                           // 38.2 KB packed RGBA8 search window
     __shared__ __attribute__((aligned(8))) float sSlab[kPNT / 64][4 * kSlabP];      // 4 x 2.1 KB
+    __shared__ uint32_t sOrder[kCand + 7];                             // this unit's part of the visiting order
     __shared__ uint32_t sGiveUp;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int seg = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave index 0..3
+#ifdef LFG_MOTION_STAMPS
+    const unsigned long long stampStart = __builtin_amdgcn_s_memrealtime();
+    unsigned stampEvals = 0u, stampBatches = 0u;
+#endif
     // Work units (PrefilterPlan): a whole tile, or one of nChunks contiguous parts of a tile's candidate order
     // with private lists.
     const int unit = blockIdx.x;
@@ -356,6 +373,13 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     const int tx0 = tileX * kPTW, ty0 = tileY * kPTH;                  // tile origin (pixels)
     const int bx0 = tx0 - kB / 2, by0 = ty0 - kB / 2;                  // image coords of block position (0,0)
     if (tid == 0) sGiveUp = 0u;
+    // A unit that shares its tile first runs the head of the order -- zero motion and the first hints -- for the
+    // thresholds only (not recorded: the unit that owns those entries records them).  Without it a unit whose part
+    // of the order holds no good candidate starts from nothing and records far more than it needs to.
+    constexpr int kHead = 16;
+    const int nHead = chunk > 0 ? kHead : 0;
+    const int eFirst = eBegin - nHead;
+    for (int i = tid; i < eEnd - eFirst; i += kPNT) sOrder[i] = order32[i < nHead ? i : eBegin + (i - nHead)];
 
     // ---- search window: prev(bx0 - R + wx, by0 - R + wy), zero outside the image (texelFetch semantics)
     for (int i = tid; i < kWinH * kWinW; i += kPNT) {
@@ -500,7 +524,10 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     // The test has levels: a packed "does anything pass" check (level 0, below), then all fourteen comparisons
     // (VALU -> scalar masks, pipelined) and one SCALAR branch per pixel; only a taken branch touches EXEC.  A divergent
     // `if` per pixel costs ~6 VALU slots each in compare -> saveexec -> branch latency (tools/bench_intops.hip).
-    auto rowSumsAndTest = [&](const f32x2 (&X)[kRunIn], uint32_t cand, uint32_t countIt) {
+    uint32_t plateauSeen = 0u;            // bit 7 hb + i: this pixel's list already holds a member of its plateau
+    auto rowSumsAndTest = [&](const f32x2 (&X)[kRunIn], uint32_t ord, uint32_t countIt) {
+        const uint32_t cand = ord & 0xFFFFu;
+        const int candDx = (int)((ord >> 16) / (uint32_t)kWinH) - kR, candDy = (int)((ord >> 16) % (uint32_t)kWinH) - kR;
         const uint32_t zeroCap = 0x00800000u + cand;                   // float bits, wave-uniform
         f32x2 s2[kRun];
         runSums(X, s2);
@@ -548,7 +575,12 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
                         // flags the tile
                         const uint32_t at = __umul24(min(n, (uint32_t)kListK - 1u), rowStride) + laneOff[hb] + (uint32_t)i;
                         waveList[at] = uint2{__builtin_bit_cast(uint32_t, s), cand};
-                        cnt2[hb][i >> 1] += (s != 0.0f) ? (countIt << (16 * (i & 1))) : 0u;
+                        // one member per plateau (block_leaves_prev): a second one is written but not counted
+                        const uint32_t bit = 1u << (kRun * hb + i);
+                        const bool plateau = block_leaves_prev(px0 + i, ty0 + kSeg * seg + 8 * hb + r8, candDx, candDy, W, H);
+                        const bool counted = s != 0.0f && countIt != 0u && !(plateau && (plateauSeen & bit) != 0u);
+                        cnt2[hb][i >> 1] += counted ? (1u << (16 * (i & 1))) : 0u;
+                        plateauSeen |= (plateau && counted) ? bit : 0u;
                     }
                 }
             }
@@ -578,18 +610,10 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
         uint32_t p[kSegD];
         float v8[kSeg];
         f32x2 x[kRunIn];
-        // A unit that shares its tile first runs the head of the order -- zero motion and the first hints -- for the
-        // thresholds only (not recorded: the unit that owns those entries records them).  Without it a unit whose part
-        // of the order holds no good candidate records every member of a plateau of equal costs (e.g. all the
-        // candidates that sample nothing but out-of-image zeros at the rim) and overflows its lists.
-        constexpr int kHead = 16;
-        const int eFirst = chunk > 0 ? eBegin - kHead : eBegin;
-        auto orderAt = [&](int e) { return order32[e < eBegin ? e - eFirst : min(e, kCand - 1)]; };
-        uint32_t ordE = orderAt(eFirst), ordN = orderAt(eFirst + 1);   // candidates e, e+1 (scalar loads, one step ahead)
         // Once EVERY pixel of this wave owns a zero-cost candidate, a candidate can only still matter if it comes
-        // earlier in the tie order than the latest of those: zeroBound = that rank (none: 0xFFFFFFFF), refreshed
-        // every 16 candidates.  Later-ranked candidates are skipped outright -- static areas and exact
-        // translations end the search early, exactly as "stop at cost 0" would, without changing any result.
+        // earlier in the tie order than the latest of those: zeroBound = that rank (none: 0xFFFFFFFF).  Later-ranked
+        // candidates are skipped outright -- static areas and exact translations end the search early, exactly as
+        // "stop at cost 0" would, without changing any result.
         uint32_t zeroBound = 0xFFFFFFFFu;
         float waveThr = __builtin_inff();
         auto refreshZeroBound = [&]() {
@@ -614,67 +638,101 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
         // of positions that puts a point into every pixel's 8 x 8 block therefore certifies the whole wave: if the
         // candidate's distance exceeds waveThr at all of them, no pixel can pass its own (smaller) threshold and the
         // candidate is dropped after a handful of its 23 x 63 distances.
-        //   interior tiles: rows 3|11|19, columns = 3 mod 8 -- exactly one point per block, 24 in all;
+        //   interior tiles: rows 3|11|19, columns = 3 mod 8 -- exactly one point per block, 3 x 8 in all;
         //   border tiles:   rows 4|8|12|16, columns = 0 mod 4 in 4..56 -- the point (4*floor(x/4), 4*floor(y/4)) of
         //                   pixel (x, y) lies in its block and inside the image whenever the pixel does, so
-        //                   positions outside the image are simply left out.
-        // The lattice texels of candidate e+2 are read while e+1 is decided.
-        uint32_t lat[4];
-        const bool latticeLane = borderTile ? ((lane & 3) == 0 && lane >= 4 && lane <= kPTW)
-                                            : ((lane & 7) == 3 && lane < kPTW + kB - 1);
-        auto fetchLattice = [&](uint32_t ord) {
-            const lds_ro_u32_ptr w = winBase + (ord >> 16);
-            if (borderTile) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) lat[t] = w[4 + 4 * t];
-            } else {
-#pragma unroll
-                for (int t = 0; t < 3; ++t) lat[t] = w[3 + 8 * t];
-            }
-        };
-        auto latticeDistance = [&](int j, uint32_t texel) {                         // same arithmetic as columnSums
-            const float f1 = __builtin_bit_cast(float, __builtin_amdgcn_udot4(texel, texel, cc[j], false));
-            const float f2 = __builtin_bit_cast(float, __builtin_amdgcn_udot4(c[j], texel, 0x4B800000u, false));
+        //                   positions outside the image are simply left out; 4 x 14 points.
+        // A wave tests a BATCH of candidates at once: lane = (lattice column, candidate), 8 lanes per candidate and
+        // 8 candidates on interior tiles, 16 and 4 on border tiles.  A lane fetches its candidate's entry of the
+        // order from LDS, the texels of its column from the window and the current-frame texels of that column from
+        // the lane that owns them (ds_bpermute); one ballot gives the candidates that survive.  The thresholds a
+        // batch is tested against may be one batch old -- larger, so the test only gets weaker.
+        const int nEntries = eEnd - eFirst;
+        int border = borderTile;
+        asm volatile("" : "+s"(border));   // one copy of the loop below, not one per kind of tile
+        const int grpShift = border ? 4 : 3;
+        const int perBatch = 64 >> grpShift;
+        const int ci = lane & ((1 << grpShift) - 1);
+        const int latCol = border ? 4 + 4 * ci : 3 + 8 * ci;           // border: ci = 14, 15 have no column
+        const int kSub = (border && ci >= 14) ? 2 * kCand : (lane >> grpShift);
+        const int latColC = min(latCol, kPTW + kB - 2);
+        const lds_ro_u32_ptr latBase = (lds_ro_u32_ptr)(sWin + latColC * kWinH + kSeg * seg);
+        auto distanceOf = [&](uint32_t cT, uint32_t texel) {           // same arithmetic as columnSums
+            const uint32_t ccT = __builtin_amdgcn_udot4(cT, cT, 0x4B000000u, false);
+            const float f1 = __builtin_bit_cast(float, __builtin_amdgcn_udot4(texel, texel, ccT, false));
+            const float f2 = __builtin_bit_cast(float, __builtin_amdgcn_udot4(cT, texel, 0x4B800000u, false));
             return __builtin_amdgcn_sqrtf((f1 - f2) + 8388608.0f);
         };
-        auto latticeRejects = [&]() -> bool {
-            bool pass = true;              // every lattice distance of this lane exceeds waveThr
-            if (borderTile) {
+        auto fromColumn = [&](uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute(latColC * 4, (int)v); };
+        // bit (k << grpShift) of the result: candidate i0 + k of the staged order has to be evaluated in full
+        auto latticeBatch = [&](int i0, uint32_t &ordL) -> unsigned long long {
+            const int idx = i0 + kSub;
+            ordL = ((lds_ro_u32_ptr)sOrder)[min(idx, nEntries - 1)];
+            bool need = idx < nEntries && (ordL & 0xFFFFu) < zeroBound;
+            if (waveThr < 510.0f) {                                    // a distance is at most sqrt(4 * 255^2) = 510
+                const lds_ro_u32_ptr w = latBase + (ordL >> 16);
+                bool allAbove = true;      // every lattice distance of this lane exceeds waveThr
+                if (border) {
+                    const uint32_t vL = fromColumn(valid);
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    pass = pass && (((valid >> (4 + 4 * t)) & 1u) == 0u || latticeDistance(4 + 4 * t, lat[t]) > waveThr);
-            } else {
+                    for (int t = 0; t < 4; ++t) {
+                        const float d = distanceOf(fromColumn(c[4 + 4 * t]), w[4 + 4 * t]);
+                        allAbove = allAbove && (((vL >> (4 + 4 * t)) & 1u) == 0u || d > waveThr);
+                    }
+                } else {
 #pragma unroll
-                for (int t = 0; t < 3; ++t) pass = pass && latticeDistance(3 + 8 * t, lat[t]) > waveThr;
+                    for (int t = 0; t < 3; ++t) allAbove = allAbove && distanceOf(fromColumn(c[3 + 8 * t]), w[3 + 8 * t]) > waveThr;
+                }
+                need = need && !allAbove;
             }
-            return __builtin_amdgcn_readfirstlane(__ballot(latticeLane && !pass) == 0ull);
+            unsigned long long m = __ballot(need);
+            m |= m >> 1; m |= m >> 2; m |= m >> 4;
+            if (border) m |= m >> 8;
+            return m & (border ? 0x0001000100010001ull : 0x0101010101010101ull);
         };
-        bool skipE = false;                                            // candidate e was skipped (no sums in x)
-        fetchWindow(p, ordE);
-        fetchLattice(ordN);
-        columnSums(p, v8);
-        transpose(v8, x);
-        for (int e = eFirst; e < eEnd; ++e) {
-            const uint32_t ordNN = orderAt(e + 2);
-            const bool skipN = e + 1 >= eEnd || (ordN & 0xFFFFu) >= zeroBound || latticeRejects();
-            fetchLattice(ordNN);
-            if (!skipN) fetchWindow(p, ordN);                          // candidate e+1: reads in flight ...
-            if (!skipE) rowSumsAndTest(x, ordE & 0xFFFFu, e >= eBegin ? 1u : 0u);   // ... while candidate e is finished
-            __builtin_amdgcn_sched_barrier(0);
-            if (!skipN) {
-                columnSums(p, v8);
-                transpose(v8, x);
+        for (int i0 = 0; i0 < nEntries; i0 += perBatch) {
+            uint32_t ordL;
+            unsigned long long m = latticeBatch(i0, ordL);
+#ifdef LFG_MOTION_STAMPS
+            stampBatches += 1u; stampEvals += (unsigned)__builtin_popcountll(m);
+#endif
+            if (m == 0ull) continue;
+            // The survivors, software-pipelined: the window reads of one are in flight while the previous one is
+            // finished; a last pass drains the pipeline.
+            bool pending = false;
+            uint32_t ordP = 0u, cntP = 0u;
+            while (m != 0ull || pending) {
+                const bool have = m != 0ull;
+                uint32_t ord = 0u, cntIt = 0u;
+                if (have) {
+                    const int b = __builtin_ctzll(m);
+                    m &= m - 1ull;
+                    ord = (uint32_t)__builtin_amdgcn_readlane((int)ordL, b);
+                    cntIt = (i0 + (b >> grpShift)) >= nHead ? 1u : 0u;
+                    fetchWindow(p, ord);
+                }
+                if (pending) rowSumsAndTest(x, ordP, cntP);
+                __builtin_amdgcn_sched_barrier(0);
+                if (have) {
+                    columnSums(p, v8);
+                    transpose(v8, x);
+                }
+                ordP = ord; cntP = cntIt; pending = have;
             }
-            ordE = ordN; ordN = ordNN; skipE = skipN;
-            if ((e & 15) == 15) {                                      // lists full somewhere in the tile: stop early
-                if (__builtin_amdgcn_readfirstlane(__ballot(listsOverflowed()) != 0ull)) sGiveUp = 1u;
-                if (__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)&sGiveUp) != 0) return true;   // keeps the loop uniform
-                refreshZeroBound();
-            }
+            // lists full somewhere in the tile: stop early
+            if (__builtin_amdgcn_readfirstlane(__ballot(listsOverflowed()) != 0ull)) sGiveUp = 1u;
+            if (__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)&sGiveUp) != 0) return true;
+            refreshZeroBound();
         }
         return __builtin_amdgcn_readfirstlane(__ballot(listsOverflowed()) != 0ull);
     };
     const bool gaveUp = run();
+#ifdef LFG_MOTION_STAMPS
+    if (lane == 0 && blockIdx.x < 8192) {
+        unsigned long long *o = gMotionStamps + ((size_t)blockIdx.x * 4 + seg) * 4;
+        o[0] = stampStart; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = stampEvals; o[3] = ((unsigned long long)borderTile << 32) | stampBatches;
+    }
+#endif
     if (gaveUp) {
         // Flags live on the exact kernel's 64 x 64 tile grid (cleared before this launch): this tile spans
         // one or two of its columns.  Racing writers all store 1.  Sibling waves that already finished have
@@ -773,6 +831,18 @@ __global__ __launch_bounds__(256) void motion_resolve_kernel(
         cnts = sp.auxCount + (unit0 * kPTH + (size_t)ly) * kPTW + (size_t)lx;
         listStride = (uint32_t)(kPTH * kListK * kPTW); recStride = kPTW; thrStride = (uint32_t)(kPTH * kPTW);
     }
+    // A recorded candidate whose block leaves prev stands for its whole plateau (block_leaves_prev): same exact
+    // cost, so the plateau's first member in tie order takes its place.
+    auto leaves = [&](int qx, int qy, uint32_t rank) {
+        const int scan = (int)rank2scan[rank];
+        return block_leaves_prev(qx, qy, scan % kSide - kR, scan / kSide - kR, W, H);
+    };
+    auto firstOfPlateau = [&](int qx, int qy, uint32_t rank) {
+        if (!leaves(qx, qy, rank)) return rank;
+        for (uint32_t r = 0; r < rank; ++r)
+            if (leaves(qx, qy, r)) return r;
+        return rank;
+    };
     float bound = __builtin_inff();        // thresholds are monotone: the tightest one holds for every list
     uint32_t survivors = 0u, bestC = 0u;
     if (live) {
@@ -840,11 +910,13 @@ __global__ __launch_bounds__(256) void motion_resolve_kernel(
 #pragma unroll
                 for (int i = 0; i < kB * kB; ++i) v += sDist[wv][i];
                 wave_lds_sync();
-                if (v < bestV || (v == bestV && rec.y < bestR)) { bestV = v; bestR = rec.y; }
+                const uint32_t r = firstOfPlateau(qx, qy, rec.y);
+                if (v < bestV || (v == bestV && r < bestR)) { bestV = v; bestR = r; }
             }
         }
         if (lane == L) bestC = bestR;
     }
+    if (live && survivors == 1u) bestC = firstOfPlateau(px, py, bestC);
     if (live) {
         const int bscan = (int)rank2scan[bestC];
         const int dyi = bscan / kSide, dxi = bscan - dyi * kSide;
@@ -887,25 +959,30 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, Motion
 
 // How the prefilter's tiles become work units for `slots` concurrently resident workgroups.
 //   * Tiles on the rim of the image (some block position outside it) often hold pixels without a good match -- the
-//     band a moving camera exposes -- so their partial-distortion test rarely fires and they run the full search,
-//     many times longer than an interior tile: they are dispatched first, so the short interior tiles fill in
-//     around them instead of waiting for them at the end.
-//   * A frame with fewer tiles than half the slots is split by candidates throughout (contiguous parts of the
-//     candidate order per unit, private lists, merged by the resolve kernel), to fill the chip.
+//     band a moving camera exposes, the rows and columns an upscaler filters differently at the edge -- so their
+//     partial-distortion test rarely fires and they run the full search, many times longer than an interior tile.
+//     Their units are dispatched first, so that the long ones start at once and the short ones fill in behind them.
+//   * A frame with fewer tiles than half the slots has every tile shared by up to 8 units (contiguous parts of the
+//     candidate order, private lists, merged by the resolve kernel), to fill the chip.
+#ifndef LFG_RIM_SPLIT
+#define LFG_RIM_SPLIT 1
+#endif
 PrefilterPlanHost prefilter_plan(uint32_t width, uint32_t height, int slots) {
+    constexpr int kRimSplit = LFG_RIM_SPLIT;
     PrefilterPlanHost p;
     const int W = (int)width, H = (int)height;
     p.tilesX = (W + kPTW - 1) / kPTW;
     const int tilesY = (H + kPTH - 1) / kPTH;
     p.tiles = p.tilesX * tilesY;
     p.tileMap.assign((size_t)p.tiles, 0xFFFFFFFFu);
-    const int n = (slots > 0 && p.tiles * 2 <= slots) ? std::max(2, std::min(8, slots / std::max(p.tiles, 1))) : 1;
+    const int everywhere = (slots > 0 && p.tiles * 2 <= slots) ? std::max(2, std::min(8, slots / std::max(p.tiles, 1))) : 1;
     for (int pass = 0; pass < 2; ++pass) {                 // pass 0: rim tiles, pass 1: interior tiles
         for (int t = 0; t < p.tiles; ++t) {
             const int ty = t / p.tilesX, tx = t - ty * p.tilesX;
             const int bx0 = tx * kPTW - kB / 2, by0 = ty * kPTH - kB / 2;
             const bool rim = !((bx0 >= 0) && (bx0 + kPTW + kB - 2 < W) && (by0 >= 0) && (by0 + kPTH + kB - 2 < H));
             if (rim != (pass == 0)) continue;
+            const int n = rim ? std::max(kRimSplit, everywhere) : everywhere;
             if (n == 1) { p.unitMap.push_back((uint32_t)t | (1u << 24)); p.unitAux.push_back(0xFFFFFFFFu); continue; }
             p.tileMap[(size_t)t] = (uint32_t)p.auxUnits | ((uint32_t)n << 24);
             for (int c = 0; c < n; ++c) {
@@ -1098,6 +1175,31 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
                        (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, order, sp);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
+#ifdef LFG_MOTION_STAMPS
+    {
+        static int calls = 0;
+        if (++calls == 3) {
+            std::vector<unsigned long long> h(8192 * 16);
+            hipStreamSynchronize(s);
+            hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(gMotionStamps), h.size() * 8);
+            const int n = std::min(sp.units, 8192);
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (int u = 0; u < n; ++u) for (int w = 0; w < 4; ++w) { if (!h[(u * 4 + w) * 4 + 1]) continue; t0 = std::min(t0, h[(u * 4 + w) * 4]); t1 = std::max(t1, h[(u * 4 + w) * 4 + 1]); }
+            double sum[2] = {0, 0}, mx[2] = {0, 0}, ev[2] = {0, 0}; int cnt[2] = {0, 0};
+            for (int u = 0; u < n; ++u) {
+                unsigned long long a = ~0ull, b = 0, evals = 0; int rim = 0;
+                for (int w = 0; w < 4; ++w) { const unsigned long long *o = &h[(u * 4 + w) * 4]; if (!o[1]) continue; a = std::min(a, o[0]); b = std::max(b, o[1]); evals += o[2]; rim = (int)(o[3] >> 32); }
+                if (!b) continue;
+                const double us = (double)(b - a) / 100.0;
+                sum[rim] += us; mx[rim] = std::max(mx[rim], us); ev[rim] += (double)evals / 4; ++cnt[rim];
+                if (u % 97 == 0 || us > 1200) fprintf(stderr, "unit %d rim %d start %.1f us dur %.1f us evals/wave %.1f\n", u, rim, (double)(a - t0) / 100.0, us, (double)evals / 4);
+            }
+            for (int r = 0; r < 2; ++r)
+                fprintf(stderr, "%s units %d: mean %.1f us, max %.1f us, evaluations per wave %.1f\n", r ? "rim" : "interior", cnt[r], sum[r] / std::max(cnt[r], 1), mx[r], ev[r] / std::max(cnt[r], 1));
+            fprintf(stderr, "span %.1f us\n", (double)(t1 - t0) / 100.0);
+        }
+    }
+#endif
     hipLaunchKernelGGL(motion_resolve_kernel, dim3((curr.width + 63) / 64, (curr.height + 3) / 4), dim3(256), 0, s,
                        (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
                        (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, sp, rank2scan);
