@@ -261,6 +261,12 @@ __global__ __launch_bounds__(256, 3) void scale_2x_kernel(
             const bool ok = odd ? (oy0 + 1 < outH) : (oy0 >= 0);
             const int voff = ok ? offLane - sub : kOobOffset;
             __builtin_amdgcn_raw_buffer_store_b128(q, rOut, voff, max(oy0, 0) * outPitch, kStoreAux);
+            // A buffer store of more than 8 bytes reads its data registers over several cycles after issue; a VALU
+            // write to them in the next slots wins the race (seen on gfx950 as the next row's unpacked float in
+            // the first pixel of lanes 12/14 mod 16, a few dozen pixels per 4K frame, not every run).  The
+            // compiler's hazard recogniser leaves the case "scalar register in the soffset field" out, so the
+            // wait states are spelled out here.
+            asm volatile("s_nop 3");
         }
         __builtin_amdgcn_sched_barrier(0);     // keep each step's registers local
     }

@@ -109,6 +109,30 @@ def test_scale_1080p_to_4k_roi(ctx, oracle):
         assert_within_1lsb(got[y0:y1, x0:x1], want[y0:y1, x0:x1])
 
 
+def test_scale_1080p_to_4k_every_pixel_repeated(ctx, oracle):
+    """Every pixel of the full-size output, on several runs and both frames of the benchmark pair: catches the rare,
+    timing-dependent faults a region check misses (a store-data hazard once left a few dozen pixels per frame holding
+    an unpacked float, on some runs only).  Also the property the motion stage leans on: an exact 2x upscale commutes
+    with integer translations away from the rim (up to the last bit: the filter weights come from per-column float
+    arithmetic)."""
+    prev, curr = synth.make_pair(1920, 1080, stream=0, shift=(3, -2))
+    ups = []
+    for src in (prev, curr):
+        want = oracle.scale(src, 3840, 2160)
+        s, d = ctx.frame_from(src), ctx.create_frame(3840, 2160)
+        for _ in range(4):
+            ctx.scale(s, d)
+            ctx.sync()
+            got = ctx.download(d)
+            assert_within_1lsb(got, want)
+        ups.append(got)
+        ctx.destroy_frame(s)
+        ctx.destroy_frame(d)
+    P, C = ups
+    d = np.abs(C[16:2160 - 16, 16:3840 - 16].astype(np.int16) - P[16 + 4:2160 - 16 + 4, 16 - 6:3840 - 16 - 6].astype(np.int16))
+    assert d.max() <= 1 and float((d != 0).mean()) < 1e-3
+
+
 # ------------------------------------------------------------------------------ motion
 
 def as_int(mv_f32):
