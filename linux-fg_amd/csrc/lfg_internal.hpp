@@ -26,11 +26,12 @@ struct AxisTable {
 
 struct MotionWorkspaceLayout { size_t list, umin, count, tileFlags, order, plan, auxList, auxUmin, auxCount, total; };
 // Work units of the motion prefilter (motion.hip: prefilter_plan).  A unit is a 56 x 64 tile, or one of nChunks
-// contiguous parts of a tile's candidate order with private lists in the aux arrays (merged by the resolve kernel).
+// contiguous parts of a tile's candidate order, or one 16-row segment of a tile with its four waves on four parts of
+// the order; parts have private lists in the aux arrays (merged by the resolve kernel).
 struct PrefilterPlan {               // passed by value to the kernels
     int tilesX, units;
-    const uint32_t *unitMap;         // per unit: tile | chunk << 20 | nChunks << 24
-    const uint32_t *unitAux;         // per unit: index of its 56 x 64 block in the aux arrays (whole tiles: 0xFFFFFFFF)
+    const uint32_t *unitMap;         // per unit: tile | (first) chunk << 20 | nChunks << 24 | segment unit << 28 | segment << 29
+    const uint32_t *unitAux;         // per unit: index of its tile's first 56 x 64 block in the aux arrays (whole tiles: 0xFFFFFFFF)
     const uint32_t *tileMap;         // per tile: 0xFFFFFFFF (whole) or first aux index | nChunks << 24
     uint2 *auxList;
     float *auxUmin;

@@ -339,7 +339,7 @@ typedef const __attribute__((address_space(3))) uint32_t *lds_ro_u32_ptr;
 typedef const __attribute__((address_space(3))) float *lds_ro_f32_ptr;
 
 #ifdef LFG_MOTION_STAMPS   // diagnostic build (tools/build_variant.sh stamps -DLFG_MOTION_STAMPS): per-wave timing and counts
-__device__ unsigned long long gMotionStamps[8192 * 4 * 4];
+__device__ unsigned long long gMotionStamps[8192 * 4 * 8];
 #endif
 
 // order32[e] = the candidate's rank in the tie order (motion_tables) in the low half, its window offset
@@ -351,21 +351,29 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     const uint32_t *__restrict__ order32, PrefilterPlan sp) {
     __shared__ uint32_t sWin[kWinH * kWinW];                           // 38.2 KB packed RGBA8 search window
     __shared__ __attribute__((aligned(8))) float sSlab[kPNT / 64][4 * kSlabP];      // 4 x 2.1 KB
-    __shared__ uint32_t sOrder[kCand + 7];                             // this unit's part of the visiting order
+    __shared__ uint32_t sOrder[kCand + 7];                             // the visiting order
     __shared__ uint32_t sGiveUp;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int seg = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave index 0..3
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         // wave index 0..3
 #ifdef LFG_MOTION_STAMPS
     const unsigned long long stampStart = __builtin_amdgcn_s_memrealtime();
     unsigned stampEvals = 0u, stampBatches = 0u;
+    unsigned long long stampStaged = 0ull, stampFirst = 0ull;
 #endif
-    // Work units (PrefilterPlan): a whole tile, or one of nChunks contiguous parts of a tile's candidate order
-    // with private lists.
+    // Work units (PrefilterPlan).  A tile is 4 segments of 16 rows, and a workgroup is either
+    //   * a whole tile: wave = segment, the entire candidate order;
+    //   * one of nChunks contiguous parts of a tile's candidate order: wave = segment, private lists;
+    //   * one segment of a tile: wave = one of 4 consecutive parts of the order (of nChunks), private lists --
+    //     for tiles whose segments differ widely in cost, so that the waves of a workgroup finish together.
+    // `seg` is the segment this wave works on, `wave` its place in the workgroup (its slab).
     const int unit = blockIdx.x;
     const uint32_t um = sp.unitMap[unit];
-    const int tile = (int)(um & 0xFFFFFu), chunk = (int)((um >> 20) & 0xFu), nChunks = (int)(um >> 24);
+    const bool segUnit = ((um >> 28) & 1u) != 0u;
+    const int tile = (int)(um & 0xFFFFFu), nChunks = (int)((um >> 24) & 0xFu);
+    const int seg = segUnit ? (int)((um >> 29) & 3u) : wave;
+    const int chunk = (int)((um >> 20) & 0xFu) + (segUnit ? wave : 0);
     const bool whole = nChunks == 1;
     const int perChunk = (kCand + nChunks - 1) / nChunks;
     const int eBegin = chunk * perChunk, eEnd = min(kCand, eBegin + perChunk);
@@ -376,19 +384,37 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     // A unit that shares its tile first runs the head of the order -- zero motion and the first hints -- for the
     // thresholds only (not recorded: the unit that owns those entries records them).  Without it a unit whose part
     // of the order holds no good candidate starts from nothing and records far more than it needs to.
-    constexpr int kHead = 16;
+#ifndef LFG_HEAD
+#define LFG_HEAD 8
+#endif
+    constexpr int kHead = LFG_HEAD;
     const int nHead = chunk > 0 ? kHead : 0;
-    const int eFirst = eBegin - nHead;
-    for (int i = tid; i < eEnd - eFirst; i += kPNT) sOrder[i] = order32[i < nHead ? i : eBegin + (i - nHead)];
+    for (int i = tid; i < kCand; i += kPNT) sOrder[i] = order32[i];
 
     // ---- search window: prev(bx0 - R + wx, by0 - R + wy), zero outside the image (texelFetch semantics)
-    for (int i = tid; i < kWinH * kWinW; i += kPNT) {
-        const int wy = i / kWinW, wx = i - wy * kWinW;                 // global reads stay row-major (coalesced)
-        const int gx = bx0 - kR + wx, gy = by0 - kR + wy;
-        uint32_t v = 0u;
-        if (gx >= 0 && gx < W && gy >= 0 && gy < H)
-            v = *reinterpret_cast<const uint32_t *>(prev + (size_t)gy * (size_t)prevPitch + (size_t)gx * 4u);
-        sWin[wx * kWinH + wy] = v;
+    // (ten loads in flight per thread: one at a time, the 39 rounds cost 39 memory latencies; a segment unit
+    //  stages its own 55 rows only)
+    constexpr int kStageAhead = 10;
+    const int stageRow0 = segUnit ? kSeg * seg : 0;
+    const int stageTexels = (segUnit ? kSegD + 2 * kR : kWinH) * kWinW;
+    for (int r0 = 0; r0 * kPNT < stageTexels; r0 += kStageAhead) {
+        uint32_t v[kStageAhead];
+#pragma unroll
+        for (int k = 0; k < kStageAhead; ++k) {
+            const int i = (r0 + k) * kPNT + tid;
+            const int wy = stageRow0 + i / kWinW, wx = i % kWinW;      // global reads stay row-major (coalesced)
+            const int gx = bx0 - kR + wx, gy = by0 - kR + wy;
+            // branch-free: the load goes to the nearest texel inside the image and is dropped afterwards
+            const uint32_t t = *reinterpret_cast<const uint32_t *>(prev + (size_t)clampi(gy, 0, H - 1) * (size_t)prevPitch +
+                                                                   (size_t)clampi(gx, 0, W - 1) * 4u);
+            v[k] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? t : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < kStageAhead; ++k) {
+            const int i = (r0 + k) * kPNT + tid;
+            const int wy = stageRow0 + i / kWinW, wx = i % kWinW;
+            if (i < stageTexels) sWin[wx * kWinH + wy] = v[k];
+        }
     }
 
     // ---- this thread's 23 block positions (column bx0 + lane, rows by0 + 16 seg + j)
@@ -410,6 +436,9 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
         !((bx0 >= 0) && (bx0 + kPTW + kB - 2 < W) && (by0 >= 0) && (by0 + kPTH + kB - 2 < H)));
 
     __syncthreads();                       // window staged; the only workgroup barrier
+#ifdef LFG_MOTION_STAMPS
+    stampStaged = __builtin_amdgcn_s_memrealtime();
+#endif
     if (ty0 + kSeg * seg >= H) return;     // this wave's rows lie below the image
 
     // (lane 63 has no position column: it re-reads lane 62's texels, its sums are never used)
@@ -471,8 +500,8 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     // ---- row sums: rows r8 and r8 + 8 of the wave's 16, pixels tx0 + 7 q .. + 6
     const int r8 = lane & 7, q = lane >> 3;
     const int px0 = tx0 + kRun * q;
-    f32x2 *const slabW = reinterpret_cast<f32x2 *>(sSlab[seg]) + lane;               // write: rows (2a, 2a+1), column lane
-    const lds_ro_f32_ptr slabR = (lds_ro_f32_ptr)(sSlab[seg] + (r8 >> 1) * kSlabP + 2 * kRun * q + (r8 & 1));
+    f32x2 *const slabW = reinterpret_cast<f32x2 *>(sSlab[wave]) + lane;               // write: rows (2a, 2a+1), column lane
+    const lds_ro_f32_ptr slabR = (lds_ro_f32_ptr)(sSlab[wave] + (r8 >> 1) * kSlabP + 2 * kRun * q + (r8 & 1));
     f32x2 thr2[kRun];                     // (row r8, row r8 + 8): kRatio * (smallest S~ so far); a candidate survives
                                           // while S~ <= thr
     uint32_t cnt2[2][(kRun + 1) / 2];                                  // 16-bit counters (1089 events at most)
@@ -481,7 +510,7 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     // Address = wave-uniform base + 32-bit lane offset; k * W is a 24-bit multiply.
     // Whole tiles write into the image-shaped arrays (row stride W), shared tiles into their unit's private
     // 56 x 64 block of the auxiliary arrays (row stride 56).
-    const int auxUnit = whole ? 0 : (int)sp.unitAux[unit];
+    const int auxUnit = whole ? 0 : (int)sp.unitAux[unit] + chunk;     // unitAux: the tile's first auxiliary block
     const uint32_t rowStride = whole ? (uint32_t)W : (uint32_t)kPTW;
     uint2 *const waveList = whole
         ? list + ((size_t)(ty0 + kSeg * seg) * (size_t)kListK * (size_t)W + (size_t)tx0)
@@ -631,6 +660,7 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
             for (int off = 32; off > 0; off >>= 1) k = max(k, (uint32_t)__shfl_xor((int)k, off));
             k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
             zeroBound = k < 0x00800000u + (uint32_t)kCand ? (k >= 0x00800000u ? k - 0x00800000u : 0u) : 0xFFFFFFFFu;
+            zeroBound = (uint32_t)__builtin_amdgcn_readfirstlane((int)zeroBound);
             waveThr = __builtin_bit_cast(float, k);                    // largest threshold of the wave's pixels (+inf: none yet)
         };
         // Partial-distortion test.  S~ is a sum of non-negative distances, and a rounded fp32 sum of non-negative
@@ -642,57 +672,66 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
         //   border tiles:   rows 4|8|12|16, columns = 0 mod 4 in 4..56 -- the point (4*floor(x/4), 4*floor(y/4)) of
         //                   pixel (x, y) lies in its block and inside the image whenever the pixel does, so
         //                   positions outside the image are simply left out; 4 x 14 points.
-        // A wave tests a BATCH of candidates at once: lane = (lattice column, candidate), 8 lanes per candidate and
-        // 8 candidates on interior tiles, 16 and 4 on border tiles.  A lane fetches its candidate's entry of the
-        // order from LDS, the texels of its column from the window and the current-frame texels of that column from
-        // the lane that owns them (ds_bpermute); one ballot gives the candidates that survive.  The thresholds a
-        // batch is tested against may be one batch old -- larger, so the test only gets weaker.
-        const int nEntries = eEnd - eFirst;
+        // A wave tests a BATCH of up to 64 candidates at once, one per lane: the lane fetches its candidate's entry of
+        // the order from LDS and walks the lattice -- per point one texel of the window (the candidate's offset, the
+        // point's position as an immediate), the current-frame texel of the point from the lane that owns it
+        // (v_readlane: wave-uniform), one distance, one running minimum.  All chains are independent, so the batch
+        // runs at issue rate, and one ballot gives the candidates that survive.  The thresholds a batch is tested
+        // against are those at its start; the first two batches are short (zero motion and the first hint, then six
+        // more) so that the long ones start with thresholds worth testing against.
+#ifdef LFG_DBG_MAXENTRIES          // timing experiments only (wrong results): visit the first entries of the order only
+        const int nEntries = min(nHead + eEnd - eBegin, LFG_DBG_MAXENTRIES);
+#else
+        const int nEntries = nHead + eEnd - eBegin;                    // the head, then this wave's part of the order
+#endif
         int border = borderTile;
         asm volatile("" : "+s"(border));   // one copy of the loop below, not one per kind of tile
-        const int grpShift = border ? 4 : 3;
-        const int perBatch = 64 >> grpShift;
-        const int ci = lane & ((1 << grpShift) - 1);
-        const int latCol = border ? 4 + 4 * ci : 3 + 8 * ci;           // border: ci = 14, 15 have no column
-        const int kSub = (border && ci >= 14) ? 2 * kCand : (lane >> grpShift);
-        const int latColC = min(latCol, kPTW + kB - 2);
-        const lds_ro_u32_ptr latBase = (lds_ro_u32_ptr)(sWin + latColC * kWinH + kSeg * seg);
         auto distanceOf = [&](uint32_t cT, uint32_t texel) {           // same arithmetic as columnSums
             const uint32_t ccT = __builtin_amdgcn_udot4(cT, cT, 0x4B000000u, false);
             const float f1 = __builtin_bit_cast(float, __builtin_amdgcn_udot4(texel, texel, ccT, false));
             const float f2 = __builtin_bit_cast(float, __builtin_amdgcn_udot4(cT, texel, 0x4B800000u, false));
             return __builtin_amdgcn_sqrtf((f1 - f2) + 8388608.0f);
         };
-        auto fromColumn = [&](uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute(latColC * 4, (int)v); };
-        // bit (k << grpShift) of the result: candidate i0 + k of the staged order has to be evaluated in full
-        auto latticeBatch = [&](int i0, uint32_t &ordL) -> unsigned long long {
-            const int idx = i0 + kSub;
-            ordL = ((lds_ro_u32_ptr)sOrder)[min(idx, nEntries - 1)];
-            bool need = idx < nEntries && (ordL & 0xFFFFu) < zeroBound;
+        // bit k of the result: candidate i0 + k of the staged order has to be evaluated in full
+        auto latticeBatch = [&](int i0, int count, uint32_t &ordL) -> unsigned long long {
+            uint32_t l;                    // lane number; volatile, so that it is not hoisted out of the loop and spilled
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(l));
+            const int idx = i0 + (int)l;
+            ordL = ((lds_ro_u32_ptr)sOrder)[min(idx < nHead ? idx : eBegin + (idx - nHead), kCand - 1)];
+            bool need = (int)l < count && idx < nEntries && (ordL & 0xFFFFu) < zeroBound;
             if (waveThr < 510.0f) {                                    // a distance is at most sqrt(4 * 255^2) = 510
-                const lds_ro_u32_ptr w = latBase + (ordL >> 16);
-                bool allAbove = true;      // every lattice distance of this lane exceeds waveThr
+                const lds_ro_u32_ptr w = (lds_ro_u32_ptr)(sWin + kSeg * seg) + (ordL >> 16);
+                // the candidate's smallest lattice distance, as bits: distances are non-negative floats, whose
+                // order is the order of their bit patterns (one v_min_u32 per point, no NaN handling)
+                uint32_t dMin = 0x7F800000u;
+                auto bitsOf = [](float d) { return __builtin_bit_cast(uint32_t, d); };
                 if (border) {
-                    const uint32_t vL = fromColumn(valid);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const float d = distanceOf(fromColumn(c[4 + 4 * t]), w[4 + 4 * t]);
-                        allAbove = allAbove && (((vL >> (4 + 4 * t)) & 1u) == 0u || d > waveThr);
+                    for (int col = 4; col <= kPTW; col += 4) {
+                        const uint32_t inImage = (uint32_t)__builtin_amdgcn_readlane((int)valid, col);
+#pragma unroll
+                        for (int row = 4; row <= 16; row += 4) {
+                            // a point outside the image is no point: its distance becomes "at least infinity"
+                            // (scalar mask, no branch)
+                            const uint32_t drop = (((inImage >> row) & 1u) - 1u) & 0x7F800000u;
+                            dMin = min(dMin, bitsOf(distanceOf((uint32_t)__builtin_amdgcn_readlane((int)c[row], col), w[col * kWinH + row])) | drop);
+                        }
                     }
                 } else {
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) allAbove = allAbove && distanceOf(fromColumn(c[3 + 8 * t]), w[3 + 8 * t]) > waveThr;
+                    for (int col = 3; col < kPTW + kB - 1; col += 8) {
+#pragma unroll
+                        for (int row = 3; row < kSegD; row += 8)
+                            dMin = min(dMin, bitsOf(distanceOf((uint32_t)__builtin_amdgcn_readlane((int)c[row], col), w[col * kWinH + row])));
+                    }
                 }
-                need = need && !allAbove;
+                need = need & !(dMin > __builtin_bit_cast(uint32_t, waveThr));
             }
-            unsigned long long m = __ballot(need);
-            m |= m >> 1; m |= m >> 2; m |= m >> 4;
-            if (border) m |= m >> 8;
-            return m & (border ? 0x0001000100010001ull : 0x0101010101010101ull);
+            return __ballot(need);
         };
-        for (int i0 = 0; i0 < nEntries; i0 += perBatch) {
+        for (int i0 = 0, count = 2; i0 < nEntries; i0 += count, count = i0 == 2 ? 6 : 64) {
             uint32_t ordL;
-            unsigned long long m = latticeBatch(i0, ordL);
+            unsigned long long m = latticeBatch(i0, count, ordL);
 #ifdef LFG_MOTION_STAMPS
             stampBatches += 1u; stampEvals += (unsigned)__builtin_popcountll(m);
 #endif
@@ -708,7 +747,7 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
                     const int b = __builtin_ctzll(m);
                     m &= m - 1ull;
                     ord = (uint32_t)__builtin_amdgcn_readlane((int)ordL, b);
-                    cntIt = (i0 + (b >> grpShift)) >= nHead ? 1u : 0u;
+                    cntIt = (i0 + b) >= nHead ? 1u : 0u;
                     fetchWindow(p, ord);
                 }
                 if (pending) rowSumsAndTest(x, ordP, cntP);
@@ -723,14 +762,18 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
             if (__builtin_amdgcn_readfirstlane(__ballot(listsOverflowed()) != 0ull)) sGiveUp = 1u;
             if (__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)&sGiveUp) != 0) return true;
             refreshZeroBound();
+#ifdef LFG_MOTION_STAMPS
+            if (i0 == 0) stampFirst = __builtin_amdgcn_s_memrealtime();
+#endif
         }
         return __builtin_amdgcn_readfirstlane(__ballot(listsOverflowed()) != 0ull);
     };
     const bool gaveUp = run();
 #ifdef LFG_MOTION_STAMPS
     if (lane == 0 && blockIdx.x < 8192) {
-        unsigned long long *o = gMotionStamps + ((size_t)blockIdx.x * 4 + seg) * 4;
+        unsigned long long *o = gMotionStamps + ((size_t)blockIdx.x * 4 + wave) * 8;
         o[0] = stampStart; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = stampEvals; o[3] = ((unsigned long long)borderTile << 32) | stampBatches;
+        o[4] = stampStaged; o[5] = stampFirst;
     }
 #endif
     if (gaveUp) {
@@ -957,18 +1000,23 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, Motion
     return l.total;
 }
 
-// How the prefilter's tiles become work units for `slots` concurrently resident workgroups.
-//   * Tiles on the rim of the image (some block position outside it) often hold pixels without a good match -- the
-//     band a moving camera exposes, the rows and columns an upscaler filters differently at the edge -- so their
-//     partial-distortion test rarely fires and they run the full search, many times longer than an interior tile.
-//     Their units are dispatched first, so that the long ones start at once and the short ones fill in behind them.
+// How the prefilter's tiles become work units for `slots` concurrently resident workgroups (unitMap entry:
+// tile | first chunk << 20 | chunks << 24 | segment unit << 28 | segment << 29).
+//   * Tiles on the rim of the image (some block position outside it) hold pixels without a good match -- the band a
+//     moving camera exposes, the rows and columns an upscaler filters differently at the edge -- and the segments
+//     that contain them run the full search, hundreds of times the work of a segment in which the partial-distortion
+//     test fires.  A rim tile therefore becomes one unit per SEGMENT, whose four waves take a quarter of the
+//     candidate order each (private lists, merged by the resolve kernel): the waves of a workgroup finish together
+//     whether their segment is a cheap or an expensive one.  These units are dispatched first, so that the long
+//     ones start at once and the short ones fill in behind them.
 //   * A frame with fewer tiles than half the slots has every tile shared by up to 8 units (contiguous parts of the
-//     candidate order, private lists, merged by the resolve kernel), to fill the chip.
+//     candidate order, private lists), to fill the chip.
 #ifndef LFG_RIM_SPLIT
-#define LFG_RIM_SPLIT 1
+#define LFG_RIM_SPLIT 4
 #endif
 PrefilterPlanHost prefilter_plan(uint32_t width, uint32_t height, int slots) {
-    constexpr int kRimSplit = LFG_RIM_SPLIT;
+    constexpr int kRimSplit = LFG_RIM_SPLIT;          // 4 or 8 parts of the order per rim segment; 1: rim tiles whole
+    static_assert(kRimSplit == 1 || kRimSplit == 4 || kRimSplit == 8, "a segment unit's four waves take one part each");
     PrefilterPlanHost p;
     const int W = (int)width, H = (int)height;
     p.tilesX = (W + kPTW - 1) / kPTW;
@@ -982,12 +1030,24 @@ PrefilterPlanHost prefilter_plan(uint32_t width, uint32_t height, int slots) {
             const int bx0 = tx * kPTW - kB / 2, by0 = ty * kPTH - kB / 2;
             const bool rim = !((bx0 >= 0) && (bx0 + kPTW + kB - 2 < W) && (by0 >= 0) && (by0 + kPTH + kB - 2 < H));
             if (rim != (pass == 0)) continue;
-            const int n = rim ? std::max(kRimSplit, everywhere) : everywhere;
+            const bool bySegment = rim && everywhere == 1 && kRimSplit > 1;
+            const int n = bySegment ? kRimSplit : everywhere;
             if (n == 1) { p.unitMap.push_back((uint32_t)t | (1u << 24)); p.unitAux.push_back(0xFFFFFFFFu); continue; }
-            p.tileMap[(size_t)t] = (uint32_t)p.auxUnits | ((uint32_t)n << 24);
-            for (int c = 0; c < n; ++c) {
-                p.unitMap.push_back((uint32_t)t | ((uint32_t)c << 20) | ((uint32_t)n << 24));
-                p.unitAux.push_back((uint32_t)p.auxUnits++);
+            const uint32_t aux0 = (uint32_t)p.auxUnits;
+            p.tileMap[(size_t)t] = aux0 | ((uint32_t)n << 24);
+            p.auxUnits += n;
+            if (bySegment) {
+                for (int seg = 0; seg < kPTH / kSeg && ty * kPTH + seg * kSeg < H; ++seg) {
+                    for (int c0 = 0; c0 < n; c0 += 4) {
+                        p.unitMap.push_back((uint32_t)t | ((uint32_t)c0 << 20) | ((uint32_t)n << 24) | (1u << 28) | ((uint32_t)seg << 29));
+                        p.unitAux.push_back(aux0);
+                    }
+                }
+            } else {
+                for (int c = 0; c < n; ++c) {
+                    p.unitMap.push_back((uint32_t)t | ((uint32_t)c << 20) | ((uint32_t)n << 24));
+                    p.unitAux.push_back(aux0);
+                }
             }
         }
     }
@@ -1179,23 +1239,25 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
     {
         static int calls = 0;
         if (++calls == 3) {
-            std::vector<unsigned long long> h(8192 * 16);
+            std::vector<unsigned long long> h(8192 * 32);
             hipStreamSynchronize(s);
             hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(gMotionStamps), h.size() * 8);
             const int n = std::min(sp.units, 8192);
             unsigned long long t0 = ~0ull, t1 = 0;
-            for (int u = 0; u < n; ++u) for (int w = 0; w < 4; ++w) { if (!h[(u * 4 + w) * 4 + 1]) continue; t0 = std::min(t0, h[(u * 4 + w) * 4]); t1 = std::max(t1, h[(u * 4 + w) * 4 + 1]); }
-            double sum[2] = {0, 0}, mx[2] = {0, 0}, ev[2] = {0, 0}; int cnt[2] = {0, 0};
+            for (int u = 0; u < n; ++u) for (int w = 0; w < 4; ++w) { const unsigned long long *o = &h[(u * 4 + w) * 8]; if (!o[1]) continue; t0 = std::min(t0, o[0]); t1 = std::max(t1, o[1]); }
+            double sum[2] = {0, 0}, mx[2] = {0, 0}, ev[2] = {0, 0}, stg[2] = {0, 0}, fst[2] = {0, 0}; int cnt[2] = {0, 0};
             for (int u = 0; u < n; ++u) {
-                unsigned long long a = ~0ull, b = 0, evals = 0; int rim = 0;
-                for (int w = 0; w < 4; ++w) { const unsigned long long *o = &h[(u * 4 + w) * 4]; if (!o[1]) continue; a = std::min(a, o[0]); b = std::max(b, o[1]); evals += o[2]; rim = (int)(o[3] >> 32); }
+                unsigned long long a = ~0ull, b = 0, evals = 0; int rim = 0; double st = 0, fs = 0;
+                for (int w = 0; w < 4; ++w) { const unsigned long long *o = &h[(u * 4 + w) * 8]; if (!o[1]) continue; a = std::min(a, o[0]); b = std::max(b, o[1]); evals += o[2]; rim = (int)(o[3] >> 32);
+                    st = std::max(st, (double)(o[4] - o[0]) / 100.0); if (o[5]) fs = std::max(fs, (double)(o[5] - o[4]) / 100.0); }
                 if (!b) continue;
                 const double us = (double)(b - a) / 100.0;
-                sum[rim] += us; mx[rim] = std::max(mx[rim], us); ev[rim] += (double)evals / 4; ++cnt[rim];
-                if (u % 97 == 0 || us > 1200) fprintf(stderr, "unit %d rim %d start %.1f us dur %.1f us evals/wave %.1f\n", u, rim, (double)(a - t0) / 100.0, us, (double)evals / 4);
+                sum[rim] += us; mx[rim] = std::max(mx[rim], us); ev[rim] += (double)evals / 4; stg[rim] += st; fst[rim] += fs; ++cnt[rim];
+                if (u % 197 == 0) fprintf(stderr, "unit %d rim %d start %.1f us dur %.1f us evals/wave %.1f\n", u, rim, (double)(a - t0) / 100.0, us, (double)evals / 4);
             }
             for (int r = 0; r < 2; ++r)
-                fprintf(stderr, "%s units %d: mean %.1f us, max %.1f us, evaluations per wave %.1f\n", r ? "rim" : "interior", cnt[r], sum[r] / std::max(cnt[r], 1), mx[r], ev[r] / std::max(cnt[r], 1));
+                fprintf(stderr, "%s units %d: mean %.1f us (staging %.1f, first batch %.1f), max %.1f us, evaluations per wave %.1f\n", r ? "rim" : "interior", cnt[r],
+                        sum[r] / std::max(cnt[r], 1), stg[r] / std::max(cnt[r], 1), fst[r] / std::max(cnt[r], 1), mx[r], ev[r] / std::max(cnt[r], 1));
             fprintf(stderr, "span %.1f us\n", (double)(t1 - t0) / 100.0);
         }
     }
