@@ -127,7 +127,10 @@ int ensure_motion_tables(lfg_context *ctx) {
 int ensure_motion_workspace(lfg_context *ctx, uint32_t width, uint32_t height) {
     if (ctx->motion_ws && ctx->motion_ws_w == width && ctx->motion_ws_h == height) return LFG_OK;
     lfg::MotionWorkspaceLayout layout;
-    if (ctx->motion_slots == 0) ctx->motion_slots = lfg::prefilter_slots();
+    if (ctx->motion_slots == 0) {
+        ctx->motion_slots = lfg::prefilter_slots();
+        if (getenv("LFG_DEBUG")) fprintf(stderr, "lfg: motion prefilter: %d workgroups resident at once\n", ctx->motion_slots);
+    }
     const size_t bytes = lfg::motion_workspace_bytes(width, height, ctx->motion_slots, &layout);
     if (bytes > ctx->motion_ws_bytes) {
         LFG_HIP(ctx, hipStreamSynchronize(ctx->stream));          // a queued kernel may still use the old one

@@ -435,6 +435,10 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     const int borderTile = __builtin_amdgcn_readfirstlane(
         !((bx0 >= 0) && (bx0 + kPTW + kB - 2 < W) && (by0 >= 0) && (by0 + kPTH + kB - 2 < H)));
 
+    // Some candidate's block can leave prev altogether only if the search window does.
+    const int windowLeavesPrev = __builtin_amdgcn_readfirstlane(
+        !((bx0 - kR >= 0) && (bx0 + kPTW + kB - 2 + kR < W) && (by0 - kR >= 0) && (by0 + kPTH + kB - 2 + kR < H)));
+
     __syncthreads();                       // window staged; the only workgroup barrier
 #ifdef LFG_MOTION_STAMPS
     stampStaged = __builtin_amdgcn_s_memrealtime();
@@ -604,12 +608,15 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
                         // flags the tile
                         const uint32_t at = __umul24(min(n, (uint32_t)kListK - 1u), rowStride) + laneOff[hb] + (uint32_t)i;
                         waveList[at] = uint2{__builtin_bit_cast(uint32_t, s), cand};
-                        // one member per plateau (block_leaves_prev): a second one is written but not counted
-                        const uint32_t bit = 1u << (kRun * hb + i);
-                        const bool plateau = block_leaves_prev(px0 + i, ty0 + kSeg * seg + 8 * hb + r8, candDx, candDy, W, H);
-                        const bool counted = s != 0.0f && countIt != 0u && !(plateau && (plateauSeen & bit) != 0u);
-                        cnt2[hb][i >> 1] += counted ? (1u << (16 * (i & 1))) : 0u;
-                        plateauSeen |= (plateau && counted) ? bit : 0u;
+                        uint32_t inc = (s != 0.0f && countIt != 0u) ? (1u << (16 * (i & 1))) : 0u;
+                        if (windowLeavesPrev) {                        // wave-uniform: tiles away from the rim skip this
+                            // one member per plateau (block_leaves_prev): a second one is written but not counted
+                            const uint32_t bit = 1u << (kRun * hb + i);
+                            const bool plateau = block_leaves_prev(px0 + i, ty0 + kSeg * seg + 8 * hb + r8, candDx, candDy, W, H);
+                            inc = (plateau && (plateauSeen & bit) != 0u) ? 0u : inc;
+                            plateauSeen |= (plateau && inc != 0u) ? bit : 0u;
+                        }
+                        cnt2[hb][i >> 1] += inc;
                     }
                 }
             }

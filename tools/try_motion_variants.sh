@@ -10,8 +10,12 @@ sys.path.insert(0, '$R')
 from linux_fg_amd import capi, synth
 ctx = capi.Context(0)
 W, H = 3840, 2160
-# the benchmark's frames: a translated 1080p pair, both upscaled on the device
-pin = synth.make_prev(W // 2, H // 2, seed=synth.BASE_SEED); cin = synth.translate(pin, (3, -2), synth.BASE_SEED)
+# the benchmark's frames: a translated 1080p pair, both upscaled on the device (CONTENT=uncorrelated: two noise frames)
+import os
+if os.environ.get('CONTENT') == 'uncorrelated':
+    pin, cin = synth.make_uncorrelated_pair(W // 2, H // 2)
+else:
+    pin = synth.make_prev(W // 2, H // 2, seed=synth.BASE_SEED); cin = synth.translate(pin, (3, -2), synth.BASE_SEED)
 Pin, Cin = ctx.frame_from(pin), ctx.frame_from(cin)
 P, C = ctx.create_frame(W, H), ctx.create_frame(W, H); M = ctx.create_frame(W, H, capi.FORMAT_MV_S8X2)
 ctx.scale(Pin, P); ctx.scale(Cin, C)
