@@ -24,7 +24,7 @@ struct AxisTable {
     float *d_weight = nullptr;    // [out_size][6]
 };
 
-struct MotionWorkspaceLayout { size_t list, umin, count, tileFlags, order, plan, auxList, auxUmin, auxCount, total; };
+struct MotionWorkspaceLayout { size_t list, umin, count, tileFlags, segDone, order, plan, auxList, auxUmin, auxCount, total; };
 // Work units of the motion prefilter (motion.hip: prefilter_plan).  A unit is a 56 x 64 tile, or one of nChunks
 // contiguous parts of a tile's candidate order, or one 16-row segment of a tile with its four waves on four parts of
 // the order; parts have private lists in the aux arrays (merged by the resolve kernel).

@@ -340,6 +340,7 @@ typedef const __attribute__((address_space(3))) float *lds_ro_f32_ptr;
 
 #ifdef LFG_MOTION_STAMPS   // diagnostic build (tools/build_variant.sh stamps -DLFG_MOTION_STAMPS): per-wave timing and counts
 __device__ unsigned long long gMotionStamps[8192 * 4 * 8];
+__device__ unsigned long long gResolveStats[4];
 #endif
 
 // order32[e] = the candidate's rank in the tie order (motion_tables) in the low half, its window offset
@@ -348,7 +349,8 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int W, int H, uint2 *__restrict__ list, float *__restrict__ uminOut,
     uint32_t *__restrict__ countOut, uint32_t *__restrict__ tileFlags, int flagTilesX,
-    const uint32_t *__restrict__ order32, PrefilterPlan sp) {
+    const uint32_t *__restrict__ order32, PrefilterPlan sp,
+    int8_t *__restrict__ mv, int mvPitch, const uint32_t *__restrict__ rank2scan, uint32_t *__restrict__ segDone) {
     __shared__ uint32_t sWin[kWinH * kWinW];                           // 38.2 KB packed RGBA8 search window
     __shared__ __attribute__((aligned(8))) float sSlab[kPNT / 64][4 * kSlabP];      // 4 x 2.1 KB
     __shared__ uint32_t sOrder[kCand + 7];                             // the visiting order
@@ -392,9 +394,9 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
     for (int i = tid; i < kCand; i += kPNT) sOrder[i] = order32[i];
 
     // ---- search window: prev(bx0 - R + wx, by0 - R + wy), zero outside the image (texelFetch semantics)
-    // (ten loads in flight per thread: one at a time, the 39 rounds cost 39 memory latencies; a segment unit
+    // (thirteen loads in flight per thread: one at a time, the 39 rounds cost 39 memory latencies; a segment unit
     //  stages its own 55 rows only)
-    constexpr int kStageAhead = 10;
+    constexpr int kStageAhead = 13;
     const int stageRow0 = segUnit ? kSeg * seg : 0;
     const int stageTexels = (segUnit ? kSegD + 2 * kR : kWinH) * kWinW;
     for (int r0 = 0; r0 * kPNT < stageTexels; r0 += kStageAhead) {
@@ -725,11 +727,18 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
                         }
                     }
                 } else {
+                    uint32_t tex[8][3];    // all 24 texel reads in flight at once: one LDS round trip, not 24
 #pragma unroll
-                    for (int col = 3; col < kPTW + kB - 1; col += 8) {
+                    for (int ci = 0; ci < 8; ++ci) {
 #pragma unroll
-                        for (int row = 3; row < kSegD; row += 8)
-                            dMin = min(dMin, bitsOf(distanceOf((uint32_t)__builtin_amdgcn_readlane((int)c[row], col), w[col * kWinH + row])));
+                        for (int t = 0; t < 3; ++t) tex[ci][t] = w[(3 + 8 * ci) * kWinH + 3 + 8 * t];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ci = 0; ci < 8; ++ci) {
+#pragma unroll
+                        for (int t = 0; t < 3; ++t)
+                            dMin = min(dMin, bitsOf(distanceOf((uint32_t)__builtin_amdgcn_readlane((int)c[3 + 8 * t], 3 + 8 * ci), tex[ci][t])));
                     }
                 }
                 need = need & !(dMin > __builtin_bit_cast(uint32_t, waveThr));
@@ -814,6 +823,56 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
             }
         }
     }
+    // Whole tiles away from the rim settle their easy pixels here and now, while threshold and count are still in
+    // registers: a zero-cost candidate (encoded in the threshold), a single record, or two records of which one
+    // survives ARE the answer (motion_resolve_kernel's rules; no plateaus where the window stays inside prev).
+    // A segment whose pixels were all settled says so, and the resolve kernel skips the blocks it covers.
+    if (whole && !windowLeavesPrev) {
+        uint2 ra[2][kRun], rb[2][kRun];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+            for (int i = 0; i < kRun; ++i) {           // (beyond the count: stale records, read but not used)
+                ra[hb][i] = waveList[laneOff[hb] + (uint32_t)i];
+                rb[hb][i] = waveList[rowStride + laneOff[hb] + (uint32_t)i];
+            }
+        }
+        uint32_t best[2][kRun];
+        bool allSettled = true;
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            const int py = ty0 + kSeg * seg + 8 * hb + r8;
+#pragma unroll
+            for (int i = 0; i < kRun; ++i) {
+                const float fx = thr2[i].x, fy = thr2[i].y;            // (named floats: see refreshZeroBound)
+                const float bound = hb ? fy : fx;
+                const uint32_t cnt = (cnt2[hb][i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+                const bool inImage = py < H && px0 + i < W;
+                const bool sa = __builtin_bit_cast(float, ra[hb][i].x) <= bound, sb = __builtin_bit_cast(float, rb[hb][i].x) <= bound;
+                uint32_t b = 0xFFFFFFFFu;
+                if (bound < 0.5f) b = __builtin_bit_cast(uint32_t, bound) - 0x00800000u;
+                else if (cnt == 1u) b = ra[hb][i].y;
+                else if (cnt == 2u && sa != sb) b = sa ? ra[hb][i].y : rb[hb][i].y;
+                best[hb][i] = inImage ? b : 0xFFFFFFFFu;
+                allSettled = allSettled && (!inImage || b != 0xFFFFFFFFu);
+            }
+        }
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            const int py = ty0 + kSeg * seg + 8 * hb + r8;
+#pragma unroll
+            for (int i = 0; i < kRun; ++i) {
+                if (best[hb][i] != 0xFFFFFFFFu) {
+                    const int scan = (int)rank2scan[best[hb][i]];
+                    const int dyi = scan / kSide, dxi = scan - dyi * kSide;
+                    int8_t *dst = mv + (size_t)py * (size_t)mvPitch + (size_t)(px0 + i) * 2u;
+                    dst[0] = (int8_t)(dxi - kR);
+                    dst[1] = (int8_t)(dyi - kR);
+                }
+            }
+        }
+        if (__builtin_amdgcn_readfirstlane(__ballot(!allSettled) == 0ull) && lane == 0) segDone[tile * (kPTH / kSeg) + seg] = 1u;
+    }
 }
 
 // Exact chain of motion.comp:27-47 for ONE candidate of ONE pixel (literal loops, same distance
@@ -842,11 +901,21 @@ __device__ float exact_cost(const uint8_t *__restrict__ prev, int prevPitch, con
     return diff;
 }
 
-__global__ __launch_bounds__(256) void motion_resolve_kernel(
+#ifndef LFG_RESOLVE_WAVES
+#define LFG_RESOLVE_WAVES
+#endif
+__global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int8_t *__restrict__ mv, int mvPitch, int W, int H, const uint2 *__restrict__ list,
     const float *__restrict__ uminIn, const uint32_t *__restrict__ countIn, const uint32_t *__restrict__ tileFlags,
-    int tilesX, PrefilterPlan sp, const uint32_t *__restrict__ rank2scan) {
+    int tilesX, PrefilterPlan sp, const uint32_t *__restrict__ rank2scan, const uint32_t *__restrict__ segDone) {
+    // Blocks whose pixels the prefilter settled itself (see its last lines): the 64 x 4 pixels lie in one 16-row segment
+    // of one or two of its tiles.
+    {
+        const int y0 = (int)blockIdx.y * 4, x0 = (int)blockIdx.x * 64, x1 = min(x0 + 63, W - 1);
+        const int row = (y0 / kPTH) * sp.tilesX, seg = (y0 % kPTH) / kSeg;
+        if (segDone[(row + x0 / kPTW) * (kPTH / kSeg) + seg] != 0u && segDone[(row + x1 / kPTW) * (kPTH / kSeg) + seg] != 0u) return;
+    }
     // Candidates are identified by their RANK in the tie order everywhere in the prefiltered path (lists, the
     // zero-cost encoding), so "smallest rank among equal costs" is the tie-break; rank2scan turns it into (dx, dy).
     __shared__ float sDist[4][kB * kB];    // one block of distances per wave (cooperative exact evaluation)
@@ -856,12 +925,19 @@ __global__ __launch_bounds__(256) void motion_resolve_kernel(
     // No early exits: every lane stays for the cooperative part below.  `live` = this lane owns a pixel to resolve
     // (inside the image and not in a tile that goes through the exact kernel).
     const bool inside = px < W && py < H;
-    const bool live = inside && tileFlags[(py / kTH) * tilesX + px / kTW] == 0u;
-    // Where this pixel's records live: one list in the image-shaped arrays, or several lists (one per unit that
-    // shared the tile's candidates) in the auxiliary arrays.  Record k of list c: recs[c * listStride + k * recStride].
     const int cpx = min(px, W - 1), cpy = min(py, H - 1);
+    // Everything a pixel of a whole tile usually needs -- threshold, count, first record -- is read up front, next to
+    // the two table look-ups and independent of them: one memory latency for the common case instead of a chain of four.
+    const size_t pix = (size_t)cpy * (size_t)W + (size_t)cpx;
+    const float thr0 = uminIn[pix];
+    const uint32_t cnt0 = countIn[pix];
+    const uint2 rec0 = list[(size_t)cpy * (size_t)kListK * (size_t)W + (size_t)cpx];
+    const uint32_t flagged = tileFlags[(cpy / kTH) * tilesX + cpx / kTW];
     const int ptile = (cpy / kPTH) * sp.tilesX + cpx / kPTW;
     const uint32_t tm = sp.tileMap[ptile];
+    const bool live = inside && flagged == 0u;
+    // Where this pixel's records live: one list in the image-shaped arrays, or several lists (one per unit that
+    // shared the tile's candidates) in the auxiliary arrays.  Record k of list c: recs[c * listStride + k * recStride].
     const bool whole = tm == 0xFFFFFFFFu;
     const int nLists = whole ? 1 : (int)(tm >> 24);
     const uint2 *recs;
@@ -887,23 +963,51 @@ __global__ __launch_bounds__(256) void motion_resolve_kernel(
         const int scan = (int)rank2scan[rank];
         return block_leaves_prev(qx, qy, scan % kSide - kR, scan / kSide - kR, W, H);
     };
+    // Called by the whole wave with the same arguments: the lanes test 64 ranks at a time (a serial scan of up to
+    // 1089 table look-ups per pixel made a handful of rim pixels the longest-running part of this kernel).
     auto firstOfPlateau = [&](int qx, int qy, uint32_t rank) {
         if (!leaves(qx, qy, rank)) return rank;
-        for (uint32_t r = 0; r < rank; ++r)
-            if (leaves(qx, qy, r)) return r;
+        for (uint32_t r0 = 0; r0 < rank; r0 += 64u) {
+            const uint32_t r = r0 + (uint32_t)lane;
+            const unsigned long long hit = __ballot(r < rank && leaves(qx, qy, r));
+            if (hit != 0ull) return r0 + (uint32_t)__builtin_ctzll(hit);
+        }
         return rank;
     };
     float bound = __builtin_inff();        // thresholds are monotone: the tightest one holds for every list
     uint32_t survivors = 0u, bestC = 0u;
     if (live) {
-        for (int c = 0; c < nLists; ++c) bound = __builtin_fminf(bound, thrs[(size_t)c * thrStride]);
+        // Threshold, count and first record of up to 8 lists: all loads of a pixel are issued together (a shared
+        // tile's pixel would otherwise walk a chain of a dozen dependent reads).
+        constexpr int kMaxLists = 8;
+        float thrL[kMaxLists];
+        uint32_t cntL[kMaxLists];
+        uint2 recL[kMaxLists];
+        thrL[0] = thr0; cntL[0] = cnt0; recL[0] = rec0;
+#pragma unroll
+        for (int c = 0; c < kMaxLists; ++c) {
+            if (!whole && c < nLists) {
+                thrL[c] = thrs[(size_t)c * thrStride];
+                cntL[c] = cnts[(size_t)c * thrStride];
+                recL[c] = recs[(size_t)c * listStride];
+            } else if (c > 0 || !whole) {
+                thrL[c] = __builtin_inff(); cntL[c] = 0u; recL[c] = uint2{0u, 0u};
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < kMaxLists; ++c) bound = __builtin_fminf(bound, thrL[c]);
         if (bound < 0.5f) {                // a zero-cost candidate exists; the first one in tie order is encoded here
             bestC = __builtin_bit_cast(uint32_t, bound) - 0x00800000u;
         } else {
             // A single survivor IS the shader's answer (the exact minimiser always survives): no evaluation.
-            for (int c = 0; c < nLists; ++c) {
-                const uint32_t n = min(cnts[(size_t)c * thrStride], (uint32_t)kListK);
-                for (uint32_t k = 0; k < n; ++k) {
+#pragma unroll
+            for (int c = 0; c < kMaxLists; ++c) {
+                const uint32_t n = min(cntL[c], (uint32_t)kListK);
+                if (n > 0u && __builtin_bit_cast(float, recL[c].x) <= bound) {
+                    if (survivors == 0u) bestC = recL[c].y;
+                    ++survivors;
+                }
+                for (uint32_t k = 1; k < n; ++k) {
                     const uint2 rec = recs[(size_t)c * listStride + (size_t)k * recStride];
                     if (__builtin_bit_cast(float, rec.x) <= bound) {
                         if (survivors == 0u) bestC = rec.y;
@@ -919,6 +1023,13 @@ __global__ __launch_bounds__(256) void motion_resolve_kernel(
     // walks it), the 64 distances go through LDS and every lane adds them in the shader's order -- 64 loads and
     // distances per lane and candidate would otherwise run with one or two lanes active.
     unsigned long long todo = __ballot(survivors > 1u);
+#ifdef LFG_MOTION_STAMPS
+    if (survivors > 1u) { atomicAdd(&gResolveStats[0], 1ull); atomicAdd(&gResolveStats[1], (unsigned long long)survivors);
+                          atomicAdd(&gResolveStats[2], (unsigned long long)(px < 64 || py < 64 || px >= W - 64 || py >= H - 64)); }
+#endif
+#ifdef LFG_DBG_NOCOOP          // timing experiments only (wrong results)
+    todo = 0ull;
+#endif
     while (todo != 0ull) {
         const int L = __builtin_ctzll(todo);
         todo &= todo - 1ull;
@@ -966,7 +1077,14 @@ __global__ __launch_bounds__(256) void motion_resolve_kernel(
         }
         if (lane == L) bestC = bestR;
     }
-    if (live && survivors == 1u) bestC = firstOfPlateau(px, py, bestC);
+    // single survivors that stand for a plateau: again one pixel at a time, the wave searching together
+    unsigned long long stands = __ballot(live && survivors == 1u && leaves(px, py, bestC));
+    while (stands != 0ull) {
+        const int L = __builtin_ctzll(stands);
+        stands &= stands - 1ull;
+        const uint32_t r = firstOfPlateau(__shfl(px, L), __shfl(py, L), (uint32_t)__shfl((int)bestC, L));
+        if (lane == L) bestC = r;
+    }
     if (live) {
         const int bscan = (int)rank2scan[bestC];
         const int dyi = bscan / kSide, dxi = bscan - dyi * kSide;
@@ -994,7 +1112,10 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, Motion
     l.umin = align(l.list + px * kListK * sizeof(uint2));
     l.count = align(l.umin + px * sizeof(float));
     l.tileFlags = align(l.count + px * sizeof(uint32_t));
-    l.order = align(l.tileFlags + tiles * sizeof(uint32_t));          // this call's hints and visiting order
+    // one word per 16-row segment of a prefilter tile, right behind the flags: one memset clears both
+    const size_t ptiles = (size_t)((width + kPTW - 1) / kPTW) * ((height + kPTH - 1) / kPTH);
+    l.segDone = l.tileFlags + tiles * sizeof(uint32_t);
+    l.order = align(l.segDone + ptiles * (kPTH / kSeg) * sizeof(uint32_t));   // this call's hints and visiting order
     // work-unit tables and the auxiliary arrays of the shared tiles (see prefilter_plan): one 56 x 64 block per unit
     const PrefilterPlanHost plan = prefilter_plan(width, height, slots);
     const size_t auxUnits = (size_t)plan.auxUnits;
@@ -1118,8 +1239,8 @@ void motion_tables(bool intended, uint32_t *rank2scan, uint32_t *order32, uint32
 // The fewer running minima a pixel sees, the less the prefilter records.  Two tiny kernels put the candidates
 // that are likely to be the answer at the front of the visiting order of THIS call: motion_hint_kernel block-matches
 // 256 sample blocks (a 16 x 16 grid over the frame) with a plain SAD over all 1089 candidates and reports each
-// block's best; motion_order_kernel emits zero motion, then the distinct hints, then the rest of the fixed
-// pseudo-random order.  With a few dominant motions in the frame (a pan, a handful of objects) most pixels meet
+// block's best; motion_order_kernel emits the most popular hint, zero motion, the other distinct hints, then the
+// rest of the fixed pseudo-random order.  With a few dominant motions in the frame (a pan, a handful of objects) most pixels meet
 // their minimum within the first few candidates and close their thresholds at once.  The order only changes what
 // is recorded along the way: every candidate is still evaluated for every pixel and the results are identical.
 
@@ -1170,19 +1291,32 @@ __global__ __launch_bounds__(256) void motion_order_kernel(
     const uint32_t *__restrict__ hints, const uint32_t *__restrict__ baseScan,
     const uint32_t *__restrict__ entryOfScan, uint32_t *__restrict__ order32) {
     __shared__ uint32_t sOwner[kCand];               // lowest hint index that proposes this candidate
+    __shared__ uint32_t sVotes[kCand];               // how many sample blocks propose it
     __shared__ uint32_t sWaveSum[4];
-    __shared__ uint32_t sRunning;
+    __shared__ uint32_t sRunning, sTop;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint32_t zero = baseScan[0];               // zero motion: always first
-    for (int i = tid; i < kCand; i += 256) sOwner[i] = 0xFFFFFFFFu;
-    if (tid == 0) sRunning = 1u;
+    const uint32_t zero = baseScan[0];               // zero motion
+    for (int i = tid; i < kCand; i += 256) { sOwner[i] = 0xFFFFFFFFu; sVotes[i] = 0u; }
+    if (tid == 0) sTop = 0u;
     __syncthreads();
     // Hints are taken in a scrambled order of the sample blocks: under a zoom or a rotation the hints vary smoothly
     // across the frame, and in raster order a pixel would see them approach its own motion -- one running minimum
     // after the other -- which is exactly what fills the lists.
     const uint32_t mine = hints[(tid * 97 + 13) & (kHints - 1)];
     if (mine != zero) atomicMin(&sOwner[mine], (uint32_t)tid);
-    if (tid == 0) order32[0] = entryOfScan[zero];
+    atomicAdd(&sVotes[mine], 1u);
+    __syncthreads();
+    // The most popular hint goes first: where it is the answer (a pan: nearly everywhere) the very first evaluation
+    // closes the thresholds, and zero motion -- second -- already fails the cheap test instead of being recorded for
+    // every pixel.  (Ties: the candidate earlier in scan order.)
+    atomicMax(&sTop, (sVotes[mine] << 11) | (uint32_t)(kCand - 1 - (int)mine));
+    __syncthreads();
+    const uint32_t top = (uint32_t)(kCand - 1) - (sTop & 0x7FFu);
+    if (tid == 0) {
+        order32[0] = entryOfScan[top];
+        if (top != zero) order32[1] = entryOfScan[zero];
+        sRunning = top != zero ? 2u : 1u;
+    }
     __syncthreads();
     // block-wide exclusive scan of one flag per thread, appended at sRunning
     auto append = [&](bool keep, uint32_t scan) {
@@ -1197,7 +1331,7 @@ __global__ __launch_bounds__(256) void motion_order_kernel(
         if (tid == 0) sRunning += sWaveSum[0] + sWaveSum[1] + sWaveSum[2] + sWaveSum[3];
         __syncthreads();
     };
-    append(mine != zero && sOwner[mine] == (uint32_t)tid, mine);       // distinct hints
+    append(mine != zero && mine != top && sOwner[mine] == (uint32_t)tid, mine);       // the other distinct hints
     for (int e0 = 1; e0 < kCand; e0 += 256) {                          // then everything no hint proposed
         const int e = e0 + tid;
         const uint32_t scan = e < kCand ? baseScan[e] : 0u;
@@ -1224,7 +1358,8 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
     sp.auxList = reinterpret_cast<uint2 *>(workspace + l.auxList);
     sp.auxUmin = reinterpret_cast<float *>(workspace + l.auxUmin);
     sp.auxCount = reinterpret_cast<uint32_t *>(workspace + l.auxCount);
-    hipError_t e = hipMemsetAsync(flags, 0, (size_t)tilesX * tilesY * sizeof(uint32_t), s);
+    uint32_t *segDone = reinterpret_cast<uint32_t *>(workspace + l.segDone);
+    hipError_t e = hipMemsetAsync(flags, 0, l.order - l.tileFlags, s);             // tile flags and segment marks
     if (e != hipSuccess) return e;
     if (useHints && curr.width >= 64u && curr.height >= 64u) {         // this call's visiting order
         uint32_t *hints = reinterpret_cast<uint32_t *>(workspace + l.order);
@@ -1239,7 +1374,8 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
     }
     hipLaunchKernelGGL(motion_prefilter_kernel, dim3(sp.units), dim3(kPNT), 0, s,
                        (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
-                       (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, order, sp);
+                       (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, order, sp,
+                       (int8_t *)mv.data, (int)mv.pitch, rank2scan, segDone);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
 #ifdef LFG_MOTION_STAMPS
@@ -1266,12 +1402,15 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
                 fprintf(stderr, "%s units %d: mean %.1f us (staging %.1f, first batch %.1f), max %.1f us, evaluations per wave %.1f\n", r ? "rim" : "interior", cnt[r],
                         sum[r] / std::max(cnt[r], 1), stg[r] / std::max(cnt[r], 1), fst[r] / std::max(cnt[r], 1), mx[r], ev[r] / std::max(cnt[r], 1));
             fprintf(stderr, "span %.1f us\n", (double)(t1 - t0) / 100.0);
+            unsigned long long rs[4];
+            hipMemcpyFromSymbol(rs, HIP_SYMBOL(gResolveStats), sizeof(rs));
+            fprintf(stderr, "resolve (previous calls together): %llu pixels with several survivors (%llu within 64 px of the rim), %llu survivors\n", rs[0], rs[2], rs[1]);
         }
     }
 #endif
     hipLaunchKernelGGL(motion_resolve_kernel, dim3((curr.width + 63) / 64, (curr.height + 3) / 4), dim3(256), 0, s,
                        (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
-                       (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, sp, rank2scan);
+                       (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, sp, rank2scan, segDone);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     return launch_motion_tiled_8_16(s, prev, curr, mv, flags, rank2scan);
