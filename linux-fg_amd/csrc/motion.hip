@@ -695,11 +695,13 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
 #endif
         int border = borderTile;
         asm volatile("" : "+s"(border));   // one copy of the loop below, not one per kind of tile
-        auto distanceOf = [&](uint32_t cT, uint32_t texel) {           // same arithmetic as columnSums
+        // The SQUARED distance n (an exact integer, same arithmetic as columnSums) is enough here: the lattice test
+        // compares with a squared threshold and saves the square root, the most expensive operation of a point.
+        auto distanceOf = [&](uint32_t cT, uint32_t texel) {
             const uint32_t ccT = __builtin_amdgcn_udot4(cT, cT, 0x4B000000u, false);
             const float f1 = __builtin_bit_cast(float, __builtin_amdgcn_udot4(texel, texel, ccT, false));
             const float f2 = __builtin_bit_cast(float, __builtin_amdgcn_udot4(cT, texel, 0x4B800000u, false));
-            return __builtin_amdgcn_sqrtf((f1 - f2) + 8388608.0f);
+            return (f1 - f2) + 8388608.0f;
         };
         // bit k of the result: candidate i0 + k of the staged order has to be evaluated in full
         auto latticeBatch = [&](int i0, int count, uint32_t &ordL) -> unsigned long long {
@@ -710,8 +712,8 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
             bool need = (int)l < count && idx < nEntries && (ordL & 0xFFFFu) < zeroBound;
             if (waveThr < 510.0f) {                                    // a distance is at most sqrt(4 * 255^2) = 510
                 const lds_ro_u32_ptr w = (lds_ro_u32_ptr)(sWin + kSeg * seg) + (ordL >> 16);
-                // the candidate's smallest lattice distance, as bits: distances are non-negative floats, whose
-                // order is the order of their bit patterns (one v_min_u32 per point, no NaN handling)
+                // the candidate's smallest squared lattice distance, as bits: non-negative floats, whose order is
+                // the order of their bit patterns (one v_min_u32 per point, no NaN handling)
                 uint32_t dMin = 0x7F800000u;
                 auto bitsOf = [](float d) { return __builtin_bit_cast(uint32_t, d); };
                 if (border) {
@@ -741,7 +743,12 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
                             dMin = min(dMin, bitsOf(distanceOf((uint32_t)__builtin_amdgcn_readlane((int)c[3 + 8 * t], 3 + 8 * ci), tex[ci][t])));
                     }
                 }
-                need = need & !(dMin > __builtin_bit_cast(uint32_t, waveThr));
+                // n > waveThr^2 (1 + 2^-21) => sqrt(n) > waveThr (1 + 2^-22), which v_sqrt_f32's 1 ulp cannot bring
+                // back to waveThr: every distance S~ would add exceeds the threshold.  (Both factors below round,
+                // 2^-24 each, against a margin of 2^-20; a threshold that stands for a zero cost squares to 0 and
+                // the test reads n > 0.)
+                const float thrSq = (waveThr * waveThr) * 1.000001f;
+                need = need & !(dMin > __builtin_bit_cast(uint32_t, thrSq));
             }
             return __ballot(need);
         };
@@ -1343,7 +1350,7 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
                                           const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &l, int units,
                                           const uint32_t *rank2scan, const uint32_t *order,
                                           const uint32_t *entryOfScan, const uint32_t *baseScan, bool useHints) {
-    const int tilesX = ((int)curr.width + kTW - 1) / kTW, tilesY = ((int)curr.height + kTH - 1) / kTH;
+    const int tilesX = ((int)curr.width + kTW - 1) / kTW;
     uint2 *list = reinterpret_cast<uint2 *>(workspace + l.list);
     float *umin = reinterpret_cast<float *>(workspace + l.umin);
     uint32_t *count = reinterpret_cast<uint32_t *>(workspace + l.count);
