@@ -98,6 +98,37 @@ def pmc_traffic(kernel_prefixes):
     return None, None
 
 
+def pmc_executed(kernel_prefix):
+    """What the dominant kernel actually executed per launch, from the newest committed SQ counter summary
+    (profiles/rNN_motion_sq_counters.txt, one rocprofv3 --pmc pass over tools/run_stage.py motion): wave-level
+    VALU / LDS / SALU instruction counts and the kernel's mean duration in that pass.  None if absent."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_motion_sq_counters.txt")))
+    if not files:
+        return None
+    out, cur = {}, None
+    for line in open(files[-1]):
+        if ": launches" in line and not line.startswith(" "):
+            cur = line.split(": launches")[0].replace("void ", "").split("<")[0].split("(")[0].strip()
+            m = re.search(r"mean ([0-9.]+) us", line)
+            if cur.startswith(kernel_prefix) and m:
+                out = {"mean_us": float(m.group(1))}
+        m = re.match(r"^\s+(SQ_\w+)\s+([0-9.e+]+)", line)
+        if m and cur and cur.startswith(kernel_prefix):
+            out[m.group(1)] = float(m.group(2))
+    if not {"mean_us", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU"} <= set(out):
+        return None
+    simds, clock_hz = 1024, 2.4e9                       # 256 CUs x 4 SIMDs, peak engine clock
+    slots = out["mean_us"] * 1e-6 * clock_hz * simds
+    return {"source": os.path.relpath(files[-1], ROOT), "kernel_us_in_that_pass": out["mean_us"],
+            "valu_wave_instructions": out["SQ_INSTS_VALU"], "lds_wave_instructions": out["SQ_INSTS_LDS"],
+            "salu_wave_instructions": out["SQ_INSTS_SALU"],
+            "valu_issue_utilisation": round(out["SQ_INSTS_VALU"] * 4.0 / slots, 3),
+            "how": "VALU wave-instructions x 4 cycles / (duration x 2.4 GHz x 1024 SIMDs): the share of the VALU issue "
+                   "slots the kernel filled -- the utilisation figure that `frac` (an algorithmic rate) is not"}
+
+
 def motion_flops(w: int, h: int, block: int = 8, radius: int = 16) -> float:
     """Algorithmic flops of motion.comp with per-position distance reuse: per candidate, one distance
     per pixel (4 sub, 4 mul, 3 add, 1 sqrt = 12 flops) and block*block adds per pixel."""
@@ -305,8 +336,15 @@ def main():
                                  "the shader (W*H*1089*(64 adds + 12 per distance)) / duration of the whole lfg_motion call (HIP "
                                  "events around its launches).  The default path does not execute all of them: an exact bracket "
                                  "on the cost rules out all but ~1 candidate per pixel before the literal 64-add chain is "
-                                 "needed (DESIGN.md, motion); LFG_MOTION_MODE=1 runs the literal kernel alone.  The 157.3 "
-                                 "TFLOP/s peak counts an FMA as 2; an add-only stream tops out at 78.65.")}
+                                 "needed, and a partial-distortion test drops most candidates of a 16 x 56 pixel segment after "
+                                 "24 of their 1449 distances (DESIGN.md, motion) -- which is how frac can exceed 1: it is the "
+                                 "rate at which the shader's work is disposed of, not a utilisation (see `executed`).  "
+                                 "LFG_MOTION_MODE=1 runs the literal kernel alone.  The 157.3 TFLOP/s peak counts an FMA as 2; "
+                                 "an add-only stream tops out at 78.65.")}
+            if not exact_only and args.input == "1080p" and not in_res:
+                ex = pmc_executed("lfg::motion_prefilter")
+                if ex is not None:
+                    roofline["executed"] = ex
             if motion_stats is not None:
                 roofline["motion_mode"] = "prefiltered"
                 roofline["fallback_tiles"] = {"of": motion_stats[0], "exact_kernel": motion_stats[1]}
