@@ -581,17 +581,15 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
         float sv[2][kRun], thr[2][kRun];
 #pragma unroll
         for (int i = 0; i < kRun; ++i) { sv[0][i] = s2[i].x; sv[1][i] = s2[i].y; thr[0][i] = thr2[i].x; thr[1][i] = thr2[i].y; }
-        unsigned long long hit[2][kRun];
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
+            // seven masks at a time (all fourteen at once is more scalar registers than the loop has to spare)
+            unsigned long long hit[kRun];
 #pragma unroll
-            for (int i = 0; i < kRun; ++i) hit[hb][i] = __ballot(sv[hb][i] <= thr[hb][i]);
-        }
-#pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {
+            for (int i = 0; i < kRun; ++i) hit[i] = __ballot(sv[hb][i] <= thr[hb][i]);
 #pragma unroll
             for (int i = 0; i < kRun; ++i) {
-                if (hit[hb][i] != 0ull) {                              // wave-uniform
+                if (hit[i] != 0ull) {                                  // wave-uniform
                     asm volatile("; some lane records a candidate");  // keeps this a scalar branch of its own
                     const float s = sv[hb][i];
                     if (s <= thr[hb][i]) {                             // rare: ~7.6 times per pixel in 1089
@@ -613,8 +611,13 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
                         uint32_t inc = (s != 0.0f && countIt != 0u) ? (1u << (16 * (i & 1))) : 0u;
                         if (windowLeavesPrev) {                        // wave-uniform: tiles away from the rim skip this
                             // one member per plateau (block_leaves_prev): a second one is written but not counted
+                            // (the pixel's coordinates are recomputed from the lane number here: kept in registers
+                            //  across the evaluation they end up spilled, and a scratch reload costs a memory latency)
+                            uint32_t l;
+                            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(l));
                             const uint32_t bit = 1u << (kRun * hb + i);
-                            const bool plateau = block_leaves_prev(px0 + i, ty0 + kSeg * seg + 8 * hb + r8, candDx, candDy, W, H);
+                            const bool plateau = block_leaves_prev(tx0 + kRun * (int)(l >> 3) + i, ty0 + kSeg * seg + 8 * hb + (int)(l & 7u),
+                                                                   candDx, candDy, W, H);
                             inc = (plateau && (plateauSeen & bit) != 0u) ? 0u : inc;
                             plateauSeen |= (plateau && inc != 0u) ? bit : 0u;
                         }
@@ -1253,7 +1256,9 @@ void motion_tables(bool intended, uint32_t *rank2scan, uint32_t *order32, uint32
 
 constexpr int kHintWin = kB + 2 * kR;                // 40 x 40 texels of prev around a sample block
 
-__global__ __launch_bounds__(256) void motion_hint_kernel(
+constexpr int kHintThreads = 1024;                   // one or two candidates per thread: the kernel is a latency chain, not work
+
+__global__ __launch_bounds__(kHintThreads) void motion_hint_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int W, int H, uint32_t *__restrict__ hints) {
     __shared__ uint32_t sP[kHintWin * kHintWin];
@@ -1263,10 +1268,19 @@ __global__ __launch_bounds__(256) void motion_hint_kernel(
     const int gx = blockIdx.x % kHintGrid, gy = blockIdx.x / kHintGrid;
     const int bx = (2 * gx + 1) * W / (2 * kHintGrid) - kB / 2, by = (2 * gy + 1) * H / (2 * kHintGrid) - kB / 2;
     if (tid == 0) sBest = 0xFFFFFFFFu;
-    for (int i = tid; i < kHintWin * kHintWin; i += 256) {
-        const int x = bx - kR + i % kHintWin, y = by - kR + i / kHintWin;
-        sP[i] = (x >= 0 && x < W && y >= 0 && y < H)
-                    ? *reinterpret_cast<const uint32_t *>(prev + (size_t)y * (size_t)prevPitch + (size_t)x * 4u) : 0u;
+    {   // both loads of a thread in flight at once (branch-free: clamped address, value dropped outside the image)
+        constexpr int kRounds = (kHintWin * kHintWin + kHintThreads - 1) / kHintThreads;
+        uint32_t v[kRounds];
+#pragma unroll
+        for (int k = 0; k < kRounds; ++k) {
+            const int i = min(k * kHintThreads + tid, kHintWin * kHintWin - 1);
+            const int x = bx - kR + i % kHintWin, y = by - kR + i / kHintWin;
+            const uint32_t t = *reinterpret_cast<const uint32_t *>(prev + (size_t)clampi(y, 0, H - 1) * (size_t)prevPitch + (size_t)clampi(x, 0, W - 1) * 4u);
+            v[k] = (x >= 0 && x < W && y >= 0 && y < H) ? t : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < kRounds; ++k)
+            if (k * kHintThreads + tid < kHintWin * kHintWin) sP[k * kHintThreads + tid] = v[k];
     }
     if (tid < kB * kB) {
         const int x = bx + tid % kB, y = by + tid / kB;
@@ -1275,18 +1289,23 @@ __global__ __launch_bounds__(256) void motion_hint_kernel(
         sValid[tid] = ok ? 1u : 0u;
     }
     __syncthreads();
-    // the 64 curr texels and their in-image masks stay in registers; per candidate 64 LDS reads and 64 v_sad_u8
-    uint32_t c[kB * kB], m[kB * kB];
-#pragma unroll
-    for (int p = 0; p < kB * kB; ++p) { c[p] = sC[p]; m[p] = sValid[p] ? 0xFFFFFFFFu : 0u; }
+    // Per candidate 64 LDS reads of prev, 64 broadcast reads of curr and 64 v_sad_u8.  A block position outside the
+    // image (small frames only: the sample blocks of a frame of 128 x 128 or more lie inside it) has c = 0 and a
+    // masked-out prev texel.
+    const bool inside = bx >= 0 && by >= 0 && bx + kB <= W && by + kB <= H;          // workgroup-uniform
     uint32_t best = 0xFFFFFFFFu;
-    for (int cand = tid; cand < kCand; cand += 256) {
+    for (int cand = tid; cand < kCand; cand += kHintThreads) {
         const int dyi = cand / kSide, dxi = cand - dyi * kSide;
         const uint32_t *w = sP + dyi * kHintWin + dxi;
         uint32_t sad = 0u;
+        if (inside) {
 #pragma unroll
-        for (int p = 0; p < kB * kB; ++p)       // a position outside the image has c = 0 and a masked-out prev texel
-            sad = __builtin_amdgcn_sad_u8(c[p], w[(p / kB) * kHintWin + p % kB] & m[p], sad);
+            for (int p = 0; p < kB * kB; ++p) sad = __builtin_amdgcn_sad_u8(sC[p], w[(p / kB) * kHintWin + p % kB], sad);
+        } else {
+#pragma unroll
+            for (int p = 0; p < kB * kB; ++p)
+                sad = __builtin_amdgcn_sad_u8(sC[p], sValid[p] ? w[(p / kB) * kHintWin + p % kB] : 0u, sad);
+        }
         best = min(best, (sad << 11) | (uint32_t)cand);                // <= 64 * 1020 < 2^16, cand < 2^11
     }
     atomicMin(&sBest, best);
@@ -1338,11 +1357,15 @@ __global__ __launch_bounds__(256) void motion_order_kernel(
         if (tid == 0) sRunning += sWaveSum[0] + sWaveSum[1] + sWaveSum[2] + sWaveSum[3];
         __syncthreads();
     };
+    constexpr int kRounds = (kCand - 1 + 255) / 256;
+    uint32_t base[kRounds];                                            // this thread's entries of the fixed order, read up front
+#pragma unroll
+    for (int k = 0; k < kRounds; ++k) base[k] = baseScan[min(1 + k * 256 + tid, kCand - 1)];
     append(mine != zero && mine != top && sOwner[mine] == (uint32_t)tid, mine);       // the other distinct hints
-    for (int e0 = 1; e0 < kCand; e0 += 256) {                          // then everything no hint proposed
-        const int e = e0 + tid;
-        const uint32_t scan = e < kCand ? baseScan[e] : 0u;
-        append(e < kCand && sOwner[scan] == 0xFFFFFFFFu, scan);
+#pragma unroll
+    for (int k = 0; k < kRounds; ++k) {                                // then everything no hint proposed
+        const int e = 1 + k * 256 + tid;
+        append(e < kCand && sOwner[base[k]] == 0xFFFFFFFFu, base[k]);
     }
 }
 
@@ -1371,7 +1394,7 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
     if (useHints && curr.width >= 64u && curr.height >= 64u) {         // this call's visiting order
         uint32_t *hints = reinterpret_cast<uint32_t *>(workspace + l.order);
         uint32_t *callOrder = hints + kHints;
-        hipLaunchKernelGGL(motion_hint_kernel, dim3(kHints), dim3(256), 0, s,
+        hipLaunchKernelGGL(motion_hint_kernel, dim3(kHints), dim3(kHintThreads), 0, s,
                            (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
                            (int)curr.width, (int)curr.height, hints);
         hipLaunchKernelGGL(motion_order_kernel, dim3(1), dim3(256), 0, s, hints, baseScan, entryOfScan, callOrder);
