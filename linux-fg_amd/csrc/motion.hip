@@ -812,14 +812,14 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
             tileFlags[tileY * flagTilesX + ex0] = 1u;
             tileFlags[tileY * flagTilesX + ex1] = 1u;
         }
-        return;
+        if (!segUnit) return;              // (the waves of a segment unit meet at a barrier below)
     }
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
         const int py = ty0 + kSeg * seg + 8 * hb + r8;
 #pragma unroll
         for (int i = 0; i < kRun; ++i) {
-            if (py < H && px0 + i < W) {
+            if (!gaveUp && py < H && px0 + i < W) {
                 const uint32_t cnt = (cnt2[hb][i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
                 if (whole) {
                     const size_t gp = (size_t)py * (size_t)W + (size_t)(px0 + i);
@@ -882,6 +882,96 @@ __global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
             }
         }
         if (__builtin_amdgcn_readfirstlane(__ballot(!allSettled) == 0ull) && lane == 0) segDone[tile * (kPTH / kSeg) + seg] = 1u;
+    }
+    // A segment unit does the same for its segment, its four waves pooling what each learnt about its part of the
+    // candidate order: the tightest threshold of the four is the pixel's bound, every wave holds its own records
+    // against it, and a pixel with exactly one survivor among all four (or a zero-cost candidate) is settled --
+    // unless the survivor stands for a plateau, which the resolve kernel sorts out.  The exchange goes through the
+    // window's LDS, which every wave has finished with at the first barrier.
+    if (segUnit && nChunks == 4) {         // (all parts of the order in this workgroup)
+        constexpr int kPix = 2 * kRun * 64;                            // pixel slots of a wave (896)
+        float *const sBound = reinterpret_cast<float *>(sWin);        // [4][kPix] thresholds
+        uint32_t *const sMine = sWin + 4 * kPix;                       // [4][kPix] 0: no survivor, 0x80000000 | rank: one, ~0: unknown
+        uint32_t *const sOpen = sWin + 8 * kPix;                       // some pixel of the segment is left to the resolve kernel
+        static_assert(8 * kPix + 1 <= kWinH * kWinW, "exchange area fits the window");
+        __syncthreads();
+        if (*(volatile uint32_t *)&sGiveUp != 0u) return;              // the tile goes through the exact kernel
+        uint2 ra[2][kRun], rb[2][kRun];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+            for (int i = 0; i < kRun; ++i) {
+                ra[hb][i] = waveList[laneOff[hb] + (uint32_t)i];
+                rb[hb][i] = waveList[rowStride + laneOff[hb] + (uint32_t)i];
+                const float fx = thr2[i].x, fy = thr2[i].y;            // (named floats: see refreshZeroBound)
+                sBound[wave * kPix + (kRun * hb + i) * 64 + lane] = hb ? fy : fx;
+            }
+        }
+        if (tid == 0) *sOpen = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+            for (int i = 0; i < kRun; ++i) {
+                const int at = (kRun * hb + i) * 64 + lane;
+                const float bound = __builtin_fminf(__builtin_fminf(sBound[at], sBound[kPix + at]),
+                                                    __builtin_fminf(sBound[2 * kPix + at], sBound[3 * kPix + at]));
+                const uint32_t cnt = (cnt2[hb][i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+                const bool sa = cnt >= 1u && __builtin_bit_cast(float, ra[hb][i].x) <= bound;
+                const bool sb = cnt >= 2u && __builtin_bit_cast(float, rb[hb][i].x) <= bound;
+                uint32_t word = 0u;
+                if (cnt > 2u || (sa && sb)) word = 0xFFFFFFFFu;
+                else if (sa) word = 0x80000000u | ra[hb][i].y;
+                else if (sb) word = 0x80000000u | rb[hb][i].y;
+                sMine[wave * kPix + at] = word;
+            }
+        }
+        __syncthreads();
+        bool open = false;
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            const int py = ty0 + kSeg * seg + 8 * hb + r8;
+#pragma unroll
+            for (int i = 0; i < kRun; ++i) {
+                if (((kRun * hb + i) & 3) != wave) continue;           // the fourteen slots are dealt out to the four waves
+                if (!(py < H && px0 + i < W)) continue;
+                const int at = (kRun * hb + i) * 64 + lane;
+                const float bound = __builtin_fminf(__builtin_fminf(sBound[at], sBound[kPix + at]),
+                                                    __builtin_fminf(sBound[2 * kPix + at], sBound[3 * kPix + at]));
+                uint32_t best = 0xFFFFFFFFu;
+                bool single = false;
+                if (bound < 0.5f) {
+                    best = __builtin_bit_cast(uint32_t, bound) - 0x00800000u;
+                } else {
+                    uint32_t n = 0u, any = 0u, all = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const uint32_t word = sMine[w * kPix + at];
+                        n += word != 0u ? 1u : 0u;
+                        any |= word;
+                        all &= word != 0u ? word : 0xFFFFFFFFu;
+                    }
+                    // exactly one wave reports, and it reports a single rank (any == all == that word)
+                    if (n == 1u && any != 0xFFFFFFFFu) { best = any & 0x7FFFFFFFu; single = true; }
+                    (void)all;
+                }
+                bool settled = best != 0xFFFFFFFFu;
+                if (settled) {
+                    const int scan = (int)rank2scan[best];
+                    const int dyi = scan / kSide, dxi = scan - dyi * kSide;
+                    if (single && block_leaves_prev(px0 + i, py, dxi - kR, dyi - kR, W, H)) settled = false;
+                    if (settled) {
+                        int8_t *dst = mv + (size_t)py * (size_t)mvPitch + (size_t)(px0 + i) * 2u;
+                        dst[0] = (int8_t)(dxi - kR);
+                        dst[1] = (int8_t)(dyi - kR);
+                    }
+                }
+                open = open || !settled;
+            }
+        }
+        if (__builtin_amdgcn_readfirstlane(__ballot(open) != 0ull) && lane == 0) *sOpen = 1u;
+        __syncthreads();
+        if (tid == 0 && *sOpen == 0u) segDone[tile * (kPTH / kSeg) + seg] = 1u;
     }
 }
 
