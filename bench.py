@@ -53,8 +53,8 @@ def parse_args():
     ap.add_argument("--workload", choices=["pipeline", "scale", "pipeline_input_res"], default="pipeline")
     ap.add_argument("--input", choices=list(SIZES), default="1080p", help="input size; output is 2x")
     ap.add_argument("--factors", default="0.5", help="comma-separated interpolation factors per pair")
-    ap.add_argument("--content", choices=["translated", "uncorrelated", "static", "fade"], default="translated",
-                    help="translated (default: curr = prev shifted by (3,-2)), uncorrelated (independent noise frames), "
+    ap.add_argument("--content", choices=["translated", "occluded", "uncorrelated", "static", "fade"], default="translated",
+                    help="translated (default: curr = prev shifted by (3,-2)), occluded (the same with patches of fresh noise), uncorrelated (independent noise frames), "
                          "static (curr = prev), fade (flat grey frames one level apart: every candidate ties at a "
                          "non-zero cost, the prefilter's worst case -- all tiles fall back to the literal kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -229,6 +229,14 @@ def main():
         curr_in = synth.translate(prev_in, (3 + rank, -2), synth.BASE_SEED + rank)
     elif args.content == "uncorrelated":
         curr_in = synth.noise_bytes(w_in, h_in, (synth.BASE_SEED + 7919 * (rank + 1)) & 0xFFFFFFFF)
+    elif args.content == "occluded":                       # the translated pair with 24 patches of fresh noise (2 % of the frame)
+        curr_in = synth.translate(prev_in, (3 + rank, -2), synth.BASE_SEED + rank)
+        fresh = synth.noise_bytes(w_in, h_in, (synth.BASE_SEED + 104729 * (rank + 1)) & 0xFFFFFFFF)
+        rng = np.random.default_rng(20240 + rank)
+        for _ in range(24):
+            pw, ph = int(rng.integers(w_in // 60, w_in // 12)), int(rng.integers(h_in // 60, h_in // 12))
+            x0, y0 = int(rng.integers(40, w_in - 40 - pw)), int(rng.integers(40, h_in - 40 - ph))
+            curr_in[y0:y0 + ph, x0:x0 + pw] = fresh[y0:y0 + ph, x0:x0 + pw]
     elif args.content == "static":
         curr_in = prev_in.copy()
     else:                                                   # fade

@@ -345,7 +345,10 @@ __device__ unsigned long long gResolveStats[4];
 
 // order32[e] = the candidate's rank in the tie order (motion_tables) in the low half, its window offset
 // (dx+R)*kWinH + (dy+R) in the high half; 32-bit entries so the wave-uniform reads are scalar loads.
-__global__ __launch_bounds__(kPNT, 3) void motion_prefilter_kernel(
+#ifndef LFG_PREF_OCC
+#define LFG_PREF_OCC 3
+#endif
+__global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int W, int H, uint2 *__restrict__ list, float *__restrict__ uminOut,
     uint32_t *__restrict__ countOut, uint32_t *__restrict__ tileFlags, int flagTilesX,

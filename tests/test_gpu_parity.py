@@ -302,6 +302,72 @@ def test_motion_4k_modes_agree_on_noise_and_translation(ctx):
     assert (a == b).all()
 
 
+def test_motion_modes_agree_on_benchmark_frames_and_occlusions(ctx):
+    """The benchmark's own frames (a translated 1080p pair, both upscaled on the device: small non-zero costs at the
+    true vector, exposed bands at the rim) and the same pair with patches of fresh noise pasted into curr (segments in
+    the middle of the frame that find no match and search in full next to segments that close at once): prefiltered
+    path == literal kernel, nothing through the fallback."""
+    from linux_fg_amd import capi
+    W, H = 3840, 2160
+    pin = synth.make_prev(W // 2, H // 2, seed=synth.BASE_SEED)
+    cin = synth.translate(pin, (3, -2), synth.BASE_SEED)
+    P = run_scale(ctx, pin, W, H)
+    C = run_scale(ctx, cin, W, H)
+    a, stats = run_motion_mode(ctx, P, C, capi.MOTION_PREFILTERED)
+    b, _ = run_motion_mode(ctx, P, C, capi.MOTION_EXACT_ONLY)
+    assert (a == b).all() and stats[1] == 0
+    inner = a[40:H - 40, 40:W - 40]
+    assert (inner[..., 0] == -6).all() and (inner[..., 1] == 4).all()
+    C2 = C.copy()
+    patch = synth.noise_bytes(W, H, 4242)
+    for (x0, y0, w, h) in [(500, 300, 90, 70), (1900, 1000, 200, 33), (3000, 1700, 17, 150), (1234, 2000, 300, 100)]:
+        C2[y0:y0 + h, x0:x0 + w] = patch[y0:y0 + h, x0:x0 + w]
+    a, stats = run_motion_mode(ctx, P, C2, capi.MOTION_PREFILTERED)
+    b, _ = run_motion_mode(ctx, P, C2, capi.MOTION_EXACT_ONLY)
+    assert (a == b).all(), f"{(a != b).any(-1).sum()} pixels differ"
+    assert stats[1] == 0
+
+
+def test_three_stages_at_8k(ctx, oracle):
+    """BASELINE config 5 size (4K -> 8K, three interpolation factors): scale against the oracle on regions, motion by
+    the translation property and against the literal kernel everywhere, interpolate exact on regions for each factor."""
+    from linux_fg_amd import capi
+    w, h, W, H = 3840, 2160, 7680, 4320
+    pin = synth.make_prev(w, h, seed=synth.BASE_SEED + 5)
+    cin = synth.translate(pin, (-2, 5), synth.BASE_SEED + 5)
+    p, c = ctx.frame_from(pin), ctx.frame_from(cin)
+    P, C, O = ctx.create_frame(W, H), ctx.create_frame(W, H), ctx.create_frame(W, H)
+    M = ctx.create_frame(W, H, capi.FORMAT_MV_S8X2)
+    ctx.scale(p, P)
+    ctx.scale(c, C)
+    ctx.motion(P, C, M)
+    ctx.sync()
+    Pn, Cn, Mn = ctx.download(P), ctx.download(C), ctx.download(M)
+    rois = [(0, 0, 96, 24), (W - 96, H - 24, W, H), (3800, 2150, 3900, 2170)]
+    for roi in rois:
+        x0, y0, x1, y1 = roi
+        assert_within_1lsb(Cn[y0:y1, x0:x1], oracle.scale(cin, W, H, roi=roi)[y0:y1, x0:x1], max_mismatch=0.08)
+    inner = Mn[48:H - 48, 48:W - 48]
+    assert (inner[..., 0] == 4).all() and (inner[..., 1] == -10).all()
+    ctx.set_motion_mode(capi.MOTION_EXACT_ONLY)
+    try:
+        ctx.motion(P, C, M)
+        ctx.sync()
+        assert (ctx.download(M) == Mn).all()
+    finally:
+        ctx.set_motion_mode(capi.MOTION_PREFILTERED)
+    for t in (0.25, 0.5, 0.75):
+        ctx.interpolate(P, C, M, O, t)
+        ctx.sync()
+        On = ctx.download(O)
+        for roi in rois:
+            x0, y0, x1, y1 = roi
+            want = oracle.interpolate(Pn, Cn, Mn, t, roi=roi)
+            assert (On[y0:y1, x0:x1] == want[y0:y1, x0:x1]).all(), (t, roi)
+    for f in (p, c, P, C, O, M):
+        ctx.destroy_frame(f)
+
+
 def test_motion_zoom_and_rotation_fields(ctx):
     """Smoothly varying motion (a 4 % zoom, a 1.5 degree rotation of a noise texture): the per-call hints differ from
     block to block, the lists must not overflow, and both modes must agree."""
