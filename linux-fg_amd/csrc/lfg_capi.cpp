@@ -520,6 +520,11 @@ LFG_EXPORT int lfg_motion_last_stats(lfg_context *ctx, uint32_t *out_tiles, uint
     LFG_HIP(ctx, hipMemcpy(flags.data(), ctx->motion_ws + ctx->motion_ws_layout.tileFlags, flags.size() * 4, hipMemcpyDeviceToHost));
     uint32_t fb = 0;
     for (uint32_t f : flags) fb += f != 0u;
+    if (getenv("LFG_DEBUG")) {
+        uint32_t handed = 0;
+        LFG_HIP(ctx, hipMemcpy(&handed, ctx->motion_ws + ctx->motion_ws_layout.queueCount, 4, hipMemcpyDeviceToHost));
+        fprintf(stderr, "lfg: motion prefilter: %u requests to hand a segment over (room for %d)\n", handed, ctx->motion_ws_layout.queueCap);
+    }
     if (getenv("LFG_DEBUG"))
         for (size_t i = 0; i < flags.size(); ++i)
             if (flags[i]) fprintf(stderr, "lfg: motion fallback tile (%zu, %zu)\n", i % tx, i / tx);

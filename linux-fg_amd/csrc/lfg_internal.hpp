@@ -24,7 +24,8 @@ struct AxisTable {
     float *d_weight = nullptr;    // [out_size][6]
 };
 
-struct MotionWorkspaceLayout { size_t list, umin, count, tileFlags, segDone, order, plan, auxList, auxUmin, auxCount, total; };
+struct MotionWorkspaceLayout { size_t list, umin, count, tileFlags, segDone, segMap, queueCount, order, plan, auxList, auxUmin, auxCount,
+                               queue, dynList, dynUmin, dynCount, total; int queueCap; };
 // Work units of the motion prefilter (motion.hip: prefilter_plan).  A unit is a 56 x 64 tile, or one of nChunks
 // contiguous parts of a tile's candidate order, or one 16-row segment of a tile with its four waves on four parts of
 // the order; parts have private lists in the aux arrays (merged by the resolve kernel).
@@ -36,6 +37,16 @@ struct PrefilterPlan {               // passed by value to the kernels
     uint2 *auxList;
     float *auxUmin;
     uint32_t *auxCount;
+    // Segments handed over at run time (a whole tile's segment that finds no match after the first batches): a queue
+    // of unitMap-style entries and their private lists in 16-row blocks; see motion_prefilter_kernel.
+    uint32_t *segMap;                // per (tile, segment): 0, or first block | parts << 24 | 1 << 31
+    uint32_t *queueCount;            // entries pushed this call (may exceed queueCap: the excess was not handed over)
+    uint32_t *queue;                 // [queueCap] unit entries, [queueCap] first blocks
+    int queueCap;
+    int fromQueue;                   // this launch takes its units from the queue
+    uint2 *dynList;
+    float *dynUmin;
+    uint32_t *dynCount;
 };
 struct PrefilterPlanHost {
     int tilesX = 0, tiles = 0, units = 0, auxUnits = 0;

@@ -373,8 +373,13 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
     //   * one segment of a tile: wave = one of 4 consecutive parts of the order (of nChunks), private lists --
     //     for tiles whose segments differ widely in cost, so that the waves of a workgroup finish together.
     // `seg` is the segment this wave works on, `wave` its place in the workgroup (its slab).
+    //   A whole tile's wave that still has a threshold of 510 or more after the first eight candidates -- its segment
+    //   holds pixels without a match, the partial-distortion test cannot fire, all 1089 candidates await a full
+    //   evaluation -- hands the segment over instead: it pushes a segment unit onto a queue and returns, and a second
+    //   launch of this kernel (sp.fromQueue) runs the queued segments with four waves each.
     const int unit = blockIdx.x;
-    const uint32_t um = sp.unitMap[unit];
+    if (sp.fromQueue && unit >= (int)min(*sp.queueCount, (uint32_t)sp.queueCap)) return;
+    const uint32_t um = sp.fromQueue ? sp.queue[unit] : sp.unitMap[unit];
     const bool segUnit = ((um >> 28) & 1u) != 0u;
     const int tile = (int)(um & 0xFFFFFu), nChunks = (int)((um >> 24) & 0xFu);
     const int seg = segUnit ? (int)((um >> 29) & 3u) : wave;
@@ -519,11 +524,16 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
     // Address = wave-uniform base + 32-bit lane offset; k * W is a 24-bit multiply.
     // Whole tiles write into the image-shaped arrays (row stride W), shared tiles into their unit's private
     // 56 x 64 block of the auxiliary arrays (row stride 56).
-    const int auxUnit = whole ? 0 : (int)sp.unitAux[unit] + chunk;     // unitAux: the tile's first auxiliary block
+    // (auxiliary blocks: a tile's 64 rows for the units of the plan, a segment's 16 rows for queued units)
+    const int auxUnit = whole ? 0 : (int)(sp.fromQueue ? sp.queue[sp.queueCap + unit] : sp.unitAux[unit]) + chunk;
+    const int auxRows = sp.fromQueue ? kSeg : kPTH, auxRow0 = sp.fromQueue ? kSeg * seg : 0;
+    uint2 *const auxListBase = sp.fromQueue ? sp.dynList : sp.auxList;
+    float *const auxUminBase = sp.fromQueue ? sp.dynUmin : sp.auxUmin;
+    uint32_t *const auxCountBase = sp.fromQueue ? sp.dynCount : sp.auxCount;
     const uint32_t rowStride = whole ? (uint32_t)W : (uint32_t)kPTW;
     uint2 *const waveList = whole
         ? list + ((size_t)(ty0 + kSeg * seg) * (size_t)kListK * (size_t)W + (size_t)tx0)
-        : sp.auxList + ((size_t)auxUnit * kPTH + (size_t)(kSeg * seg)) * (size_t)kListK * (size_t)kPTW;
+        : auxListBase + ((size_t)auxUnit * auxRows + (size_t)(kSeg * seg - auxRow0)) * (size_t)kListK * (size_t)kPTW;
     uint32_t laneOff[2];
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
@@ -650,7 +660,7 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
         wave_lds_sync();
     };
 
-    auto run = [&]() -> bool {
+    auto run = [&]() -> int {              // 0: done, 1: lists overflowed (tile flagged), 2: segment handed over
         uint32_t p[kSegD];
         float v8[kSeg];
         f32x2 x[kRunIn];
@@ -758,9 +768,27 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
             }
             return __ballot(need);
         };
+        int firstBatchSurvivors = 0;
         for (int i0 = 0, count = 2; i0 < nEntries; i0 += count, count = i0 == 2 ? 6 : 64) {
+            // Hand the segment over?  Either no threshold to test against after the first eight candidates, or the test
+            // let a quarter of the first full batch through.
+            if (whole && !sp.fromQueue && order32[kCand] != 0u &&
+                ((i0 == 8 && !(waveThr < 510.0f)) || (i0 == 8 + 64 && firstBatchSurvivors >= 16))) {
+                uint32_t slot = 0u;
+                if (lane == 0) slot = atomicAdd(sp.queueCount, 1u);
+                slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+                if (slot < (uint32_t)sp.queueCap) {
+                    if (lane == 0) {
+                        sp.queue[slot] = (uint32_t)tile | (4u << 24) | (1u << 28) | ((uint32_t)seg << 29);
+                        sp.queue[sp.queueCap + slot] = 4u * slot;
+                        sp.segMap[tile * (kPTH / kSeg) + seg] = (4u * slot) | (4u << 24) | (1u << 31);
+                    }
+                    return 2;
+                }
+            }
             uint32_t ordL;
             unsigned long long m = latticeBatch(i0, count, ordL);
+            if (i0 == 8) firstBatchSurvivors = __builtin_popcountll(m);
 #ifdef LFG_MOTION_STAMPS
             stampBatches += 1u; stampEvals += (unsigned)__builtin_popcountll(m);
 #endif
@@ -789,15 +817,16 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
             }
             // lists full somewhere in the tile: stop early
             if (__builtin_amdgcn_readfirstlane(__ballot(listsOverflowed()) != 0ull)) sGiveUp = 1u;
-            if (__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)&sGiveUp) != 0) return true;
+            if (__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)&sGiveUp) != 0) return 1;
             refreshZeroBound();
 #ifdef LFG_MOTION_STAMPS
             if (i0 == 0) stampFirst = __builtin_amdgcn_s_memrealtime();
 #endif
         }
-        return __builtin_amdgcn_readfirstlane(__ballot(listsOverflowed()) != 0ull);
+        return __builtin_amdgcn_readfirstlane(__ballot(listsOverflowed()) != 0ull) ? 1 : 0;
     };
-    const bool gaveUp = run();
+    const int outcome = run();
+    const bool gaveUp = outcome == 1;
 #ifdef LFG_MOTION_STAMPS
     if (lane == 0 && blockIdx.x < 8192) {
         unsigned long long *o = gMotionStamps + ((size_t)blockIdx.x * 4 + wave) * 8;
@@ -817,6 +846,7 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
         }
         if (!segUnit) return;              // (the waves of a segment unit meet at a barrier below)
     }
+    if (outcome == 2) return;              // handed over (whole tiles only: no barrier below for them)
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
         const int py = ty0 + kSeg * seg + 8 * hb + r8;
@@ -829,9 +859,9 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
                     uminOut[gp] = hb ? thr2[i].y : thr2[i].x;
                     countOut[gp] = cnt;
                 } else {
-                    const size_t ap = ((size_t)auxUnit * kPTH + (size_t)(py - ty0)) * kPTW + (size_t)(px0 + i - tx0);
-                    sp.auxUmin[ap] = hb ? thr2[i].y : thr2[i].x;
-                    sp.auxCount[ap] = cnt;
+                    const size_t ap = ((size_t)auxUnit * auxRows + (size_t)(py - ty0 - auxRow0)) * kPTW + (size_t)(px0 + i - tx0);
+                    auxUminBase[ap] = hb ? thr2[i].y : thr2[i].x;
+                    auxCountBase[ap] = cnt;
                 }
             }
         }
@@ -1038,16 +1068,26 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
     const uint32_t flagged = tileFlags[(cpy / kTH) * tilesX + cpx / kTW];
     const int ptile = (cpy / kPTH) * sp.tilesX + cpx / kPTW;
     const uint32_t tm = sp.tileMap[ptile];
+    const uint32_t sm = sp.segMap[ptile * (kPTH / kSeg) + (cpy % kPTH) / kSeg];      // segment handed over at run time?
     const bool live = inside && flagged == 0u;
     // Where this pixel's records live: one list in the image-shaped arrays, or several lists (one per unit that
-    // shared the tile's candidates) in the auxiliary arrays.  Record k of list c: recs[c * listStride + k * recStride].
-    const bool whole = tm == 0xFFFFFFFFu;
-    const int nLists = whole ? 1 : (int)(tm >> 24);
+    // shared the tile's candidates) in the auxiliary arrays -- blocks of a tile's 64 rows for the units of the plan,
+    // of a segment's 16 rows for a segment handed over at run time.  Record k of list c: recs[c * listStride + k * recStride].
+    const bool handedOver = tm == 0xFFFFFFFFu && sm != 0u;
+    const bool whole = tm == 0xFFFFFFFFu && sm == 0u;
+    const int nLists = whole ? 1 : (int)(((handedOver ? sm : tm) >> 24) & 0xFu);
     const uint2 *recs;
     const float *thrs;
     const uint32_t *cnts;
     uint32_t listStride, recStride, thrStride;
-    if (whole) {
+    if (handedOver) {
+        const size_t blk0 = (size_t)(sm & 0xFFFFFFu);
+        const int ly = cpy % kSeg, lx = cpx % kPTW;
+        recs = sp.dynList + (blk0 * kSeg + (size_t)ly) * (size_t)kListK * kPTW + (size_t)lx;
+        thrs = sp.dynUmin + (blk0 * kSeg + (size_t)ly) * kPTW + (size_t)lx;
+        cnts = sp.dynCount + (blk0 * kSeg + (size_t)ly) * kPTW + (size_t)lx;
+        listStride = (uint32_t)(kSeg * kListK * kPTW); recStride = kPTW; thrStride = (uint32_t)(kSeg * kPTW);
+    } else if (whole) {
         recs = list + (size_t)cpy * (size_t)kListK * (size_t)W + (size_t)cpx;
         thrs = uminIn + (size_t)cpy * (size_t)W + (size_t)cpx;
         cnts = countIn + (size_t)cpy * (size_t)W + (size_t)cpx;
@@ -1217,8 +1257,11 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, Motion
     l.tileFlags = align(l.count + px * sizeof(uint32_t));
     // one word per 16-row segment of a prefilter tile, right behind the flags: one memset clears both
     const size_t ptiles = (size_t)((width + kPTW - 1) / kPTW) * ((height + kPTH - 1) / kPTH);
+    // ... and behind them the map of the segments handed over at run time and the length of their queue
     l.segDone = l.tileFlags + tiles * sizeof(uint32_t);
-    l.order = align(l.segDone + ptiles * (kPTH / kSeg) * sizeof(uint32_t));   // this call's hints and visiting order
+    l.segMap = l.segDone + ptiles * (kPTH / kSeg) * sizeof(uint32_t);
+    l.queueCount = l.segMap + ptiles * (kPTH / kSeg) * sizeof(uint32_t);
+    l.order = align(l.queueCount + sizeof(uint32_t));                          // this call's hints and visiting order
     // work-unit tables and the auxiliary arrays of the shared tiles (see prefilter_plan): one 56 x 64 block per unit
     const PrefilterPlanHost plan = prefilter_plan(width, height, slots);
     const size_t auxUnits = (size_t)plan.auxUnits;
@@ -1226,7 +1269,15 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, Motion
     l.auxList = align(l.plan + (size_t)(2 * plan.units + plan.tiles) * sizeof(uint32_t));
     l.auxUmin = align(l.auxList + auxUnits * kPTH * kPTW * kListK * sizeof(uint2));
     l.auxCount = align(l.auxUmin + auxUnits * kPTH * kPTW * sizeof(float));
-    l.total = align(l.auxCount + auxUnits * kPTH * kPTW * sizeof(uint32_t));
+    // Up to a quarter of the frame's segments (2048 at most) can be handed over at run time; each gets four 16-row
+    // blocks of private lists (0.92 MB).  Beyond that a segment is searched by the wave that owns it, as before.
+    l.queueCap = (int)std::min<size_t>(2048, std::max<size_t>(1, ptiles * (kPTH / kSeg) / 4));
+    const size_t dynBlocks = (size_t)l.queueCap * 4;
+    l.queue = align(l.auxCount + auxUnits * kPTH * kPTW * sizeof(uint32_t));
+    l.dynList = align(l.queue + 2 * (size_t)l.queueCap * sizeof(uint32_t));
+    l.dynUmin = align(l.dynList + dynBlocks * kSeg * kPTW * kListK * sizeof(uint2));
+    l.dynCount = align(l.dynUmin + dynBlocks * kSeg * kPTW * sizeof(float));
+    l.total = align(l.dynCount + dynBlocks * kSeg * kPTW * sizeof(uint32_t));
     if (layout) *layout = l;
     return l.total;
 }
@@ -1403,7 +1454,7 @@ __global__ __launch_bounds__(kHintThreads) void motion_hint_kernel(
     }
     atomicMin(&sBest, best);
     __syncthreads();
-    if (tid == 0) hints[blockIdx.x] = sBest & 0x7FFu;
+    if (tid == 0) hints[blockIdx.x] = sBest;           // best SAD << 11 | candidate (scan index)
 }
 
 __global__ __launch_bounds__(256) void motion_order_kernel(
@@ -1421,7 +1472,13 @@ __global__ __launch_bounds__(256) void motion_order_kernel(
     // Hints are taken in a scrambled order of the sample blocks: under a zoom or a rotation the hints vary smoothly
     // across the frame, and in raster order a pixel would see them approach its own motion -- one running minimum
     // after the other -- which is exactly what fills the lists.
-    const uint32_t mine = hints[(tid * 97 + 13) & (kHints - 1)];
+    const uint32_t hint = hints[(tid * 97 + 13) & (kHints - 1)];
+    const uint32_t mine = hint & 0x7FFu;
+    // A sample block whose best SAD is 1020 or more has no candidate with a cost below 510 (a distance is at least
+    // half the sum of its four absolute differences): such a segment would search in full.  Handing segments over
+    // (motion_prefilter_kernel) pays when they are the exception; with a quarter of the samples unmatched it is off.
+    const uint32_t unmatched = (uint32_t)__popcll(__ballot((hint >> 11) >= 1020u));
+    if (lane == 0) sWaveSum[wv] = unmatched;
     if (mine != zero) atomicMin(&sOwner[mine], (uint32_t)tid);
     atomicAdd(&sVotes[mine], 1u);
     __syncthreads();
@@ -1432,6 +1489,7 @@ __global__ __launch_bounds__(256) void motion_order_kernel(
     __syncthreads();
     const uint32_t top = (uint32_t)(kCand - 1) - (sTop & 0x7FFu);
     if (tid == 0) {
+        order32[kCand] = (sWaveSum[0] + sWaveSum[1] + sWaveSum[2] + sWaveSum[3]) * 4u <= (uint32_t)kHints ? 1u : 0u;
         order32[0] = entryOfScan[top];
         if (top != zero) order32[1] = entryOfScan[zero];
         sRunning = top != zero ? 2u : 1u;
@@ -1481,8 +1539,16 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
     sp.auxList = reinterpret_cast<uint2 *>(workspace + l.auxList);
     sp.auxUmin = reinterpret_cast<float *>(workspace + l.auxUmin);
     sp.auxCount = reinterpret_cast<uint32_t *>(workspace + l.auxCount);
+    sp.segMap = reinterpret_cast<uint32_t *>(workspace + l.segMap);
+    sp.queueCount = reinterpret_cast<uint32_t *>(workspace + l.queueCount);
+    sp.queue = reinterpret_cast<uint32_t *>(workspace + l.queue);
+    sp.queueCap = l.queueCap;
+    sp.fromQueue = 0;
+    sp.dynList = reinterpret_cast<uint2 *>(workspace + l.dynList);
+    sp.dynUmin = reinterpret_cast<float *>(workspace + l.dynUmin);
+    sp.dynCount = reinterpret_cast<uint32_t *>(workspace + l.dynCount);
     uint32_t *segDone = reinterpret_cast<uint32_t *>(workspace + l.segDone);
-    hipError_t e = hipMemsetAsync(flags, 0, l.order - l.tileFlags, s);             // tile flags and segment marks
+    hipError_t e = hipMemsetAsync(flags, 0, l.order - l.tileFlags, s);             // tile flags, segment marks and map, queue length
     if (e != hipSuccess) return e;
     if (useHints && curr.width >= 64u && curr.height >= 64u) {         // this call's visiting order
         uint32_t *hints = reinterpret_cast<uint32_t *>(workspace + l.order);
@@ -1501,6 +1567,16 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
                        (int8_t *)mv.data, (int)mv.pitch, rank2scan, segDone);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
+    {   // the segments handed over: one workgroup per queue slot, the unused ones return at once
+        PrefilterPlan sq = sp;
+        sq.fromQueue = 1;
+        hipLaunchKernelGGL(motion_prefilter_kernel, dim3(sq.queueCap), dim3(kPNT), 0, s,
+                           (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
+                           (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, order, sq,
+                           (int8_t *)mv.data, (int)mv.pitch, rank2scan, segDone);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
 #ifdef LFG_MOTION_STAMPS
     {
         static int calls = 0;

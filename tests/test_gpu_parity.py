@@ -328,6 +328,29 @@ def test_motion_modes_agree_on_benchmark_frames_and_occlusions(ctx):
     assert stats[1] == 0
 
 
+def test_motion_hand_over_queue_overflows_gracefully(ctx):
+    """Segments that find no match are handed to a second launch through a queue with room for a quarter of the
+    frame's segments, unless the hint samples say that most of the frame is unmatched.  Here the hint samples see a
+    clean translation (islands around the 16 x 16 sample points are left intact) while everything else in curr is fresh
+    noise: nearly every segment asks to be handed over, the queue fills up, the rest search in place -- and the vectors
+    still equal the literal kernel's."""
+    from linux_fg_amd import capi
+    W, H = 3840, 2160
+    prev = synth.make_prev(W, H, seed=synth.BASE_SEED + 9)
+    curr = synth.noise_bytes(W, H, 777)
+    moved = synth.translate(prev, (5, 3), synth.BASE_SEED + 9)
+    for gy in range(16):
+        for gx in range(16):
+            cx, cy = (2 * gx + 1) * W // 32, (2 * gy + 1) * H // 32
+            curr[cy - 14:cy + 14, cx - 14:cx + 14] = moved[cy - 14:cy + 14, cx - 14:cx + 14]
+    a, stats = run_motion_mode(ctx, prev, curr, capi.MOTION_PREFILTERED)
+    b, _ = run_motion_mode(ctx, prev, curr, capi.MOTION_EXACT_ONLY)
+    assert (a == b).all(), f"{(a != b).any(-1).sum()} pixels differ"
+    assert stats[1] == 0
+    cy, cx = H // 32, W // 32
+    assert tuple(a[cy, cx]) == (-5, -3)                     # inside an island the translation is found
+
+
 def test_three_stages_at_8k(ctx, oracle):
     """BASELINE config 5 size (4K -> 8K, three interpolation factors): scale against the oracle on regions, motion by
     the translation property and against the literal kernel everywhere, interpolate exact on regions for each factor."""
