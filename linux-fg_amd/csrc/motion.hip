@@ -719,6 +719,11 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
             const float f2 = __builtin_bit_cast(float, __builtin_amdgcn_udot4(cT, texel, 0x4B800000u, false));
             return (f1 - f2) + 8388608.0f;
         };
+#ifndef LFG_ONEPOINT_MAX
+#define LFG_ONEPOINT_MAX 32.0f
+#endif
+        constexpr float kOnePointMax = LFG_ONEPOINT_MAX;   // below: the one-point test alone (cheap, and strong while thresholds are small)
+        bool useFourPoint = true;
         // bit k of the result: candidate i0 + k of the staged order has to be evaluated in full
         auto latticeBatch = [&](int i0, int count, uint32_t &ordL) -> unsigned long long {
             uint32_t l;                    // lane number; volatile, so that it is not hoisted out of the loop and spilled
@@ -766,6 +771,63 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
                 const float thrSq = (waveThr * waveThr) * 1.000001f;
                 need = need & !(dMin > __builtin_bit_cast(uint32_t, thrSq));
             }
+#ifndef LFG_FOURPOINT_MAX
+#define LFG_FOURPOINT_MAX (4.0f * 510.0f)
+#endif
+            // (only where the one-point test has just let more than an eighth of the batch through, and not any more once
+            //  a full batch came out of it three quarters intact: segments that search in full anyway stop paying for it)
+            if (useFourPoint && !(waveThr < kOnePointMax) && waveThr < LFG_FOURPOINT_MAX && __builtin_popcountll(__ballot(need)) > 8) {
+                // FOUR-point test, for thresholds a single distance rarely exceeds (a match under sensor noise costs a
+                // few hundred).  Block positions = 0 mod 4 form a lattice of 6 x 16 points of which every pixel's
+                // 8 x 8 block holds exactly a 2 x 2 group (columns 4a, 4a + 4 with a = ceil(i / 4) for pixel column
+                // i, rows likewise), and S~ >= (the sum of those four distances) (1 - 8.1 u): S~ adds the same
+                // rounded distances in a depth-6 tree (factor (1-u)^6 at worst), the group sum in two levels
+                // ((1+u)^2 at most).  If every group's sum exceeds waveThr (1 + 2^-19), no pixel passes.
+                // Positions outside the image add nothing to S~ and nothing here; groups that no pixel inside the
+                // image maps to are left out.  Walks the lattice column by column: six distances, five vertical
+                // pair sums, five group sums with the previous column's.
+                const lds_ro_u32_ptr w = (lds_ro_u32_ptr)(sWin + kSeg * seg) + (ordL >> 16);
+                auto bitsOf = [](float d) { return __builtin_bit_cast(uint32_t, d); };
+                uint32_t pMin = 0x7F800000u;
+                float vPrev[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int a = 0; a < 16; ++a) {
+                    const int col = 4 * a;
+                    // (the lane select goes through an empty asm: the current-frame texels are the same in every batch,
+                    //  and hoisted out of the batch loop their 96 scalar registers are spilled)
+                    int colL = col, tx0L = tx0, rowsL = ty0 + kSeg * seg;
+                    asm volatile("" : "+s"(colL), "+s"(tx0L), "+s"(rowsL));
+                    uint32_t tex[6];
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) tex[b] = w[col * kWinH + 4 * b];
+                    const uint32_t inImage = border ? (uint32_t)__builtin_amdgcn_readlane((int)valid, colL) : 0xFFFFFFFFu;
+                    float d[6];
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) {
+                        const float dd = __builtin_amdgcn_sqrtf(distanceOf((uint32_t)__builtin_amdgcn_readlane((int)c[4 * b], colL), tex[b]));
+                        const uint32_t keep = 0u - ((inImage >> (4 * b)) & 1u);        // scalar: all ones or zero
+                        d[b] = border ? __builtin_bit_cast(float, bitsOf(dd) & keep) : dd;
+                    }
+                    float v[5];
+#pragma unroll
+                    for (int b = 0; b < 5; ++b) v[b] = d[b] + d[b + 1];
+                    if (a > 0) {
+                        // group (a - 1, b): its first pixel is (max(0, 4 (a-1) - 3), max(0, 4 b - 3))
+                        const bool colInImage = !border || tx0L + max(0, 4 * (a - 1) - 3) < W;
+#pragma unroll
+                        for (int b = 0; b < 5; ++b) {
+                            const bool relevant = colInImage && (!border || rowsL + max(0, 4 * b - 3) < H);
+                            const uint32_t g = bitsOf(vPrev[b] + v[b]);
+                            pMin = min(pMin, relevant ? g : 0x7F800000u);
+                        }
+                    }
+#pragma unroll
+                    for (int b = 0; b < 5; ++b) vPrev[b] = v[b];
+                    if (a & 1) __builtin_amdgcn_sched_barrier(0);      // two columns' reads in flight, not all sixteen's
+                }
+                need = need & !(pMin > bitsOf(waveThr * 1.000002f));
+                if (count == 64 && __builtin_popcountll(__ballot(need)) >= 48) useFourPoint = false;
+            }
             return __ballot(need);
         };
         int firstBatchSurvivors = 0;
@@ -773,7 +835,7 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
             // Hand the segment over?  Either no threshold to test against after the first eight candidates, or the test
             // let a quarter of the first full batch through.
             if (whole && !sp.fromQueue && order32[kCand] != 0u &&
-                ((i0 == 8 && !(waveThr < 510.0f)) || (i0 == 8 + 64 && firstBatchSurvivors >= 16))) {
+                ((i0 == 8 && !(waveThr < 4.0f * 510.0f)) || (i0 == 8 + 64 && firstBatchSurvivors >= 16))) {
                 uint32_t slot = 0u;
                 if (lane == 0) slot = atomicAdd(sp.queueCount, 1u);
                 slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);

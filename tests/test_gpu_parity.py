@@ -328,6 +328,25 @@ def test_motion_modes_agree_on_benchmark_frames_and_occlusions(ctx):
     assert stats[1] == 0
 
 
+@pytest.mark.parametrize("amp", [1, 2, 6])
+def test_motion_modes_agree_under_sensor_noise(ctx, amp):
+    """A translated frame with +-amp levels of independent noise in every channel: matches cost a few hundred instead
+    of zero, the one-point partial-distortion test rarely fires and the four-point sums (interior and rim variants)
+    carry the search.  Prefiltered path == literal kernel; the translation is still found away from the rim."""
+    from linux_fg_amd import capi
+    W, H = 1920, 1080
+    prev = synth.make_prev(W, H, seed=synth.BASE_SEED + 21)
+    moved = synth.translate(prev, (-4, 7), synth.BASE_SEED + 21)
+    n = synth.noise_bytes(W, H, 31337 + amp) % (2 * amp + 1)
+    curr = np.clip(moved.astype(np.int16) + n.astype(np.int16) - amp, 0, 255).astype(np.uint8)
+    a, stats = run_motion_mode(ctx, prev, curr, capi.MOTION_PREFILTERED)
+    b, _ = run_motion_mode(ctx, prev, curr, capi.MOTION_EXACT_ONLY)
+    assert (a == b).all(), f"{(a != b).any(-1).sum()} pixels differ"
+    assert stats[1] == 0
+    inner = a[40:H - 40, 40:W - 40]
+    assert (inner[..., 0] == 4).mean() > 0.999 and (inner[..., 1] == -7).mean() > 0.999
+
+
 def test_motion_hand_over_queue_overflows_gracefully(ctx):
     """Segments that find no match are handed to a second launch through a queue with room for a quarter of the
     frame's segments, unless the hint samples say that most of the frame is unmatched.  Here the hint samples see a
