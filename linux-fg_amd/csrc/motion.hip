@@ -786,7 +786,7 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
                 // Positions outside the image add nothing to S~ and nothing here; groups that no pixel inside the
                 // image maps to are left out.  Walks the lattice column by column: six distances, five vertical
                 // pair sums, five group sums with the previous column's.
-                const lds_ro_u32_ptr w = (lds_ro_u32_ptr)(sWin + kSeg * seg) + (ordL >> 16);
+                lds_ro_u32_ptr w = (lds_ro_u32_ptr)(sWin + kSeg * seg) + (ordL >> 16);
                 auto bitsOf = [](float d) { return __builtin_bit_cast(uint32_t, d); };
                 uint32_t pMin = 0x7F800000u;
                 float vPrev[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -823,7 +823,9 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
                     }
 #pragma unroll
                     for (int b = 0; b < 5; ++b) vPrev[b] = v[b];
-                    if (a & 1) __builtin_amdgcn_sched_barrier(0);      // two columns' reads in flight, not all sixteen's
+                    // Two columns' reads in flight, not all sixteen's (96 texels read up front end up in scratch): the next
+                    // pair's addresses are made to wait for this pair's result.
+                    if (a & 1) asm volatile("" : "+v"(w), "+v"(pMin));
                 }
                 need = need & !(pMin > bitsOf(waveThr * 1.000002f));
                 if (count == 64 && __builtin_popcountll(__ballot(need)) >= 48) useFourPoint = false;

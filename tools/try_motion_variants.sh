@@ -14,6 +14,11 @@ W, H = 3840, 2160
 import os
 if os.environ.get('CONTENT') == 'uncorrelated':
     pin, cin = synth.make_uncorrelated_pair(W // 2, H // 2)
+elif os.environ.get('CONTENT') == 'noisy':
+    import numpy as np
+    pin = synth.make_prev(W // 2, H // 2, seed=synth.BASE_SEED); cin = synth.translate(pin, (3, -2), synth.BASE_SEED)
+    n = synth.noise_bytes(W // 2, H // 2, (synth.BASE_SEED + 15485863) & 0xFFFFFFFF) % 5
+    cin = np.clip(cin.astype(np.int16) + n.astype(np.int16) - 2, 0, 255).astype(np.uint8)
 else:
     pin = synth.make_prev(W // 2, H // 2, seed=synth.BASE_SEED); cin = synth.translate(pin, (3, -2), synth.BASE_SEED)
 Pin, Cin = ctx.frame_from(pin), ctx.frame_from(cin)
