@@ -73,6 +73,9 @@ def algorithmic_bytes(stage: str, w_in: int, h_in: int, w: int, h: int) -> int:
     raise ValueError(stage)
 
 
+PREFILTER_LAUNCHES_PER_CALL = 2          # motion_prefilter_kernel: the plan's units, then the queue of segments handed over
+
+
 def pmc_traffic(kernel_prefixes):
     """HBM bytes per launch of the kernels whose names start with one of `kernel_prefixes`, summed, from the
     newest committed two-pass PMC summary (profiles/rNN_hbm_traffic_pmc.txt: FETCH_SIZE and WRITE_SIZE
@@ -91,7 +94,10 @@ def pmc_traffic(kernel_prefixes):
             cur = line.split(": launches")[0].replace("void ", "").split("<")[0].split("(")[0].strip()
         m = re.match(r"^\s+(FETCH_SIZE|WRITE_SIZE)\s+([0-9.e+]+)", line)
         if m and cur and any(cur.startswith(k) for k in kernel_prefixes):
-            vals[(cur, m.group(1))] = float(m.group(2)) * 1024.0        # the last block of a kernel wins
+            # (the summary averages over launches; lfg_motion launches the prefilter twice: the tiles, then the segments
+            #  handed over -- an almost empty launch on the benchmark frames -- so a call is two launches)
+            per_call = PREFILTER_LAUNCHES_PER_CALL if cur.startswith("lfg::motion_prefilter") else 1
+            vals[(cur, m.group(1))] = float(m.group(2)) * 1024.0 * per_call       # the last block of a kernel wins
     have = {k for k, _ in vals}
     if have and all((k, c) in vals for k in have for c in ("FETCH_SIZE", "WRITE_SIZE")):
         return int(sum(vals.values())), os.path.relpath(files[-1], ROOT)
@@ -120,10 +126,12 @@ def pmc_executed(kernel_prefix):
     if not {"mean_us", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU"} <= set(out):
         return None
     simds, clock_hz = 1024, 2.4e9                       # 256 CUs x 4 SIMDs, peak engine clock
+    n = PREFILTER_LAUNCHES_PER_CALL if kernel_prefix.startswith("lfg::motion_prefilter") else 1   # the summary averages over launches
     slots = out["mean_us"] * 1e-6 * clock_hz * simds
-    return {"source": os.path.relpath(files[-1], ROOT), "kernel_us_in_that_pass": out["mean_us"],
-            "valu_wave_instructions": out["SQ_INSTS_VALU"], "lds_wave_instructions": out["SQ_INSTS_LDS"],
-            "salu_wave_instructions": out["SQ_INSTS_SALU"],
+    return {"source": os.path.relpath(files[-1], ROOT), "kernel_us_per_call_in_that_pass": round(out["mean_us"] * n, 2),
+            "launches_per_call": n,
+            "valu_wave_instructions": out["SQ_INSTS_VALU"] * n, "lds_wave_instructions": out["SQ_INSTS_LDS"] * n,
+            "salu_wave_instructions": out["SQ_INSTS_SALU"] * n,
             "valu_issue_utilisation": round(out["SQ_INSTS_VALU"] * 4.0 / slots, 3),
             "how": "VALU wave-instructions x 4 cycles / (duration x 2.4 GHz x 1024 SIMDs): the share of the VALU issue "
                    "slots the kernel filled -- the utilisation figure that `frac` (an algorithmic rate) is not"}
