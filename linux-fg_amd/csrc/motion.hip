@@ -271,14 +271,20 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
 // exact minimum while  S~(m) <= kRatio * min_j S~(j),  kRatio = 1 + 8e-5 >= (1+3.6e-5)/(1-3.6e-5) with room
 // for the rounding of the product.
 //
-//   motion_prefilter_kernel  for every candidate: per-position distances -> 8-row column sums (registers) ->
-//       8-column row sums = S~ per pixel; a candidate is recorded in the pixel's list when
-//       S~ <= kRatio * (min of S~ over the candidates seen so far) (it may still be the exact minimum); at
-//       most kListK per pixel, else the tile is flagged and left to the exact kernel.  Candidates are
-//       visited in a fixed pseudo-random order (see motion_candidate_order).
-//   motion_resolve_kernel    per pixel: the recorded candidates that pass the final bound (typically
-//       one) get the literal chain of motion.comp:33-47; the smallest (cost, scan index) wins, which is
-//       the shader's first strict minimum in scan order.
+//   motion_hint_kernel, motion_order_kernel   this call's visiting order: the SAD-best candidates of 256 sample
+//       blocks in front (most popular first), then a fixed pseudo-random order of the rest.
+//   motion_prefilter_kernel  a wave owns a 16-row segment of a 56 x 64 tile.  Per BATCH of up to 64 candidates (one
+//       per lane) a partial-distortion test drops every candidate whose distances at a lattice of block positions
+//       already exceed all of the segment's thresholds (one point per block, then 2 x 2 sums; see run()).  The
+//       survivors are evaluated in full: per-position distances -> 8-row column sums (registers) -> 8-column row
+//       sums = S~ per pixel; a candidate is recorded in the pixel's list when S~ <= kRatio * (min of S~ over the
+//       candidates seen so far) (it may still be the exact minimum); at most kListK per pixel, else the tile is
+//       flagged and left to the exact kernel.  Work units (prefilter_plan): whole tiles; rim tiles as one
+//       workgroup per segment with its four waves on quarters of the order; segments of whole tiles that find no
+//       match are handed over through a queue to a second launch.  Easy pixels are settled in the kernel itself.
+//   motion_resolve_kernel    per remaining pixel: the recorded candidates that pass the final bound (typically
+//       one) get the literal chain of motion.comp:33-47; the smallest (cost, rank in the tie order) wins, which
+//       is the shader's first strict minimum in scan order.
 //   motion_tiled_8_16_kernel with the tile flags: full exact evaluation of the flagged tiles (flat or
 //       finely tied content, where every candidate survives the filter).
 // Every exact minimiser m* is recorded and survives: S~(m*)(1-3.6e-5) <= 255 S(m*) <= 255 S(j) <=
@@ -299,10 +305,10 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
 //     ds_read2_b32 per input pair, all 32 banks distinct);
 //   * row sums, per lane two runs of 7 pixels (rows r and r+8) packed side by side: 14 input pairs -> shared
 //     pairwise tree (31 packed adds) -> 7 + 7 S~, threshold test, list append.
-//   LDS: 38.2 KB window + 4 x 2.1 KB slabs = 46.9 KB -> three workgroups (12 waves) per CU.  DS operations of
-//   one wave execute in order, so a slab needs neither double buffering nor barriers.  Loop order per
-//   candidate e: window reads(e+1) issued | row sums + test(e) | column sums(e+1) | slab write/read(e+1);
-//   the slab round trip is the one exposed latency, covered by the other two waves of the SIMD.
+//   LDS: 38.2 KB window + 4 x 2.1 KB slabs + 4.3 KB visiting order = 51 KB -> three workgroups (12 waves) per CU.
+//   DS operations of one wave execute in order, so a slab needs neither double buffering nor barriers.  Loop order
+//   per surviving candidate e: window reads(e+1) issued | row sums + test(e) | column sums(e+1) | slab
+//   write/read(e+1); the slab round trip is the one exposed latency, covered by the other two waves of the SIMD.
 
 constexpr int kPTW = 56, kPTH = 64;               // prefilter tile (pixels): 56 + 7 = 63 position columns <= 64 lanes
 constexpr int kPNT = 256;
