@@ -687,6 +687,27 @@ def test_intended_motion_matches_oracle(intended, oracle, name):
         assert (want != as_int(oracle.motion(prev, curr))).any()
 
 
+def test_intended_motion_large_frame_mechanisms(intended):
+    """1080p frames, where tiles are whole work units: hand-over (noise patches), four-point sums (sensor noise),
+    plateaus at the rim and flat areas with ties, all under the intended tie order -- prefiltered path == literal
+    kernel."""
+    from linux_fg_amd import capi
+    W, H = 1920, 1080
+    prev = synth.make_prev(W, H, seed=synth.BASE_SEED + 33)
+    curr = synth.translate(prev, (6, -9), synth.BASE_SEED + 33)
+    n = synth.noise_bytes(W, H, 99) % 5
+    curr = np.clip(curr.astype(np.int16) + n.astype(np.int16) - 2, 0, 255).astype(np.uint8)
+    fresh = synth.noise_bytes(W, H, 4711)
+    for (x0, y0, w, h) in [(300, 200, 120, 90), (1000, 500, 64, 200), (1500, 900, 250, 40)]:
+        curr[y0:y0 + h, x0:x0 + w] = fresh[y0:y0 + h, x0:x0 + w]
+    prev[600:700, 100:400] = 37                            # a flat area, static: ties at cost 0
+    curr[600:700, 100:400] = 37
+    a, stats = run_motion_mode(intended, prev, curr, capi.MOTION_PREFILTERED)
+    b, _ = run_motion_mode(intended, prev, curr, capi.MOTION_EXACT_ONLY)
+    assert (a == b).all(), f"{(a != b).any(-1).sum()} pixels differ"
+    assert (a[640:660, 200:300] == 0).all()                # the flat area reports the shortest vector
+
+
 def test_intended_motion_generic_parameters(intended, oracle):
     prev = synth.make_prev(50, 34, seed=21)
     prev[10:30, 5:40] = (7, 7, 7, 255)                                   # a flat patch: ties
