@@ -407,29 +407,57 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
     const int nHead = chunk > 0 ? kHead : 0;
     for (int i = tid; i < kCand; i += kPNT) sOrder[i] = order32[i];
 
-    // ---- search window: prev(bx0 - R + wx, by0 - R + wy), zero outside the image (texelFetch semantics)
-    // (thirteen loads in flight per thread: one at a time, the 39 rounds cost 39 memory latencies; a segment unit
-    //  stages its own 55 rows only)
-    constexpr int kStageAhead = 13;
+    // ---- search window: prev(bx0 - R + wx, by0 - R + wy), zero outside the image (texelFetch semantics); a segment
+    // unit stages its own 55 rows only.  Staging is a latency chain (load -> LDS store), so everything a thread loads is
+    // in flight at once: ten 16-byte loads of four texels each -- the window starts 20 texels left of a tile whose
+    // origin is a multiple of 56, so its groups of four are 16-byte aligned and, when the width is a multiple of four,
+    // lie inside the image or outside it as a whole.  Other pitches and widths take single texels, thirteen in flight.
     const int stageRow0 = segUnit ? kSeg * seg : 0;
-    const int stageTexels = (segUnit ? kSegD + 2 * kR : kWinH) * kWinW;
-    for (int r0 = 0; r0 * kPNT < stageTexels; r0 += kStageAhead) {
-        uint32_t v[kStageAhead];
+    const int stageRows = segUnit ? kSegD + 2 * kR : kWinH;
+    if ((W & 3) == 0 && (prevPitch & 15) == 0 && ((uintptr_t)prev & 15u) == 0u) {
+        constexpr int kGroups = (kWinW + 3) / 4;                       // 24 groups per window row (the last holds 3 texels)
+        constexpr int kRounds = (kWinH * kGroups + kPNT - 1) / kPNT;   // 10
+        uint4 v[kRounds];
 #pragma unroll
-        for (int k = 0; k < kStageAhead; ++k) {
-            const int i = (r0 + k) * kPNT + tid;
-            const int wy = stageRow0 + i / kWinW, wx = i % kWinW;      // global reads stay row-major (coalesced)
-            const int gx = bx0 - kR + wx, gy = by0 - kR + wy;
-            // branch-free: the load goes to the nearest texel inside the image and is dropped afterwards
-            const uint32_t t = *reinterpret_cast<const uint32_t *>(prev + (size_t)clampi(gy, 0, H - 1) * (size_t)prevPitch +
-                                                                   (size_t)clampi(gx, 0, W - 1) * 4u);
-            v[k] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? t : 0u;
+        for (int k = 0; k < kRounds; ++k) {
+            const int i = k * kPNT + tid;
+            const int wy = stageRow0 + i / kGroups, g = i % kGroups;
+            const int gx = bx0 - kR + 4 * g, gy = by0 - kR + wy;
+            // branch-free: the load goes to the nearest group inside the image and is dropped afterwards
+            const uint4 t = *reinterpret_cast<const uint4 *>(prev + (size_t)clampi(gy, 0, H - 1) * (size_t)prevPitch +
+                                                             (size_t)clampi(gx, 0, W - 4) * 4u);
+            v[k] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? t : uint4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
-        for (int k = 0; k < kStageAhead; ++k) {
-            const int i = (r0 + k) * kPNT + tid;
-            const int wy = stageRow0 + i / kWinW, wx = i % kWinW;
-            if (i < stageTexels) sWin[wx * kWinH + wy] = v[k];
+        for (int k = 0; k < kRounds; ++k) {
+            const int i = k * kPNT + tid;
+            const int wy = stageRow0 + i / kGroups, g = i % kGroups;
+            if (i < stageRows * kGroups) {
+                uint32_t *dst = sWin + (4 * g) * kWinH + wy;
+                dst[0] = v[k].x; dst[kWinH] = v[k].y; dst[2 * kWinH] = v[k].z;
+                if (4 * g + 3 < kWinW) dst[3 * kWinH] = v[k].w;
+            }
+        }
+    } else {
+        constexpr int kStageAhead = 13;
+        const int stageTexels = stageRows * kWinW;
+        for (int r0 = 0; r0 * kPNT < stageTexels; r0 += kStageAhead) {
+            uint32_t v[kStageAhead];
+#pragma unroll
+            for (int k = 0; k < kStageAhead; ++k) {
+                const int i = (r0 + k) * kPNT + tid;
+                const int wy = stageRow0 + i / kWinW, wx = i % kWinW;  // global reads stay row-major (coalesced)
+                const int gx = bx0 - kR + wx, gy = by0 - kR + wy;
+                const uint32_t t = *reinterpret_cast<const uint32_t *>(prev + (size_t)clampi(gy, 0, H - 1) * (size_t)prevPitch +
+                                                                       (size_t)clampi(gx, 0, W - 1) * 4u);
+                v[k] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? t : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < kStageAhead; ++k) {
+                const int i = (r0 + k) * kPNT + tid;
+                const int wy = stageRow0 + i / kWinW, wx = i % kWinW;
+                if (i < stageTexels) sWin[wx * kWinH + wy] = v[k];
+            }
         }
     }
 
