@@ -738,11 +738,7 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
         // runs at issue rate, and one ballot gives the candidates that survive.  The thresholds a batch is tested
         // against are those at its start; the first two batches are short (zero motion and the first hint, then six
         // more) so that the long ones start with thresholds worth testing against.
-#ifdef LFG_DBG_MAXENTRIES          // timing experiments only (wrong results): visit the first entries of the order only
-        const int nEntries = min(nHead + eEnd - eBegin, LFG_DBG_MAXENTRIES);
-#else
         const int nEntries = nHead + eEnd - eBegin;                    // the head, then this wave's part of the order
-#endif
         int border = borderTile;
         asm volatile("" : "+s"(border));   // one copy of the loop below, not one per kind of tile
         // The SQUARED distance n (an exact integer, same arithmetic as columnSums) is enough here: the lattice test
@@ -1267,9 +1263,6 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
 #ifdef LFG_MOTION_STAMPS
     if (survivors > 1u) { atomicAdd(&gResolveStats[0], 1ull); atomicAdd(&gResolveStats[1], (unsigned long long)survivors);
                           atomicAdd(&gResolveStats[2], (unsigned long long)(px < 64 || py < 64 || px >= W - 64 || py >= H - 64)); }
-#endif
-#ifdef LFG_DBG_NOCOOP          // timing experiments only (wrong results)
-    todo = 0ull;
 #endif
     while (todo != 0ull) {
         const int L = __builtin_ctzll(todo);
