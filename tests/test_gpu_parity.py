@@ -347,6 +347,61 @@ def test_motion_modes_agree_under_sensor_noise(ctx, amp):
     assert (inner[..., 0] == 4).mean() > 0.999 and (inner[..., 1] == -7).mean() > 0.999
 
 
+def _mixed_pair(w, h, seed):
+    """A frame pair that mixes what the prefilter treats differently: a translation, sensor noise on part of the
+    frame, patches of fresh noise, a static flat area and a flat area one level apart (ties at a non-zero cost)."""
+    rng = np.random.default_rng(seed)
+    prev = synth.make_prev(w, h, seed=seed)
+    shift = (int(rng.integers(-12, 13)), int(rng.integers(-12, 13)))
+    curr = synth.translate(prev, shift, seed)
+    if rng.random() < 0.7:                                   # sensor noise on a band of rows
+        y0, y1 = sorted(int(v) for v in rng.integers(0, h, 2))
+        amp = int(rng.integers(1, 5))
+        n = synth.noise_bytes(w, h, seed + 1) % (2 * amp + 1)
+        noisy = np.clip(curr.astype(np.int16) + n.astype(np.int16) - amp, 0, 255).astype(np.uint8)
+        curr[y0:y1] = noisy[y0:y1]
+    fresh = synth.noise_bytes(w, h, seed + 2)
+    for _ in range(int(rng.integers(0, 4))):                 # occlusions
+        pw, ph = int(rng.integers(4, max(5, w // 6))), int(rng.integers(4, max(5, h // 6)))
+        x0, y0 = int(rng.integers(0, w - pw)), int(rng.integers(0, h - ph))
+        curr[y0:y0 + ph, x0:x0 + pw] = fresh[y0:y0 + ph, x0:x0 + pw]
+    if rng.random() < 0.5:                                   # static flat area (zero-cost ties)
+        pw, ph = int(rng.integers(8, max(9, w // 4))), int(rng.integers(8, max(9, h // 4)))
+        x0, y0 = int(rng.integers(0, w - pw)), int(rng.integers(0, h - ph))
+        prev[y0:y0 + ph, x0:x0 + pw] = 90
+        curr[y0:y0 + ph, x0:x0 + pw] = 90
+    if rng.random() < 0.3:                                   # a small fade (non-zero ties: overflow, exact-kernel tiles)
+        pw, ph = int(rng.integers(20, 60)), int(rng.integers(20, 60))
+        x0, y0 = int(rng.integers(0, max(1, w - pw))), int(rng.integers(0, max(1, h - ph)))
+        prev[y0:y0 + ph, x0:x0 + pw] = 50
+        curr[y0:y0 + ph, x0:x0 + pw] = 51
+    return prev, curr
+
+
+@pytest.mark.parametrize("case", range(60))
+def test_motion_modes_agree_on_random_mixtures(ctx, case):
+    """Seeded fuzz over frame sizes and content mixtures: small frames (tiles shared between workgroups), mid-size
+    and 1080p-class frames (whole tiles, rim segment units, hand-over, both partial-distortion tests, plateaus,
+    overflowing tiles) -- the prefiltered path must equal the literal kernel bit for bit."""
+    from linux_fg_amd import capi
+    rng = np.random.default_rng(9000 + case)
+    if case % 3 == 0:
+        w, h = int(rng.integers(64, 400)), int(rng.integers(64, 300))
+    elif case % 3 == 1:
+        w, h = int(rng.integers(400, 1300)), int(rng.integers(300, 900))
+    else:
+        w, h = int(rng.integers(1300, 2100)), int(rng.integers(1000, 1300))
+    prev, curr = _mixed_pair(w, h, 9000 + case)
+    if case % 5 == 4:                                        # every fifth case under the opt-in tie order
+        ctx.set_semantics(capi.SEMANTICS_INTENDED)
+    try:
+        a, _ = run_motion_mode(ctx, prev, curr, capi.MOTION_PREFILTERED)
+        b, _ = run_motion_mode(ctx, prev, curr, capi.MOTION_EXACT_ONLY)
+    finally:
+        ctx.set_semantics(capi.SEMANTICS_REFERENCE)
+    assert (a == b).all(), f"{(a != b).any(-1).sum()} pixels differ at {w}x{h}"
+
+
 def test_motion_hand_over_queue_overflows_gracefully(ctx):
     """Segments that find no match are handed to a second launch through a queue with room for a quarter of the
     frame's segments, unless the hint samples say that most of the frame is unmatched.  Here the hint samples see a
