@@ -761,7 +761,10 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
             const int idx = i0 + (int)l;
             ordL = ((lds_ro_u32_ptr)sOrder)[min(idx < nHead ? idx : eBegin + (idx - nHead), kCand - 1)];
             bool need = (int)l < count && idx < nEntries && (ordL & 0xFFFFu) < zeroBound;
-            if (waveThr < 510.0f) {                                    // a distance is at most sqrt(4 * 255^2) = 510
+#ifndef LFG_ONEPOINT_OFF
+#define LFG_ONEPOINT_OFF 96.0f
+#endif
+            if (waveThr < LFG_ONEPOINT_OFF) {                          // (a distance is at most 510, but few exceed a threshold of a hundred)
                 const lds_ro_u32_ptr w = (lds_ro_u32_ptr)(sWin + kSeg * seg) + (ordL >> 16);
                 // the candidate's smallest squared lattice distance, as bits: non-negative floats, whose order is
                 // the order of their bit patterns (one v_min_u32 per point, no NaN handling)
