@@ -31,4 +31,5 @@ for c in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WA
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_sq -- python3 $R/tools/run_stage.py motion 2 > /dev/null 2>&1
 done
 python3 $R/tools/pmc_summary.py /tmp/pmc_sq | sed "s#/tmp/##" > $OUT/${TAG}_motion_sq_counters.txt
+bash $R/tools/bench_contents.sh > $OUT/${TAG}_content_table.txt 2>&1
 echo "pmc done"; ls -la $OUT
