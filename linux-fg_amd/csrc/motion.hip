@@ -865,6 +865,37 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
             }
             return __ballot(need);
         };
+        // A window of ONE colour (zero fill included) makes every candidate of every pixel of the segment read the same
+        // prev texel at every block position: all 1089 costs are the same operations on the same values, equal to the
+        // last bit, and the first candidate in tie order wins whatever curr holds.  Flat areas whose brightness changes
+        // (a fade over letterbox bars, a flat background) would otherwise tie at a non-zero cost, overflow the lists
+        // and send the tile through the exact kernel.  The answer is carried like a zero-cost one: rank 0 inside the
+        // threshold word, no records, and the usual paths turn it into the vector.  (Checked in chunks of eleven
+        // rows; textured content leaves after the first.)
+        {
+            const lds_ro_u32_ptr wb = (lds_ro_u32_ptr)(sWin + kSeg * seg);
+            const uint32_t ref = wb[0];
+            const int colA = lane, colB = lane + (kWinW - 64);         // 0..63 and 31..94: all 95 window columns
+            bool flat = true;
+            constexpr int kRows = kSegD + 2 * kR;                      // 55 window rows serve this segment
+            for (int r0 = 0; r0 < kRows && flat; r0 += kRows / 5) {
+                bool same = true;
+#pragma unroll
+                for (int r = 0; r < kRows / 5; ++r)
+                    same = same && wb[colA * kWinH + r0 + r] == ref && wb[colB * kWinH + r0 + r] == ref;
+                flat = __builtin_amdgcn_readfirstlane(__ballot(!same) == 0ull);
+            }
+            if (flat) {
+                const float first = __builtin_bit_cast(float, 0x00800000u);          // "zero-cost" word of rank 0
+#pragma unroll
+                for (int i = 0; i < kRun; ++i) {
+                    const float fx = thr2[i].x, fy = thr2[i].y;        // +inf inside the image, -inf outside
+                    thr2[i].x = fx > 0.0f ? first : fx;
+                    thr2[i].y = fy > 0.0f ? first : fy;
+                }
+                return 0;
+            }
+        }
         int firstBatchSurvivors = 0;
         for (int i0 = 0, count = 2; i0 < nEntries; i0 += count, count = i0 == 2 ? 6 : 64) {
             // Hand the segment over?  Either no threshold to test against after the first eight candidates, or the test

@@ -347,6 +347,29 @@ def test_motion_modes_agree_under_sensor_noise(ctx, amp):
     assert (inner[..., 0] == 4).mean() > 0.999 and (inner[..., 1] == -7).mean() > 0.999
 
 
+def test_motion_flat_areas_with_a_brightness_change(ctx, oracle):
+    """Flat frames one grey level apart: every candidate ties at a non-zero cost.  Where the whole search window is
+    one colour the prefilter knows the answer (the first candidate in tie order) without a search; tiles at the rim
+    (zero fill in the window) and at the edge of a textured inset still go through the exact kernel.  Both paths
+    agree everywhere, and most tiles stay out of the fallback."""
+    from linux_fg_amd import capi
+    W, H = 1920, 1080
+    prev = np.full((H, W, 4), 100, np.uint8)
+    curr = np.full((H, W, 4), 101, np.uint8)
+    tex = synth.make_prev(W, H, seed=synth.BASE_SEED + 77)
+    prev[400:700, 800:1200] = tex[400:700, 800:1200]
+    curr[400:700, 800:1200] = tex[398:698, 803:1203]
+    a, stats = run_motion_mode(ctx, prev, curr, capi.MOTION_PREFILTERED)
+    b, _ = run_motion_mode(ctx, prev, curr, capi.MOTION_EXACT_ONLY)
+    assert (a == b).all(), f"{(a != b).any(-1).sum()} pixels differ"
+    assert stats[1] < stats[0] // 2, stats                     # the flat interior stayed out of the exact kernel
+    assert (a[100, 300] == (-16, -16)).all()                  # all candidates tie: the first in scan order (F6)
+    small = (slice(0, 80), slice(0, 120))
+    want = as_int(oracle.motion(prev[small], curr[small]))
+    got = run_motion(ctx, prev[small].copy(), curr[small].copy())
+    assert (got == want).all()
+
+
 def _mixed_pair(w, h, seed):
     """A frame pair that mixes what the prefilter treats differently: a translation, sensor noise on part of the
     frame, patches of fresh noise, a static flat area and a flat area one level apart (ties at a non-zero cost)."""
