@@ -521,9 +521,10 @@ LFG_EXPORT int lfg_motion_last_stats(lfg_context *ctx, uint32_t *out_tiles, uint
     uint32_t fb = 0;
     for (uint32_t f : flags) fb += f != 0u;
     if (getenv("LFG_DEBUG")) {
-        uint32_t handed = 0;
-        LFG_HIP(ctx, hipMemcpy(&handed, ctx->motion_ws + ctx->motion_ws_layout.queueCount, 4, hipMemcpyDeviceToHost));
-        fprintf(stderr, "lfg: motion prefilter: %u requests to hand a segment over (room for %d)\n", handed, ctx->motion_ws_layout.queueCap);
+        uint32_t handed[2] = {0, 0};
+        LFG_HIP(ctx, hipMemcpy(handed, ctx->motion_ws + ctx->motion_ws_layout.queueCount, 8, hipMemcpyDeviceToHost));
+        fprintf(stderr, "lfg: motion prefilter: %u requests to hand a segment over (room for %d), %u tiles flagged for the exact kernel\n",
+                handed[0], ctx->motion_ws_layout.queueCap, handed[1]);
     }
     if (getenv("LFG_DEBUG"))
         for (size_t i = 0; i < flags.size(); ++i)

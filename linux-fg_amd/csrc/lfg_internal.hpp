@@ -40,7 +40,7 @@ struct PrefilterPlan {               // passed by value to the kernels
     // Segments handed over at run time (a whole tile's segment that finds no match after the first batches): a queue
     // of unitMap-style entries and their private lists in 16-row blocks; see motion_prefilter_kernel.
     uint32_t *segMap;                // per (tile, segment): 0, or first block | parts << 24 | 1 << 31
-    uint32_t *queueCount;            // entries pushed this call (may exceed queueCap: the excess was not handed over)
+    uint32_t *queueCount;            // [0] entries pushed this call (may exceed queueCap: the excess was not handed over), [1] tiles flagged
     uint32_t *queue;                 // [queueCap] unit entries, [queueCap] first blocks
     int queueCap;
     int fromQueue;                   // this launch takes its units from the queue
@@ -96,7 +96,9 @@ hipError_t launch_scale_2x(hipStream_t s, const lfg_frame &in, const lfg_frame &
                            const AxisTable &tx, const AxisTable &ty);
 bool scale_2x_supported(const lfg_frame &in, const lfg_frame &out);
 hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
-                                    const lfg_frame &mv, const uint32_t *tileFlags, const uint32_t *rank2scan);
+                                    const lfg_frame &mv, const uint32_t *tileFlags, const uint32_t *rank2scan,
+                                    unsigned long long *merge = nullptr, size_t mergeRowStride = 0,
+                                    const uint32_t *flaggedTiles = nullptr);
 // Candidate tables of the blockSize 8 / searchRadius 16 paths for one tie-break rule (motion.hip: motion_tables).
 constexpr int kMotionTableWords = 1092;     // 33 * 33 candidates + the sentinel, padded to a multiple of 4
 void motion_tables(bool intended, uint32_t *rank2scan, uint32_t *order32, uint32_t *entryOfScan, uint32_t *baseScan);

@@ -86,10 +86,18 @@ constexpr int kCand = kSide * kSide;
 static_assert(kTW / 8 * kTH == kNT, "one thread per 8x1 pixel patch");
 static_assert(kNT / 64 * kMainRows >= kDH && kExtra <= kNT, "phase-A map covers the plane");
 
+constexpr int kShareBelow = 256;        // flagged tiles up to which the exact kernel shares each between several workgroups
+
 __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int8_t *__restrict__ mv, int mvPitch, int W, int H, const uint32_t *__restrict__ tileFlags,
-    const uint32_t *__restrict__ rank2scan) {
+    const uint32_t *__restrict__ rank2scan, unsigned long long *__restrict__ merge, size_t mergeRowStride,
+    const uint32_t *__restrict__ flaggedTiles) {
+    // As the second pass of the prefiltered path (tileFlags != nullptr) a flagged tile is shared by gridDim.z
+    // workgroups, each on a contiguous part of the tie order: one workgroup needs 4.3 ms for a tile whatever else the
+    // chip is doing, and a frame rarely has more than a few such tiles.  The parts meet in `merge` (one 64-bit word
+    // per pixel, preset to all ones): atomicMin of (cost bits << 32 | rank) is the smallest cost and, among equal
+    // costs, the first candidate in tie order; motion_merge_kernel turns the words into vectors.
     // Candidates are visited in TIE ORDER: rank2scan[r] is the scan index (dy+R)*33 + (dx+R) of the r-th candidate
     // and the first strict minimum wins, so the table decides between equal costs.  Reference semantics: the
     // identity (motion.comp's scan order).  Entry kCand is a sentinel (scan index kCand, one row below the window).
@@ -180,10 +188,17 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
 #pragma unroll
     for (int i = 0; i < 8; ++i) { best[i] = 1e10f; bestCand[i] = 0; }   // motion.comp:23-24
 
-    phaseA(0, 0);
+    // Many flagged tiles fill the chip by themselves: then each is one workgroup's again (sharing costs a fifth more
+    // in repeated set-up), and the vectors are written directly.
+    // (two launches, one per regime; the launch whose regime it is not returns here)
+    const int parts = (int)gridDim.z;
+    if (flaggedTiles && (*flaggedTiles <= (uint32_t)kShareBelow) != (parts > 1)) return;
+    const int perPart = (kCand + parts - 1) / parts;
+    const int candBegin = (int)blockIdx.z * perPart, candEnd = min(kCand, candBegin + perPart);
+    phaseA(candBegin, candBegin & 1);
     __syncthreads();
 
-    for (int cand = 0; cand < kCand; ++cand) {
+    for (int cand = candBegin; cand < candEnd; ++cand) {
         phaseA(cand + 1, (cand + 1) & 1);   // cand + 1 == kCand reads past the last row: zeros, never used
         __builtin_amdgcn_sched_barrier(0);  // keep phase A's loaded texels out of phase B's live range
 
@@ -229,6 +244,17 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
     }
 
     const int py = ty0 + ry, px0 = tx0 + rxq * 8;
+    if (parts > 1) {
+        if (py < H) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (px0 + i < W)
+                    atomicMin(&merge[(size_t)py * mergeRowStride + (size_t)(px0 + i)],
+                              ((unsigned long long)__builtin_bit_cast(uint32_t, best[i]) << 32) | (unsigned long long)(uint32_t)bestCand[i]);
+            }
+        }
+        return;
+    }
     if (py < H && px0 < W) {
         uint32_t o[4] = {0u, 0u, 0u, 0u};                             // 8 x (int8 dx, int8 dy)
 #pragma unroll
@@ -969,8 +995,9 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
         if (lane == 0) {
             sGiveUp = 1u;
             const int ex0 = tx0 / kTW, ex1 = min(tx0 + kPTW - 1, W - 1) / kTW;
-            tileFlags[tileY * flagTilesX + ex0] = 1u;
-            tileFlags[tileY * flagTilesX + ex1] = 1u;
+            // (the number of flagged tiles decides how the exact kernel shares them out; it follows the queue length)
+            if (atomicExch(&tileFlags[tileY * flagTilesX + ex0], 1u) == 0u) atomicAdd(sp.queueCount + 1, 1u);
+            if (ex1 != ex0 && atomicExch(&tileFlags[tileY * flagTilesX + ex1], 1u) == 0u) atomicAdd(sp.queueCount + 1, 1u);
         }
         if (!segUnit) return;              // (the waves of a segment unit meet at a barrier below)
     }
@@ -1169,13 +1196,15 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int8_t *__restrict__ mv, int mvPitch, int W, int H, const uint2 *__restrict__ list,
     const float *__restrict__ uminIn, const uint32_t *__restrict__ countIn, const uint32_t *__restrict__ tileFlags,
-    int tilesX, PrefilterPlan sp, const uint32_t *__restrict__ rank2scan, const uint32_t *__restrict__ segDone) {
+    int tilesX, PrefilterPlan sp, const uint32_t *__restrict__ rank2scan, const uint32_t *__restrict__ segDone,
+    unsigned long long *__restrict__ mergeWords) {
     // Blocks whose pixels the prefilter settled itself (see its last lines): the 64 x 4 pixels lie in one 16-row segment
     // of one or two of its tiles.
     {
         const int y0 = (int)blockIdx.y * 4, x0 = (int)blockIdx.x * 64, x1 = min(x0 + 63, W - 1);
         const int row = (y0 / kPTH) * sp.tilesX, seg = (y0 % kPTH) / kSeg;
-        if (segDone[(row + x0 / kPTW) * (kPTH / kSeg) + seg] != 0u && segDone[(row + x1 / kPTW) * (kPTH / kSeg) + seg] != 0u) return;
+        if (tileFlags[(y0 / kTH) * tilesX + (int)blockIdx.x] == 0u &&          // (a flagged tile's pixels are preset below)
+            segDone[(row + x0 / kPTW) * (kPTH / kSeg) + seg] != 0u && segDone[(row + x1 / kPTW) * (kPTH / kSeg) + seg] != 0u) return;
     }
     // Candidates are identified by their RANK in the tie order everywhere in the prefiltered path (lists, the
     // zero-cost encoding), so "smallest rank among equal costs" is the tie-break; rank2scan turns it into (dx, dy).
@@ -1198,6 +1227,8 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
     const uint32_t tm = sp.tileMap[ptile];
     const uint32_t sm = sp.segMap[ptile * (kPTH / kSeg) + (cpy % kPTH) / kSeg];      // segment handed over at run time?
     const bool live = inside && flagged == 0u;
+    // A flagged tile goes through the exact kernel in parts that meet in record 0 of the pixel's list (atomicMin).
+    if (inside && flagged != 0u) mergeWords[(size_t)cpy * (size_t)kListK * (size_t)W + (size_t)cpx] = ~0ull;
     // Where this pixel's records live: one list in the image-shaped arrays, or several lists (one per unit that
     // shared the tile's candidates) in the auxiliary arrays -- blocks of a tile's 64 rows for the units of the plan,
     // of a segment's 16 rows for a segment handed over at run time.  Record k of list c: recs[c * listStride + k * recStride].
@@ -1362,12 +1393,48 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
     }
 }
 
+// The vectors of the flagged tiles from the words their parts left in `merge`.
+__global__ __launch_bounds__(256) void motion_merge_kernel(
+    int8_t *__restrict__ mv, int mvPitch, int W, int H, const uint32_t *__restrict__ tileFlags,
+    const uint32_t *__restrict__ rank2scan, const unsigned long long *__restrict__ merge, size_t mergeRowStride,
+    const uint32_t *__restrict__ flaggedTiles) {
+    if (*flaggedTiles > (uint32_t)kShareBelow || tileFlags[blockIdx.y * gridDim.x + blockIdx.x] == 0u) return;
+    const int px = (int)blockIdx.x * kTW + (int)(threadIdx.x & 63);
+    if (px >= W) return;
+    for (int r = (int)(threadIdx.x >> 6); r < kTH; r += 4) {
+        const int py = (int)blockIdx.y * kTH + r;
+        if (py >= H) break;
+        const int scan = (int)rank2scan[(uint32_t)merge[(size_t)py * mergeRowStride + (size_t)px]];
+        const int dyi = scan / kSide, dxi = scan - dyi * kSide;
+        int8_t *dst = mv + (size_t)py * (size_t)mvPitch + (size_t)px * 2u;
+        dst[0] = (int8_t)(dxi - kR);
+        dst[1] = (int8_t)(dyi - kR);
+    }
+}
+
+// merge == nullptr: every tile (tileFlags == nullptr) or the flagged ones, one workgroup each, vectors written directly.
+// Otherwise the flagged tiles in kFallbackParts parts through `merge` (preset to all ones for their pixels).
+constexpr int kFallbackParts = 8;
 hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
-                                    const lfg_frame &mv, const uint32_t *tileFlags, const uint32_t *rank2scan) {
-    dim3 grid((curr.width + kTW - 1) / kTW, (curr.height + kTH - 1) / kTH);
+                                    const lfg_frame &mv, const uint32_t *tileFlags, const uint32_t *rank2scan,
+                                    unsigned long long *merge, size_t mergeRowStride, const uint32_t *flaggedTiles) {
+    dim3 grid((curr.width + kTW - 1) / kTW, (curr.height + kTH - 1) / kTH, 1);
     hipLaunchKernelGGL(motion_tiled_8_16_kernel, grid, dim3(kNT), 0, s,
                        (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
-                       (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, tileFlags, rank2scan);
+                       (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, tileFlags, rank2scan,
+                       merge, mergeRowStride, flaggedTiles);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !merge) return e;
+    grid.z = kFallbackParts;
+    hipLaunchKernelGGL(motion_tiled_8_16_kernel, grid, dim3(kNT), 0, s,
+                       (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
+                       (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, tileFlags, rank2scan,
+                       merge, mergeRowStride, flaggedTiles);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(motion_merge_kernel, dim3(grid.x, grid.y), dim3(256), 0, s,
+                       (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, tileFlags, rank2scan,
+                       (const unsigned long long *)merge, mergeRowStride, flaggedTiles);
     return hipGetLastError();
 }
 
@@ -1386,7 +1453,7 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, Motion
     l.segDone = l.tileFlags + tiles * sizeof(uint32_t);
     l.segMap = l.segDone + ptiles * (kPTH / kSeg) * sizeof(uint32_t);
     l.queueCount = l.segMap + ptiles * (kPTH / kSeg) * sizeof(uint32_t);
-    l.order = align(l.queueCount + sizeof(uint32_t));                          // this call's hints and visiting order
+    l.order = align(l.queueCount + 2 * sizeof(uint32_t));                      // (+ the number of flagged tiles) this call's hints and visiting order
     // work-unit tables and the auxiliary arrays of the shared tiles (see prefilter_plan): one 56 x 64 block per unit
     const PrefilterPlanHost plan = prefilter_plan(width, height, slots);
     const size_t auxUnits = (size_t)plan.auxUnits;
@@ -1734,10 +1801,13 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
 #endif
     hipLaunchKernelGGL(motion_resolve_kernel, dim3((curr.width + 63) / 64, (curr.height + 3) / 4), dim3(256), 0, s,
                        (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
-                       (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, sp, rank2scan, segDone);
+                       (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, sp, rank2scan, segDone,
+                       reinterpret_cast<unsigned long long *>(list));
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return launch_motion_tiled_8_16(s, prev, curr, mv, flags, rank2scan);
+    // (the flagged tiles' parts merge in record 0 of their pixels' lists, which nothing reads any more)
+    return launch_motion_tiled_8_16(s, prev, curr, mv, flags, rank2scan, reinterpret_cast<unsigned long long *>(list),
+                                    (size_t)kListK * (size_t)curr.width, sp.queueCount + 1);
 }
 
 // Diagnostic: compares exact_sqrt with __builtin_sqrtf for every float whose bit pattern lies in
