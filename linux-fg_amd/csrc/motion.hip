@@ -372,7 +372,7 @@ typedef const __attribute__((address_space(3))) float *lds_ro_f32_ptr;
 
 #ifdef LFG_MOTION_STAMPS   // diagnostic build (tools/build_variant.sh stamps -DLFG_MOTION_STAMPS): per-wave timing and counts
 __device__ unsigned long long gMotionStamps[8192 * 4 * 8];
-__device__ unsigned long long gResolveStats[4];
+__device__ unsigned long long gResolveStats[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, ~0ull, 0, 0};
 #endif
 
 // order32[e] = the candidate's rank in the tie order (motion_tables) in the low half, its window offset
@@ -1206,6 +1206,9 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
         if (tileFlags[(y0 / kTH) * tilesX + (int)blockIdx.x] == 0u &&          // (a flagged tile's pixels are preset below)
             segDone[(row + x0 / kPTW) * (kPTH / kSeg) + seg] != 0u && segDone[(row + x1 / kPTW) * (kPTH / kSeg) + seg] != 0u) return;
     }
+#ifdef LFG_MOTION_STAMPS
+    const unsigned long long stampT0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // Candidates are identified by their RANK in the tie order everywhere in the prefiltered path (lists, the
     // zero-cost encoding), so "smallest rank among equal costs" is the tie-break; rank2scan turns it into (dx, dy).
     __shared__ float sDist[4][kB * kB];    // one block of distances per wave (cooperative exact evaluation)
@@ -1302,18 +1305,38 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
             bestC = __builtin_bit_cast(uint32_t, bound) - 0x00800000u;
         } else {
             // A single survivor IS the shader's answer (the exact minimiser always survives): no evaluation.
-#pragma unroll
-            for (int c = 0; c < kMaxLists; ++c) {
-                const uint32_t n = min(cntL[c], (uint32_t)kListK);
-                if (n > 0u && __builtin_bit_cast(float, recL[c].x) <= bound) {
-                    if (survivors == 0u) bestC = recL[c].y;
+            auto count = [&](const uint2 rec, bool valid) {
+                if (valid && __builtin_bit_cast(float, rec.x) <= bound) {
+                    if (survivors == 0u) bestC = rec.y;
                     ++survivors;
                 }
-                for (uint32_t k = 1; k < n; ++k) {
-                    const uint2 rec = recs[(size_t)c * listStride + (size_t)k * recStride];
-                    if (__builtin_bit_cast(float, rec.x) <= bound) {
-                        if (survivors == 0u) bestC = rec.y;
-                        ++survivors;
+            };
+            uint32_t nL[kMaxLists];
+#pragma unroll
+            for (int c = 0; c < kMaxLists; ++c) {
+                nL[c] = min(cntL[c], (uint32_t)kListK);
+                count(recL[c], nL[c] > 0u);
+            }
+            // The rest of the lists: four lists x four records per round, all sixteen loads in flight (a pixel
+            // without a match holds a handful of records in each list, and one load per loop trip was a memory
+            // latency each -- 30 us per wave at the rim).  Survivors are counted in list order within a round and
+            // round by round; which of them is remembered as "the" survivor only matters when there is exactly one.
+#pragma unroll
+            for (int c0 = 0; c0 < kMaxLists; c0 += 4) {
+                const uint32_t nMax = max(max(nL[c0], nL[c0 + 1]), max(nL[c0 + 2], nL[c0 + 3]));
+                for (uint32_t k0 = 1; k0 < nMax; k0 += 4u) {
+                    uint2 r[4][4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                        for (uint32_t j = 0; j < 4u; ++j)
+                            r[c][j] = recs[(size_t)(c0 + c) * listStride * (nL[c0 + c] > 0u ? 1u : 0u) +
+                                           (size_t)min(k0 + j, max(nL[c0 + c], 1u) - 1u) * recStride];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                        for (uint32_t j = 0; j < 4u; ++j) count(r[c][j], k0 + j < nL[c0 + c]);
                     }
                 }
             }
@@ -1326,6 +1349,8 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
     // distances per lane and candidate would otherwise run with one or two lanes active.
     unsigned long long todo = __ballot(survivors > 1u);
 #ifdef LFG_MOTION_STAMPS
+    const unsigned long long stampT1 = __builtin_amdgcn_s_memrealtime();
+    const int stampTodo = __builtin_popcountll(todo);
     if (survivors > 1u) { atomicAdd(&gResolveStats[0], 1ull); atomicAdd(&gResolveStats[1], (unsigned long long)survivors);
                           atomicAdd(&gResolveStats[2], (unsigned long long)(px < 64 || py < 64 || px >= W - 64 || py >= H - 64)); }
 #endif
@@ -1391,6 +1416,17 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
         dst[0] = (int8_t)(dxi - kR);
         dst[1] = (int8_t)(dyi - kR);
     }
+#ifdef LFG_MOTION_STAMPS
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(&gResolveStats[4], 1ull);                     // working waves
+        atomicAdd(&gResolveStats[5], stampT1 - stampT0);        // gather time (10 ns ticks)
+        atomicAdd(&gResolveStats[6], t2 - stampT1);             // cooperative + plateau + write time
+        atomicMax(&gResolveStats[7], t2 - stampT0);             // longest wave
+        atomicAdd(&gResolveStats[8], (unsigned long long)stampTodo);
+        atomicMin(&gResolveStats[9], stampT0); atomicMax(&gResolveStats[10], t2);
+    }
+#endif
 }
 
 // The vectors of the flagged tiles from the words their parts left in `merge`.
@@ -1793,8 +1829,11 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
                 fprintf(stderr, "%s units %d: mean %.1f us (staging %.1f, first batch %.1f), max %.1f us, evaluations per wave %.1f\n", r ? "rim" : "interior", cnt[r],
                         sum[r] / std::max(cnt[r], 1), stg[r] / std::max(cnt[r], 1), fst[r] / std::max(cnt[r], 1), mx[r], ev[r] / std::max(cnt[r], 1));
             fprintf(stderr, "span %.1f us\n", (double)(t1 - t0) / 100.0);
-            unsigned long long rs[4];
+            unsigned long long rs[12];
             hipMemcpyFromSymbol(rs, HIP_SYMBOL(gResolveStats), sizeof(rs));
+            fprintf(stderr, "resolve (previous calls together): %llu working waves, mean gather %.2f us, mean rest %.2f us, longest wave %.1f us, "
+                            "%llu pixels taken together, first start to last end (all calls and what lies between) %.1f us\n",
+                    rs[4], rs[4] ? rs[5] / 100.0 / rs[4] : 0.0, rs[4] ? rs[6] / 100.0 / rs[4] : 0.0, rs[7] / 100.0, rs[8], (rs[10] - rs[9]) / 100.0);
             fprintf(stderr, "resolve (previous calls together): %llu pixels with several survivors (%llu within 64 px of the rim), %llu survivors\n", rs[0], rs[2], rs[1]);
         }
     }
