@@ -1288,17 +1288,22 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
         float thrL[kMaxLists];
         uint32_t cntL[kMaxLists];
         uint2 recL[kMaxLists];
-        thrL[0] = thr0; cntL[0] = cnt0; recL[0] = rec0;
+        // (branch-free: a list that does not exist reads list 0 and is masked afterwards -- per-list branches made
+        //  every list a memory latency of its own)
 #pragma unroll
         for (int c = 0; c < kMaxLists; ++c) {
-            if (!whole && c < nLists) {
-                thrL[c] = thrs[(size_t)c * thrStride];
-                cntL[c] = cnts[(size_t)c * thrStride];
-                recL[c] = recs[(size_t)c * listStride];
-            } else if (c > 0 || !whole) {
-                thrL[c] = __builtin_inff(); cntL[c] = 0u; recL[c] = uint2{0u, 0u};
-            }
+            const size_t cc = (!whole && c < nLists) ? (size_t)c : 0u;
+            thrL[c] = thrs[cc * thrStride];
+            cntL[c] = cnts[cc * thrStride];
+            recL[c] = recs[cc * listStride];
         }
+#pragma unroll
+        for (int c = 0; c < kMaxLists; ++c) {
+            const bool exists = whole ? c == 0 : c < nLists;
+            thrL[c] = exists ? thrL[c] : __builtin_inff();
+            cntL[c] = exists ? cntL[c] : 0u;
+        }
+        if (whole) { thrL[0] = thr0; cntL[0] = cnt0; recL[0] = rec0; }
 #pragma unroll
         for (int c = 0; c < kMaxLists; ++c) bound = __builtin_fminf(bound, thrL[c]);
         if (bound < 0.5f) {                // a zero-cost candidate exists; the first one in tie order is encoded here
