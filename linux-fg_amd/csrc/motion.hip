@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int8_t *__restrict__ mv, int mvPitch, int W, int H, const uint32_t *__restrict__ tileFlags,
     const uint32_t *__restrict__ rank2scan, unsigned long long *__restrict__ merge, size_t mergeRowStride,
-    const uint32_t *__restrict__ flaggedTiles) {
+    const uint32_t *__restrict__ flaggedTiles, int tilesX) {
     // As the second pass of the prefiltered path (tileFlags != nullptr) a flagged tile is shared by gridDim.z
     // workgroups, each on a contiguous part of the tie order: one workgroup needs 4.3 ms for a tile whatever else the
     // chip is doing, and a frame rarely has more than a few such tiles.  The parts meet in `merge` (one 64-bit word
@@ -103,14 +103,22 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
     // identity (motion.comp's scan order).  Entry kCand is a sentinel (scan index kCand, one row below the window).
     __shared__ __attribute__((aligned(16))) float sD[2][kDH * kDS];    // 2 x 21 KB
 
-    // Second pass of the prefiltered path: only the tiles the prefilter gave up on (flag != 0).
-    if (tileFlags && tileFlags[blockIdx.y * gridDim.x + blockIdx.x] == 0u) return;
+    // Second pass of the prefiltered path: only the tiles the prefilter gave up on (flag != 0).  In the shared regime
+    // (gridDim.z > 1) the grid is the compact list of flagged tiles behind the count, not the tile grid.
+    int tileX = (int)blockIdx.x, tileY = (int)blockIdx.y;
+    if (gridDim.z > 1) {
+        if (*flaggedTiles > (uint32_t)kShareBelow || blockIdx.x >= *flaggedTiles) return;
+        const int t = (int)flaggedTiles[1 + blockIdx.x];
+        tileY = t / tilesX; tileX = t - tileY * tilesX;
+    } else if (tileFlags) {
+        if ((flaggedTiles && *flaggedTiles <= (uint32_t)kShareBelow) || tileFlags[tileY * tilesX + tileX] == 0u) return;
+    }
 
     constexpr int kOob = (int)0x80000000;        // a buffer offset that always fails the range check
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int g = __builtin_amdgcn_readfirstlane(tid >> 6);           // wave index 0..7
-    const int tx0 = blockIdx.x * kTW, ty0 = blockIdx.y * kTH;         // tile origin (pixels)
+    const int tx0 = tileX * kTW, ty0 = tileY * kTH;                   // tile origin (pixels)
     const int bx0 = tx0 - kB / 2, by0 = ty0 - kB / 2;                 // image coords of D(0,0)
     const i32x4 rPrev = make_rgba8_rsrc(prev, (uint32_t)H * (uint32_t)prevPitch);
     const i32x4 rCurr = make_rgba8_rsrc(curr, (uint32_t)H * (uint32_t)currPitch);
@@ -190,9 +198,7 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
 
     // Many flagged tiles fill the chip by themselves: then each is one workgroup's again (sharing costs a fifth more
     // in repeated set-up), and the vectors are written directly.
-    // (two launches, one per regime; the launch whose regime it is not returns here)
-    const int parts = (int)gridDim.z;
-    if (flaggedTiles && (*flaggedTiles <= (uint32_t)kShareBelow) != (parts > 1)) return;
+    const int parts = (int)gridDim.z;      // (two launches, one per regime; the other one has returned above)
     const int perPart = (kCand + parts - 1) / parts;
     const int candBegin = (int)blockIdx.z * perPart, candEnd = min(kCand, candBegin + perPart);
     phaseA(candBegin, candBegin & 1);
@@ -995,9 +1001,14 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
         if (lane == 0) {
             sGiveUp = 1u;
             const int ex0 = tx0 / kTW, ex1 = min(tx0 + kPTW - 1, W - 1) / kTW;
-            // (the number of flagged tiles decides how the exact kernel shares them out; it follows the queue length)
-            if (atomicExch(&tileFlags[tileY * flagTilesX + ex0], 1u) == 0u) atomicAdd(sp.queueCount + 1, 1u);
-            if (ex1 != ex0 && atomicExch(&tileFlags[tileY * flagTilesX + ex1], 1u) == 0u) atomicAdd(sp.queueCount + 1, 1u);
+            // (the number of flagged tiles decides how the exact kernel shares them out; it follows the queue length;
+            // the first kShareBelow of them are also listed, right behind the count)
+            for (int ex = ex0; ex <= ex1; ++ex) {
+                if (atomicExch(&tileFlags[tileY * flagTilesX + ex], 1u) == 0u) {
+                    const uint32_t slot = atomicAdd(sp.queueCount + 1, 1u);
+                    if (slot < (uint32_t)kShareBelow) sp.queueCount[2 + slot] = (uint32_t)(tileY * flagTilesX + ex);
+                }
+            }
         }
         if (!segUnit) return;              // (the waves of a segment unit meet at a barrier below)
     }
@@ -1438,12 +1449,13 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
 __global__ __launch_bounds__(256) void motion_merge_kernel(
     int8_t *__restrict__ mv, int mvPitch, int W, int H, const uint32_t *__restrict__ tileFlags,
     const uint32_t *__restrict__ rank2scan, const unsigned long long *__restrict__ merge, size_t mergeRowStride,
-    const uint32_t *__restrict__ flaggedTiles) {
-    if (*flaggedTiles > (uint32_t)kShareBelow || tileFlags[blockIdx.y * gridDim.x + blockIdx.x] == 0u) return;
-    const int px = (int)blockIdx.x * kTW + (int)(threadIdx.x & 63);
+    const uint32_t *__restrict__ flaggedTiles, int tilesX) {
+    if (*flaggedTiles > (uint32_t)kShareBelow || blockIdx.x >= *flaggedTiles) return;
+    const int t = (int)flaggedTiles[1 + blockIdx.x], tileY = t / tilesX, tileX = t - tileY * tilesX;
+    const int px = tileX * kTW + (int)(threadIdx.x & 63);
     if (px >= W) return;
     for (int r = (int)(threadIdx.x >> 6); r < kTH; r += 4) {
-        const int py = (int)blockIdx.y * kTH + r;
+        const int py = tileY * kTH + r;
         if (py >= H) break;
         const int scan = (int)rank2scan[(uint32_t)merge[(size_t)py * mergeRowStride + (size_t)px]];
         const int dyi = scan / kSide, dxi = scan - dyi * kSide;
@@ -1463,19 +1475,18 @@ hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const 
     hipLaunchKernelGGL(motion_tiled_8_16_kernel, grid, dim3(kNT), 0, s,
                        (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
                        (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, tileFlags, rank2scan,
-                       merge, mergeRowStride, flaggedTiles);
+                       merge, mergeRowStride, flaggedTiles, (int)grid.x);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !merge) return e;
-    grid.z = kFallbackParts;
-    hipLaunchKernelGGL(motion_tiled_8_16_kernel, grid, dim3(kNT), 0, s,
+    hipLaunchKernelGGL(motion_tiled_8_16_kernel, dim3(kShareBelow, 1, kFallbackParts), dim3(kNT), 0, s,
                        (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
                        (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, tileFlags, rank2scan,
-                       merge, mergeRowStride, flaggedTiles);
+                       merge, mergeRowStride, flaggedTiles, (int)grid.x);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(motion_merge_kernel, dim3(grid.x, grid.y), dim3(256), 0, s,
+    hipLaunchKernelGGL(motion_merge_kernel, dim3(kShareBelow), dim3(256), 0, s,
                        (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, tileFlags, rank2scan,
-                       (const unsigned long long *)merge, mergeRowStride, flaggedTiles);
+                       (const unsigned long long *)merge, mergeRowStride, flaggedTiles, (int)grid.x);
     return hipGetLastError();
 }
 
@@ -1494,7 +1505,8 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, Motion
     l.segDone = l.tileFlags + tiles * sizeof(uint32_t);
     l.segMap = l.segDone + ptiles * (kPTH / kSeg) * sizeof(uint32_t);
     l.queueCount = l.segMap + ptiles * (kPTH / kSeg) * sizeof(uint32_t);
-    l.order = align(l.queueCount + 2 * sizeof(uint32_t));                      // (+ the number of flagged tiles) this call's hints and visiting order
+    // (+ the number of flagged tiles and the list of the first kShareBelow of them)
+    l.order = align(l.queueCount + (2 + kShareBelow) * sizeof(uint32_t));      // this call's hints and visiting order
     // work-unit tables and the auxiliary arrays of the shared tiles (see prefilter_plan): one 56 x 64 block per unit
     const PrefilterPlanHost plan = prefilter_plan(width, height, slots);
     const size_t auxUnits = (size_t)plan.auxUnits;
