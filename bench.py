@@ -53,8 +53,8 @@ def parse_args():
     ap.add_argument("--workload", choices=["pipeline", "scale", "pipeline_input_res"], default="pipeline")
     ap.add_argument("--input", choices=list(SIZES), default="1080p", help="input size; output is 2x")
     ap.add_argument("--factors", default="0.5", help="comma-separated interpolation factors per pair")
-    ap.add_argument("--content", choices=["translated", "occluded", "noisy", "uncorrelated", "static", "fade"], default="translated",
-                    help="translated (default: curr = prev shifted by (3,-2)), occluded (the same with patches of fresh noise), noisy (the same with +-2 levels of noise everywhere), uncorrelated (independent noise frames), "
+    ap.add_argument("--content", choices=["translated", "occluded", "objects", "noisy", "uncorrelated", "static", "fade"], default="translated",
+                    help="translated (default: curr = prev shifted by (3,-2)), occluded (the same with patches of fresh noise), objects (the same with patches that move on their own), noisy (the same with +-2 levels of noise everywhere), uncorrelated (independent noise frames), "
                          "static (curr = prev), fade (flat grey frames one level apart: every candidate ties at a "
                          "non-zero cost, the prefilter's worst case -- all tiles fall back to the literal kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -245,6 +245,14 @@ def main():
             pw, ph = int(rng.integers(w_in // 60, w_in // 12)), int(rng.integers(h_in // 60, h_in // 12))
             x0, y0 = int(rng.integers(40, w_in - 40 - pw)), int(rng.integers(40, h_in - 40 - ph))
             curr_in[y0:y0 + ph, x0:x0 + pw] = fresh[y0:y0 + ph, x0:x0 + pw]
+    elif args.content == "objects":                        # the translated pair with 24 patches that move on their own
+        curr_in = synth.translate(prev_in, (3 + rank, -2), synth.BASE_SEED + rank)
+        rng = np.random.default_rng(30240 + rank)
+        for _ in range(24):
+            pw, ph = int(rng.integers(w_in // 60, w_in // 12)), int(rng.integers(h_in // 60, h_in // 12))
+            x0, y0 = int(rng.integers(40, w_in - 40 - pw)), int(rng.integers(40, h_in - 40 - ph))
+            dx, dy = int(rng.integers(-7, 8)), int(rng.integers(-7, 8))
+            curr_in[y0:y0 + ph, x0:x0 + pw] = prev_in[y0 - dy:y0 - dy + ph, x0 - dx:x0 - dx + pw]
     elif args.content == "noisy":                          # the translated pair plus sensor-like noise: +-2 levels per channel
         curr_in = synth.translate(prev_in, (3 + rank, -2), synth.BASE_SEED + rank)
         n = synth.noise_bytes(w_in, h_in, (synth.BASE_SEED + 15485863 * (rank + 1)) & 0xFFFFFFFF) % 5
