@@ -355,12 +355,15 @@ constexpr int kSlabP = 136;                       // slab pitch of a ROW PAIR (f
                                                   // transposed reads on 32 distinct banks
 constexpr int kRun = 7;                           // pixels per row-sum run: 8 runs x 7 = 56
 constexpr int kRunIn = kRun + kB - 1;             // 13
-constexpr int kHintGrid = 16, kHints = kHintGrid * kHintGrid;      // sample blocks of the per-call visiting order
+#ifndef LFG_HINT_GRID
+#define LFG_HINT_GRID 16
+#endif
+constexpr int kHintGrid = LFG_HINT_GRID, kHints = kHintGrid * kHintGrid;      // sample blocks of the per-call visiting order
 constexpr int kListK = 32;              // recorded candidates per pixel.  A pseudo-random visiting order makes the
                                         // number of running minima ~Poisson(ln 1089 = 7.6) whatever the content:
                                         // P(> 32) ~ 1e-11 per pixel, so only genuinely tied content overflows
 constexpr float kRatio = 1.00008f;      // >= (1 + 3.6e-5) / (1 - 3.6e-5) with room for the product's rounding ("Bracket")
-static_assert((kHints & (kHints - 1)) == 0 && kHints == 256, "one hint per thread of the order kernel, scrambled by an odd multiplier");
+static_assert((kHints & (kHints - 1)) == 0 && kHints >= 256 && kHints <= 1024, "one hint per thread of the order kernel, scrambled by an odd multiplier");
 static_assert(kPNT / 64 * kSeg == kPTH && 8 * kRun == kPTW && kPTH == kTH, "stage maps cover the tile");
 
 static_assert(kPTW + kB - 1 <= 64 && kWinW >= kPTW + kB - 1 + 2 * kR, "one lane per position column");
@@ -928,12 +931,15 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
                 return 0;
             }
         }
+        // Batches: the top hint and zero motion; then the other hints of this call (at least six entries, so that units
+        // which run the first eight for their thresholds see the same boundary); then sixty-four at a time.
+        const int hintsEnd = nHead ? kHead : max(kHead, min((int)order32[kCand + 1], 2 + 62));
         int firstBatchSurvivors = 0;
-        for (int i0 = 0, count = 2; i0 < nEntries; i0 += count, count = i0 == 2 ? 6 : 64) {
-            // Hand the segment over?  Either no threshold to test against after the first eight candidates, or the test
+        for (int i0 = 0, count = 2; i0 < nEntries; i0 += count, count = i0 == 2 ? hintsEnd - 2 : 64) {
+            // Hand the segment over?  Either no threshold to test against once every hint has been tried, or the test
             // let a quarter of the first full batch through.
             if (whole && !sp.fromQueue && order32[kCand] != 0u &&
-                ((i0 == 8 && !(waveThr < 4.0f * 510.0f)) || (i0 == 8 + 64 && firstBatchSurvivors >= 16))) {
+                ((i0 == hintsEnd && !(waveThr < 4.0f * 510.0f)) || (i0 == hintsEnd + 64 && firstBatchSurvivors >= 16))) {
                 uint32_t slot = 0u;
                 if (lane == 0) slot = atomicAdd(sp.queueCount, 1u);
                 slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
@@ -948,7 +954,7 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
             }
             uint32_t ordL;
             unsigned long long m = latticeBatch(i0, count, ordL);
-            if (i0 == 8) firstBatchSurvivors = __builtin_popcountll(m);
+            if (i0 == hintsEnd) firstBatchSurvivors = __builtin_popcountll(m);
 #ifdef LFG_MOTION_STAMPS
             stampBatches += 1u; stampEvals += (unsigned)__builtin_popcountll(m);
 #endif
@@ -1702,16 +1708,17 @@ __global__ __launch_bounds__(kHintThreads) void motion_hint_kernel(
     if (tid == 0) hints[blockIdx.x] = sBest;           // best SAD << 11 | candidate (scan index)
 }
 
-__global__ __launch_bounds__(256) void motion_order_kernel(
+__global__ __launch_bounds__(kHints) void motion_order_kernel(
     const uint32_t *__restrict__ hints, const uint32_t *__restrict__ baseScan,
     const uint32_t *__restrict__ entryOfScan, uint32_t *__restrict__ order32) {
     __shared__ uint32_t sOwner[kCand];               // lowest hint index that proposes this candidate
     __shared__ uint32_t sVotes[kCand];               // how many sample blocks propose it
-    __shared__ uint32_t sWaveSum[4];
+    constexpr int kWaves = kHints / 64;
+    __shared__ uint32_t sWaveSum[kWaves];
     __shared__ uint32_t sRunning, sTop;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t zero = baseScan[0];               // zero motion
-    for (int i = tid; i < kCand; i += 256) { sOwner[i] = 0xFFFFFFFFu; sVotes[i] = 0u; }
+    for (int i = tid; i < kCand; i += kHints) { sOwner[i] = 0xFFFFFFFFu; sVotes[i] = 0u; }
     if (tid == 0) sTop = 0u;
     __syncthreads();
     // Hints are taken in a scrambled order of the sample blocks: under a zoom or a rotation the hints vary smoothly
@@ -1734,7 +1741,9 @@ __global__ __launch_bounds__(256) void motion_order_kernel(
     __syncthreads();
     const uint32_t top = (uint32_t)(kCand - 1) - (sTop & 0x7FFu);
     if (tid == 0) {
-        order32[kCand] = (sWaveSum[0] + sWaveSum[1] + sWaveSum[2] + sWaveSum[3]) * 4u <= (uint32_t)kHints ? 1u : 0u;
+        uint32_t unmatchedAll = 0u;
+        for (int w = 0; w < kWaves; ++w) unmatchedAll += sWaveSum[w];
+        order32[kCand] = unmatchedAll * 4u <= (uint32_t)kHints ? 1u : 0u;
         order32[0] = entryOfScan[top];
         if (top != zero) order32[1] = entryOfScan[zero];
         sRunning = top != zero ? 2u : 1u;
@@ -1750,17 +1759,18 @@ __global__ __launch_bounds__(256) void motion_order_kernel(
         for (int w = 0; w < wv; ++w) base += sWaveSum[w];
         if (keep) order32[base + before] = entryOfScan[scan];
         __syncthreads();
-        if (tid == 0) sRunning += sWaveSum[0] + sWaveSum[1] + sWaveSum[2] + sWaveSum[3];
+        if (tid == 0) { uint32_t all = 0u; for (int w = 0; w < kWaves; ++w) all += sWaveSum[w]; sRunning += all; }
         __syncthreads();
     };
-    constexpr int kRounds = (kCand - 1 + 255) / 256;
+    constexpr int kRounds = (kCand - 1 + kHints - 1) / kHints;
     uint32_t base[kRounds];                                            // this thread's entries of the fixed order, read up front
 #pragma unroll
-    for (int k = 0; k < kRounds; ++k) base[k] = baseScan[min(1 + k * 256 + tid, kCand - 1)];
+    for (int k = 0; k < kRounds; ++k) base[k] = baseScan[min(1 + k * kHints + tid, kCand - 1)];
     append(mine != zero && mine != top && sOwner[mine] == (uint32_t)tid, mine);       // the other distinct hints
+    if (tid == 0) order32[kCand + 1] = sRunning;                       // entries in front: top hint, zero motion, the other hints
 #pragma unroll
     for (int k = 0; k < kRounds; ++k) {                                // then everything no hint proposed
-        const int e = 1 + k * 256 + tid;
+        const int e = 1 + k * kHints + tid;
         append(e < kCand && sOwner[base[k]] == 0xFFFFFFFFu, base[k]);
     }
 }
@@ -1801,7 +1811,7 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
         hipLaunchKernelGGL(motion_hint_kernel, dim3(kHints), dim3(kHintThreads), 0, s,
                            (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
                            (int)curr.width, (int)curr.height, hints);
-        hipLaunchKernelGGL(motion_order_kernel, dim3(1), dim3(256), 0, s, hints, baseScan, entryOfScan, callOrder);
+        hipLaunchKernelGGL(motion_order_kernel, dim3(1), dim3(kHints), 0, s, hints, baseScan, entryOfScan, callOrder);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         order = callOrder;
