@@ -19,8 +19,10 @@ frame pair per GPU, inputs already resident in HBM:
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), launched by torch.distributed.run.
 Frame pairs are independent, so the work shards one pair per GPU with no data-path collective except
-the one the path really has: the shared previous 4K frame is broadcast from rank 0 each step
-(double-buffered, issued one step ahead so it overlaps the kernels).  Weak scaling.
+the one the path really has: the batch's shared previous frame is broadcast from rank 0 each step
+(double-buffered, issued one step ahead so it overlaps the kernels) -- as the 8.3 MB input frame, which
+every rank upscales itself (one more 17 us scale per step than at N = 1; 33 MB of upscaled frame per
+0.8 ms step would cost more on xGMI than that).  Weak scaling.
 
 The CPU baseline is the oracle (oracle/lfg_oracle.c, a restatement of the reference shaders -- NOT
 lavapipe, which this image lacks) timed on a bounded sample on the host cores, rank 0, N = 1 only.
@@ -270,23 +272,31 @@ def main():
     if args.workload == "pipeline_input_res":
         t_mv_in, f_mv_in = empty_frame(w_in, h_in, capi.FORMAT_MV_S8X2)
         t_mid_in, f_mid_in = empty_frame(w_in, h_in)
-    prev_slots = [empty_frame(w, h) for _ in range(2 if world > 1 else 1)]
-    for _, f in prev_slots:
-        ctx.scale(f_prev_in, f)                     # rank 0's copy is the broadcast source
+    # The previous frame.  One GPU: upscaled once, before the timed region (in a stream it is the last step's current
+    # frame).  Several GPUs: the batch shares its previous frame, which travels as the 8.3 MB INPUT frame -- one
+    # broadcast per step, double-buffered -- and every rank upscales it (17 us) rather than 33 MB of upscaled frame
+    # crossing xGMI under a 0.8 ms step.  LFG_BENCH_SHARE_INPUT=1 runs that data flow on one GPU (no collective).
+    share_input = world > 1 or os.environ.get("LFG_BENCH_SHARE_INPUT") == "1"
+    t_prev4, f_prev4 = empty_frame(w, h)
+    ctx.scale(f_prev_in, f_prev4)
+    prev_slots = [dev_frame(prev_in) for _ in range(2)] if share_input else [(t_prev4, f_prev4)]
     torch.cuda.synchronize(dev)
 
     shared_prev = sharding.SharedFrameBroadcaster([t for t, _ in prev_slots], src=0, dist=dist if world > 1 else None,
                                                   world_size=world)
 
     def step(k):
-        # the shared previous 4K frame of this step (waits for its RCCL broadcast, issues the next one)
-        t_prev4 = shared_prev.acquire(k)
-        f_prev4 = prev_slots[[t.data_ptr() for t, _ in prev_slots].index(t_prev4.data_ptr())][1]
+        # the shared previous frame of this step (waits for its RCCL broadcast, issues the next one)
+        t_shared = shared_prev.acquire(k)
+        f_shared = prev_slots[[t.data_ptr() for t, _ in prev_slots].index(t_shared.data_ptr())][1]
+        f_prev_step = f_shared if share_input else f_prev_in
+        if share_input and args.workload == "pipeline":
+            ctx.scale(f_shared, f_prev4)
         if args.workload == "pipeline_input_res":
-            ctx.motion(f_prev_in, f_curr_in, f_mv_in, 8, 16.0)
+            ctx.motion(f_prev_step, f_curr_in, f_mv_in, 8, 16.0)
             ctx.scale(f_curr_in, f_curr4)
             for t in factors:
-                ctx.interpolate(f_prev_in, f_curr_in, f_mv_in, f_mid_in, t)
+                ctx.interpolate(f_prev_step, f_curr_in, f_mv_in, f_mid_in, t)
                 ctx.scale(f_mid_in, f_out)
             return
         ctx.scale(f_curr_in, f_curr4)
@@ -413,7 +423,7 @@ def main():
                                                                     else "motion(8,16)+interpolate at input resolution, then scale real and generated frame" if in_res
                                                                     else "scale only")),
                        "input": [w_in, h_in], "output": [w, h], "factors": factors if args.workload != "scale" else [],
-                       "content": args.content, "parallelism": f"one frame pair per GPU x{world}" + (", RCCL broadcast of the shared previous 4K frame per step" if world > 1 else "")},
+                       "content": args.content, "parallelism": f"one frame pair per GPU x{world}" + (", RCCL broadcast of the shared previous input frame per step, upscaled on every rank" if world > 1 else "")},
             "roofline": roofline,
             "stages": stages,
             "path_hbm": {"algorithmic_bytes_per_step": total_bytes,
