@@ -235,12 +235,16 @@ def main():
     # Synthetic inputs, uploaded once before timing.  The previous frame is shared by all ranks
     # (seed of stream 0); each rank's current frame is that frame translated by its own vector.
     prev_in = synth.make_prev(w_in, h_in, synth.BASE_SEED)
+    # Every rank's own motion, inside the search range after the 2x upscale (|2 dx|, |2 dy| <= 16): (3, -2) on rank 0,
+    # then (4, -2) ... (7, -2), (3, -3) ...
+    content_rank = int(os.environ.get("LFG_BENCH_CONTENT_RANK", rank))       # (diagnostic: another rank's frames on this GPU)
+    rank_shift = (3 + content_rank % 5, -2 - (content_rank // 5) % 6)
     if args.content == "translated":
-        curr_in = synth.translate(prev_in, (3 + rank, -2), synth.BASE_SEED + rank)
+        curr_in = synth.translate(prev_in, rank_shift, synth.BASE_SEED + rank)
     elif args.content == "uncorrelated":
         curr_in = synth.noise_bytes(w_in, h_in, (synth.BASE_SEED + 7919 * (rank + 1)) & 0xFFFFFFFF)
     elif args.content == "occluded":                       # the translated pair with 24 patches of fresh noise (2 % of the frame)
-        curr_in = synth.translate(prev_in, (3 + rank, -2), synth.BASE_SEED + rank)
+        curr_in = synth.translate(prev_in, rank_shift, synth.BASE_SEED + rank)
         fresh = synth.noise_bytes(w_in, h_in, (synth.BASE_SEED + 104729 * (rank + 1)) & 0xFFFFFFFF)
         rng = np.random.default_rng(20240 + rank)
         for _ in range(24):
@@ -248,7 +252,7 @@ def main():
             x0, y0 = int(rng.integers(40, w_in - 40 - pw)), int(rng.integers(40, h_in - 40 - ph))
             curr_in[y0:y0 + ph, x0:x0 + pw] = fresh[y0:y0 + ph, x0:x0 + pw]
     elif args.content == "objects":                        # the translated pair with 24 patches that move on their own
-        curr_in = synth.translate(prev_in, (3 + rank, -2), synth.BASE_SEED + rank)
+        curr_in = synth.translate(prev_in, rank_shift, synth.BASE_SEED + rank)
         rng = np.random.default_rng(30240 + rank)
         for _ in range(24):
             pw, ph = int(rng.integers(w_in // 60, w_in // 12)), int(rng.integers(h_in // 60, h_in // 12))
@@ -256,7 +260,7 @@ def main():
             dx, dy = int(rng.integers(-7, 8)), int(rng.integers(-7, 8))
             curr_in[y0:y0 + ph, x0:x0 + pw] = prev_in[y0 - dy:y0 - dy + ph, x0 - dx:x0 - dx + pw]
     elif args.content == "noisy":                          # the translated pair plus sensor-like noise: +-2 levels per channel
-        curr_in = synth.translate(prev_in, (3 + rank, -2), synth.BASE_SEED + rank)
+        curr_in = synth.translate(prev_in, rank_shift, synth.BASE_SEED + rank)
         n = synth.noise_bytes(w_in, h_in, (synth.BASE_SEED + 15485863 * (rank + 1)) & 0xFFFFFFFF) % 5
         curr_in = np.clip(curr_in.astype(np.int16) + n.astype(np.int16) - 2, 0, 255).astype(np.uint8)
     elif args.content == "static":
