@@ -409,7 +409,9 @@ def main():
         def launches(n):        # per step
             if n == "interpolate":
                 return len(factors)
-            return 1 + len(factors) if (n == "scale" and in_res) else 1
+            if n == "scale":            # curr (+ the generated frames of the input-resolution variant) (+ the shared previous frame)
+                return 1 + (len(factors) if in_res else 0) + (1 if share_input and args.workload == "pipeline" else 0)
+            return 1
         total_bytes = sum(algorithmic_bytes(n, w_in, h_in, w if n == "scale" else mw, h if n == "scale" else mh) * launches(n)
                           for n in stage_ms)
         line = {
