@@ -139,6 +139,13 @@ def pmc_executed(kernel_prefix):
                    "slots the kernel filled -- the utilisation figure that `frac` (an algorithmic rate) is not"}
 
 
+def rank_motion(rank: int):
+    """The translation (input pixels) of rank `rank`'s current frame against the shared previous frame.  It has to stay
+    inside the motion search range after the 2x upscale (|2 dx|, |2 dy| <= 16), or that rank's frames have no match
+    anywhere and its motion stage searches in full: (3, -2) on rank 0, then (4, -2) ... (7, -2), (3, -3) ..."""
+    return (3 + rank % 5, -2 - (rank // 5) % 6)
+
+
 def motion_flops(w: int, h: int, block: int = 8, radius: int = 16) -> float:
     """Algorithmic flops of motion.comp with per-position distance reuse: per candidate, one distance
     per pixel (4 sub, 4 mul, 3 add, 1 sqrt = 12 flops) and block*block adds per pixel."""
@@ -238,7 +245,7 @@ def main():
     # Every rank's own motion, inside the search range after the 2x upscale (|2 dx|, |2 dy| <= 16): (3, -2) on rank 0,
     # then (4, -2) ... (7, -2), (3, -3) ...
     content_rank = int(os.environ.get("LFG_BENCH_CONTENT_RANK", rank))       # (diagnostic: another rank's frames on this GPU)
-    rank_shift = (3 + content_rank % 5, -2 - (content_rank // 5) % 6)
+    rank_shift = rank_motion(content_rank)
     if args.content == "translated":
         curr_in = synth.translate(prev_in, rank_shift, synth.BASE_SEED + rank)
     elif args.content == "uncorrelated":
