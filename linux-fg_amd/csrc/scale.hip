@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256, 3) void scale_2x_kernel(
             // the first pixel of lanes 12/14 mod 16, a few dozen pixels per 4K frame, not every run).  The
             // compiler's hazard recogniser leaves the case "scalar register in the soffset field" out, so the
             // wait states are spelled out here.
-            asm volatile("s_nop 3");
+            asm volatile("s_nop 7");
         }
         __builtin_amdgcn_sched_barrier(0);     // keep each step's registers local
     }
