@@ -202,6 +202,21 @@ int  lfg_interpolate(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *c
 int  lfg_interpolate_frames(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *curr,
                             lfg_frame *out, float factor);
 
+/* Several generated frames per pair -- the 60 -> 240 fps cadence of BASELINE config 5 (t = 1/4, 1/2, 3/4) -- from
+ * ONE pass over prev, curr and the motion vectors (the vectors and both sources are read once
+ * per pair instead of once per factor).  No reference counterpart beyond the single `factor` of
+ * FrameManager::InterpolateFrames (src/frame_manager.cpp:216) and ScalerConfig::interpolationFactor
+ * (src/scaler.hpp:17).  outs[i] receives the frame for factors[i]; every frame is identical, byte for byte, to
+ * lfg_interpolate(ctx, prev, curr, mv, outs[i], factors[i]).  1 <= count <= LFG_MAX_FACTORS; the outputs must
+ * not alias each other or an input. */
+#define LFG_MAX_FACTORS 16
+int  lfg_interpolate_multi(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *curr, const lfg_frame *mv,
+                           lfg_frame *const *outs, const float *factors, uint32_t count);
+/* lfg_interpolate_frames for several factors: motion (blockSize 8, searchRadius 16) ONCE, then
+ * lfg_interpolate_multi with the context-owned motion-vector temporary. */
+int  lfg_interpolate_frames_multi(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *curr,
+                                  lfg_frame *const *outs, const float *factors, uint32_t count);
+
 /* Write the motion vectors as the reference's rgba32f image: vec4(mv.x, mv.y, 0, 1) per pixel
  * (shaders/motion.comp:56) into `device_rgba32f` (width*height*16 bytes, device memory). */
 int  lfg_mv_export_rgba32f(lfg_context *ctx, const lfg_frame *mv, void *device_rgba32f);

@@ -69,6 +69,8 @@ SIGNATURES = {
     "lfg_set_semantics": (_i, [_vp, _i]),
     "lfg_interpolate": (_i, [_vp, _FP, _FP, _FP, _FP, ctypes.c_float]),
     "lfg_interpolate_frames": (_i, [_vp, _FP, _FP, _FP, ctypes.c_float]),
+    "lfg_interpolate_multi": (_i, [_vp, _FP, _FP, _FP, ctypes.POINTER(_FP), ctypes.POINTER(ctypes.c_float), _u32]),
+    "lfg_interpolate_frames_multi": (_i, [_vp, _FP, _FP, ctypes.POINTER(_FP), ctypes.POINTER(ctypes.c_float), _u32]),
     "lfg_mv_export_rgba32f": (_i, [_vp, _FP, _vp]),
     "lfg_selftest_sqrt": (_i, [_vp, _u32, _u32, ctypes.POINTER(ctypes.c_uint64)]),
     "lfg_profile_enable": (_i, [_vp, _i]),
@@ -180,6 +182,35 @@ class Context:
     def copy(self, src: Frame, dst: Frame):
         self._check(self.lib.lfg_frame_copy(self.h, ctypes.byref(src), ctypes.byref(dst)), "lfg_frame_copy")
 
+    # -- staging (pinned host memory)
+    def staging_create(self, nbytes: int) -> np.ndarray:
+        """lfg_staging_create: ``nbytes`` of pinned host memory as a uint8 array (no copy); release it with
+        staging_destroy(array)."""
+        p = _vp()
+        self._check(self.lib.lfg_staging_create(self.h, nbytes, ctypes.byref(p)), "lfg_staging_create")
+        a = np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(p.value))
+        self._staging = getattr(self, "_staging", {})
+        self._staging[a.ctypes.data] = p.value
+        return a
+
+    def staging_destroy(self, a: np.ndarray):
+        self.lib.lfg_staging_destroy(self.h, _vp(self._staging.pop(a.ctypes.data)))
+
+    def upload_async(self, f: Frame, host: np.ndarray):
+        """lfg_frame_upload without the wait: ``host`` must be pinned and stay alive until sync()."""
+        self._check(self.lib.lfg_frame_upload(self.h, ctypes.byref(f), host.ctypes.data_as(_vp), host.nbytes), "lfg_frame_upload")
+
+    def download_async(self, f: Frame, host: np.ndarray):
+        self._check(self.lib.lfg_frame_download(self.h, ctypes.byref(f), host.ctypes.data_as(_vp), host.nbytes), "lfg_frame_download")
+
+    def mv_export_rgba32f(self, mv: Frame) -> np.ndarray:
+        """The reference's rgba32f motion-vector image, vec4(mv.x, mv.y, 0, 1) per pixel, as (H, W, 4) float32."""
+        tmp = self.create_frame(mv.width * 4, mv.height)          # W*H*16 bytes of device memory
+        self._check(self.lib.lfg_mv_export_rgba32f(self.h, ctypes.byref(mv), _vp(tmp.data)), "lfg_mv_export_rgba32f")
+        raw = self.download(tmp)
+        self.destroy_frame(tmp)
+        return raw.reshape(mv.height, mv.width * 16).view(np.float32).reshape(mv.height, mv.width, 4)
+
     # -- stages (enqueue only)
     def scale(self, src: Frame, dst: Frame):
         self._check(self.lib.lfg_scale(self.h, ctypes.byref(src), ctypes.byref(dst)), "lfg_scale")
@@ -209,6 +240,24 @@ class Context:
     def interpolate_frames(self, prev: Frame, curr: Frame, out: Frame, factor: float = 0.5):
         self._check(self.lib.lfg_interpolate_frames(self.h, ctypes.byref(prev), ctypes.byref(curr),
                                                     ctypes.byref(out), factor), "lfg_interpolate_frames")
+
+    @staticmethod
+    def _multi_args(outs, factors):
+        n = len(outs)
+        if n != len(factors):
+            raise ValueError("one output frame per factor")
+        return (_FP * n)(*[ctypes.pointer(o) for o in outs]), (ctypes.c_float * n)(*factors), n
+
+    def interpolate_multi(self, prev: Frame, curr: Frame, mv: Frame, outs, factors):
+        """One pass over prev / curr / mv, one generated frame per factor (lfg_interpolate_multi)."""
+        po, pf, n = self._multi_args(outs, factors)
+        self._check(self.lib.lfg_interpolate_multi(self.h, ctypes.byref(prev), ctypes.byref(curr), ctypes.byref(mv), po, pf, n),
+                    "lfg_interpolate_multi")
+
+    def interpolate_frames_multi(self, prev: Frame, curr: Frame, outs, factors):
+        po, pf, n = self._multi_args(outs, factors)
+        self._check(self.lib.lfg_interpolate_frames_multi(self.h, ctypes.byref(prev), ctypes.byref(curr), po, pf, n),
+                    "lfg_interpolate_frames_multi")
 
     def selftest_sqrt(self, lo_bits: int, hi_bits: int) -> int:
         n = ctypes.c_uint64()

@@ -117,8 +117,12 @@ int ensure_motion_tables(lfg_context *ctx) {
         lfg::motion_tables(sem != 0, host.data() + (3 * sem) * lfg::kMotionTableWords,
                            host.data() + (3 * sem + 1) * lfg::kMotionTableWords,
                            host.data() + (3 * sem + 2) * lfg::kMotionTableWords, host.data() + 6 * lfg::kMotionTableWords);
-    LFG_HIP(ctx, hipMalloc((void **)&ctx->motion_tables, host.size() * sizeof(uint32_t)));
-    LFG_HIP(ctx, hipMemcpy(ctx->motion_tables, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    // Published only once the copy has succeeded: a later call must never find a half-initialised table.
+    uint32_t *d = nullptr;
+    LFG_HIP(ctx, hipMalloc((void **)&d, host.size() * sizeof(uint32_t)));
+    const hipError_t e = hipMemcpy(d, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); return fail_hip(ctx, e, "hipMemcpy(motion tables)"); }
+    ctx->motion_tables = d;
     return LFG_OK;
 }
 
@@ -472,7 +476,12 @@ LFG_EXPORT int lfg_motion(lfg_context *ctx, const lfg_frame *prev, const lfg_fra
     if ((prev->pitch | curr->pitch) % 4u || ((uintptr_t)prev->data | (uintptr_t)curr->data) % 4u)
         return fail(ctx, LFG_ERR_INVALID, "lfg_motion: RGBA8 frames must be 4-byte aligned");
     const int R = (int)search_radius;
-    const bool tiled = block_size == 8 && R == 16;
+    // The 8/16 kernels address rows with 32-bit byte offsets and lean on the buffer range check for rows outside
+    // the image ("negative" offsets wrap to >= 2^31): both hold only below 2 GiB per frame.  Larger frames take the
+    // generic kernel, which indexes with size_t.
+    const bool fits32 = (uint64_t)prev->height * prev->pitch < 0x7fffffffull && (uint64_t)curr->height * curr->pitch < 0x7fffffffull &&
+                        (uint64_t)mv->height * mv->pitch < 0x7fffffffull;
+    const bool tiled = block_size == 8 && R == 16 && fits32;
     const uint32_t *rank2scan = nullptr, *order32 = nullptr;
     if (tiled) {
         int rc = ensure_motion_tables(ctx);
@@ -579,6 +588,47 @@ LFG_EXPORT int lfg_interpolate_frames(lfg_context *ctx, const lfg_frame *prev, c
     int rc = lfg_motion(ctx, prev, curr, &mv, 8, 16.0f);                      // frame_manager.cpp:332-333
     if (rc != LFG_OK) return rc;
     return lfg_interpolate(ctx, prev, curr, &mv, out, factor);
+}
+
+LFG_EXPORT int lfg_interpolate_multi(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *curr, const lfg_frame *mv,
+                                     lfg_frame *const *outs, const float *factors, uint32_t count) {
+    if (!ctx) return LFG_ERR_INVALID;
+    LFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (!outs || !factors || count == 0 || count > LFG_MAX_FACTORS)
+        return fail(ctx, LFG_ERR_INVALID, "lfg_interpolate_multi: count must be in [1, LFG_MAX_FACTORS] and outs/factors non-NULL");
+    if (!frame_ok(prev, LFG_FORMAT_RGBA8_UNORM) || !frame_ok(curr, LFG_FORMAT_RGBA8_UNORM) || !frame_ok(mv, LFG_FORMAT_MV_S8X2))
+        return fail(ctx, LFG_ERR_INVALID, "lfg_interpolate_multi: bad frame (NULL, empty or wrong format)");
+    if (!same_size(prev, curr) || !same_size(curr, mv))
+        return fail(ctx, LFG_ERR_INVALID, "lfg_interpolate_multi: frames differ in size");
+    if ((prev->pitch | curr->pitch) % 4u || mv->pitch % 2u)
+        return fail(ctx, LFG_ERR_INVALID, "lfg_interpolate_multi: row pitch not a multiple of the pixel size");
+    for (uint32_t i = 0; i < count; ++i) {
+        const lfg_frame *o = outs[i];
+        if (!frame_ok(o, LFG_FORMAT_RGBA8_UNORM) || !same_size(curr, o) || o->pitch % 4u)
+            return fail(ctx, LFG_ERR_INVALID, "lfg_interpolate_multi: bad output frame (NULL, empty, wrong format, size or pitch)");
+        if (o->data == prev->data || o->data == curr->data)
+            return fail(ctx, LFG_ERR_INVALID, "lfg_interpolate_multi: an output aliases an input");
+        for (uint32_t j = 0; j < i; ++j)
+            if (outs[j]->data == o->data) return fail(ctx, LFG_ERR_INVALID, "lfg_interpolate_multi: two outputs alias each other");
+    }
+    StageTimer timer(ctx, LFG_STAGE_INTERPOLATE);
+    hipError_t e = lfg::launch_interpolate_multi(ctx->stream, *prev, *curr, *mv, outs, factors, (int)count, ctx->semantics != 0);
+    if (e != hipSuccess) return fail_hip(ctx, e, "interpolate kernel launch");
+    return LFG_OK;
+}
+
+LFG_EXPORT int lfg_interpolate_frames_multi(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *curr,
+                                            lfg_frame *const *outs, const float *factors, uint32_t count) {
+    if (!ctx || !curr) return fail(ctx, LFG_ERR_INVALID, "lfg_interpolate_frames_multi: NULL argument");
+    lfg_frame &mv = ctx->mv_tmp;
+    if (!mv.data || mv.width != curr->width || mv.height != curr->height) {   // frame_manager.cpp:226-230
+        lfg_frame_destroy(ctx, &mv);
+        int rc = lfg_frame_create(ctx, curr->width, curr->height, LFG_FORMAT_MV_S8X2, &mv);
+        if (rc != LFG_OK) return fail(ctx, rc, "Failed to create motion vectors frame");
+    }
+    int rc = lfg_motion(ctx, prev, curr, &mv, 8, 16.0f);                      // frame_manager.cpp:332-333
+    if (rc != LFG_OK) return rc;
+    return lfg_interpolate_multi(ctx, prev, curr, &mv, outs, factors, count);
 }
 
 LFG_EXPORT int lfg_mv_export_rgba32f(lfg_context *ctx, const lfg_frame *mv, void *device_rgba32f) {

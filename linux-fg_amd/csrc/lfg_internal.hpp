@@ -114,6 +114,8 @@ hipError_t launch_motion_generic(hipStream_t s, const lfg_frame &prev, const lfg
                                  const lfg_frame &mv, int block_size, int radius, bool intended);
 hipError_t launch_interpolate(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                               const lfg_frame &mv, const lfg_frame &out, float factor, bool intended);
+hipError_t launch_interpolate_multi(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv,
+                                    const lfg_frame *const *outs, const float *factors, int count, bool intended);
 hipError_t launch_mv_export(hipStream_t s, const lfg_frame &mv, float *rgba32f);
 hipError_t launch_sqrt_selftest(hipStream_t s, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *d_mismatch);
 

@@ -70,6 +70,29 @@ bool FrameManager::InterpolateFrames(const Frame& previous, const Frame& current
     return HipContext::Get().WaitIdle();                      // EndSingleTimeCommands waits idle (:183-197)
 }
 
+bool FrameManager::InterpolateFramesMultiAsync(const Frame& previous, const Frame& current, const std::vector<Frame*>& outputs,
+                                               const std::vector<float>& factors) {
+    if (outputs.empty() || outputs.size() != factors.size()) {
+        LOG_ERROR("InterpolateFramesMulti: one output frame per factor is required");
+        return false;
+    }
+    const lfg_frame p = previous.AsAbi(), c = current.AsAbi();
+    std::vector<lfg_frame> abi(outputs.size());
+    std::vector<lfg_frame*> ptrs(outputs.size());
+    for (size_t i = 0; i < outputs.size(); ++i) { abi[i] = outputs[i]->AsAbi(); ptrs[i] = &abi[i]; }
+    if (lfg_interpolate_frames_multi(Ctx(), &p, &c, ptrs.data(), factors.data(), (uint32_t)factors.size()) != LFG_OK) {
+        LOG_ERROR("Failed to interpolate frames: ", lfg_last_error(Ctx()));
+        return false;
+    }
+    return true;
+}
+
+bool FrameManager::InterpolateFramesMulti(const Frame& previous, const Frame& current, const std::vector<Frame*>& outputs,
+                                          const std::vector<float>& factors) {
+    if (!InterpolateFramesMultiAsync(previous, current, outputs, factors)) return false;
+    return HipContext::Get().WaitIdle();
+}
+
 bool FrameManager::CreateStagingBuffer(void*& buffer, size_t size) {
     if (lfg_staging_create(Ctx(), size, &buffer) != LFG_OK) {
         LOG_ERROR("Failed to create staging buffer: ", lfg_last_error(Ctx()));

@@ -5,6 +5,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <vector>
 
 #include "hip_context.hpp"
 
@@ -57,6 +58,13 @@ public:
     bool InterpolateFrames(const Frame& previous, const Frame& current, Frame& output, float factor);
     // The same two stages enqueued without the wait (the Scaler pipelines presentation behind them).
     bool InterpolateFramesAsync(const Frame& previous, const Frame& current, Frame& output, float factor);
+
+    // Several generated frames per pair (the 60 -> 240 fps cadence: factors 1/4, 1/2, 3/4): motion once, then one pass
+    // that writes outputs[i] for factors[i].  Extension of InterpolateFrames, which takes a single factor.
+    bool InterpolateFramesMulti(const Frame& previous, const Frame& current, const std::vector<Frame*>& outputs,
+                                const std::vector<float>& factors);
+    bool InterpolateFramesMultiAsync(const Frame& previous, const Frame& current, const std::vector<Frame*>& outputs,
+                                     const std::vector<float>& factors);
 
     // Buffer management (src/frame_manager.cpp:199-214): pinned host memory instead of a
     // host-visible VkBuffer.

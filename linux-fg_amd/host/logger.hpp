@@ -1,69 +1,101 @@
-// Logger -- same convention as the reference's src/logger.hpp:8-73: a mutex-protected singleton,
-// LOG_DEBUG/INFO/WARN/ERROR macros, and LOG_ERROR latching HasError()/GetLastError().  Unlike the
-// reference the per-frame INFO lines can be silenced (SetMinLevel): the reference's ~9 LOG_INFO lines
-// per frame (src/scaler.cpp:262,360,465-477) take a mutex and format a timestamp each.
+// Logger -- the logging CONVENTION of the reference (src/logger.hpp:33-41,70-73), not its code: the four
+// LOG_* macros, a process-wide Logger::Get(), and LOG_ERROR latching a last-error string that callers read with
+// HasError() / GetLastError() / ClearError() after a method has returned false.
+//
+// Written for a headless frame pump rather than a desktop tool:
+//   * lines go to stderr in one write(2)-sized fwrite, so a pixel stream on stdout (lfg_host --output-raw -) stays clean;
+//   * the level filter is an atomic read taken before any formatting or locking -- the reference formats a
+//     timestamp and takes a mutex for each of its ~9 per-frame INFO lines (src/scaler.cpp:262,360,465-477);
+//   * time stamps are wall-clock HH:MM:SS.mmm (strftime on localtime_r), the latched error text carries none.
 #pragma once
+#include <atomic>
 #include <chrono>
+#include <cstdio>
 #include <ctime>
-#include <iostream>
 #include <mutex>
 #include <sstream>
 #include <string>
+#include <utility>
 
 class Logger {
 public:
-    enum class Level { DEBUG, INFO, WARNING, ERROR };
+    enum class Level : int { DEBUG = 0, INFO = 1, WARNING = 2, ERROR = 3 };
 
     static Logger& Get() {
-        static Logger instance;
-        return instance;
+        static Logger theLogger;
+        return theLogger;
     }
 
-    template <typename... Args>
-    void Log(Level level, Args&&... args) {
-        if (level < m_minLevel && level != Level::ERROR) return;
-        std::lock_guard<std::mutex> lock(m_mutex);
-        std::stringstream ss;
-        ss << "[" << GetTimestamp() << "] " << GetLevelString(level) << ": ";
-        (ss << ... << std::forward<Args>(args));
-        std::cout << ss.str() << std::endl;
-        if (level == Level::ERROR) {
-            m_hasError = true;
-            m_lastError = ss.str();
-        }
+    template <typename... Parts>
+    void Log(Level level, Parts&&... parts) {
+        const bool isError = level == Level::ERROR;
+        if (!isError && static_cast<int>(level) < m_threshold.load(std::memory_order_relaxed)) return;
+        std::ostringstream text;
+        Append(text, std::forward<Parts>(parts)...);
+        Emit(level, text.str(), isError);
     }
 
-    bool HasError() const { return m_hasError; }
-    std::string GetLastError() const { return m_lastError; }
-    void ClearError() { m_hasError = false; m_lastError.clear(); }
-    void SetMinLevel(Level level) { m_minLevel = level; }
+    bool HasError() const {
+        std::lock_guard<std::mutex> guard(m_lock);
+        return m_errorLatched;
+    }
+    std::string GetLastError() const {
+        std::lock_guard<std::mutex> guard(m_lock);
+        return m_errorText;
+    }
+    void ClearError() {
+        std::lock_guard<std::mutex> guard(m_lock);
+        m_errorLatched = false;
+        m_errorText.clear();
+    }
+    // Not in the reference: silence everything below `level` (errors are always recorded).
+    void SetMinLevel(Level level) { m_threshold.store(static_cast<int>(level), std::memory_order_relaxed); }
 
 private:
     Logger() = default;
+    Logger(const Logger&) = delete;
+    Logger& operator=(const Logger&) = delete;
 
-    std::string GetTimestamp() {
-        auto now = std::chrono::system_clock::now();
-        auto time = std::chrono::system_clock::to_time_t(now);
-        char buffer[26];
-        ctime_r(&time, buffer);
-        buffer[24] = '\0';
-        return buffer;
+    static void Append(std::ostringstream&) {}
+    template <typename First, typename... Rest>
+    static void Append(std::ostringstream& out, First&& first, Rest&&... rest) {
+        out << std::forward<First>(first);
+        Append(out, std::forward<Rest>(rest)...);
     }
 
-    const char* GetLevelString(Level level) {
-        switch (level) {
-            case Level::DEBUG: return "DEBUG";
-            case Level::INFO: return "INFO";
-            case Level::WARNING: return "WARNING";
-            case Level::ERROR: return "ERROR";
-            default: return "UNKNOWN";
+    static const char* Name(Level level) {
+        static const char* const kNames[] = {"DEBUG", "INFO", "WARNING", "ERROR"};
+        const int i = static_cast<int>(level);
+        return i >= 0 && i < 4 ? kNames[i] : "?";
+    }
+
+    void Emit(Level level, const std::string& text, bool latch) {
+        using namespace std::chrono;
+        const auto now = system_clock::now();
+        const std::time_t secs = system_clock::to_time_t(now);
+        const int millis = static_cast<int>(duration_cast<milliseconds>(now.time_since_epoch()).count() % 1000);
+        std::tm local{};
+        localtime_r(&secs, &local);
+        char clock[16];
+        std::strftime(clock, sizeof clock, "%H:%M:%S", &local);
+        char head[48];
+        const int headLen = std::snprintf(head, sizeof head, "%s.%03d %-7s ", clock, millis, Name(level));
+        std::string line;
+        line.reserve(static_cast<size_t>(headLen) + text.size() + 1);
+        line.append(head, static_cast<size_t>(headLen)).append(text).push_back('\n');
+
+        std::lock_guard<std::mutex> guard(m_lock);
+        std::fwrite(line.data(), 1, line.size(), stderr);
+        if (latch) {
+            m_errorLatched = true;
+            m_errorText = text;
         }
     }
 
-    std::mutex m_mutex;
-    bool m_hasError = false;
-    std::string m_lastError;
-    Level m_minLevel = Level::INFO;
+    mutable std::mutex m_lock;
+    std::atomic<int> m_threshold{static_cast<int>(Level::INFO)};
+    bool m_errorLatched = false;
+    std::string m_errorText;
 };
 
 #define LOG_DEBUG(...) Logger::Get().Log(Logger::Level::DEBUG, __VA_ARGS__)

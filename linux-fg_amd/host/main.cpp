@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <iostream>
 #include <string>
 
 #include "scaler.hpp"
@@ -20,6 +21,8 @@ static void PrintUsage() {
               << "  --target-fps FPS         Accepted for compatibility; frames are not paced\n"
               << "  --no-interpolation       Disable frame interpolation\n"
               << "  --interpolation-factor F Interpolation blend factor (0.0-1.0, default: 0.5)\n"
+              << "  --factors A,B,...        Several generated frames per pair, in presentation order (e.g. 0.25,0.5,0.75\n"
+              << "                           for 60 -> 240 fps); motion runs once per pair\n"
               << "  --frames N               Number of input frames to process (default: 10)\n"
               << "  --device N               HIP device ordinal (default: 0)\n"
               << "  --dump-dir DIR           Write every presented frame to DIR as raw RGBA8\n"
@@ -37,6 +40,7 @@ int main(int argc, char* argv[]) {
     uint32_t stream = 0;
     int frames = 10, device = 0;
     std::string dumpDir, inputRaw, outputRaw;
+    std::vector<float> factors;
     bool syncPresent = false;
 
     for (int i = 1; i < argc; i++) {
@@ -48,6 +52,15 @@ int main(int argc, char* argv[]) {
         else if (strcmp(argv[i], "--target-fps") == 0 && i + 1 < argc) config.targetFps = std::atoi(argv[++i]);
         else if (strcmp(argv[i], "--no-interpolation") == 0) config.enableInterpolation = false;
         else if (strcmp(argv[i], "--interpolation-factor") == 0 && i + 1 < argc) config.interpolationFactor = (float)std::atof(argv[++i]);
+        else if (strcmp(argv[i], "--factors") == 0 && i + 1 < argc) {
+            factors.clear();
+            for (const char* p = argv[++i]; *p;) {
+                char* end = nullptr;
+                factors.push_back(std::strtof(p, &end));
+                if (end == p) { LOG_ERROR("Invalid --factors list"); return 1; }
+                p = *end == ',' ? end + 1 : end;
+            }
+        }
         else if (strcmp(argv[i], "--frames") == 0 && i + 1 < argc) frames = std::atoi(argv[++i]);
         else if (strcmp(argv[i], "--device") == 0 && i + 1 < argc) device = std::atoi(argv[++i]);
         else if (strcmp(argv[i], "--dump-dir") == 0 && i + 1 < argc) dumpDir = argv[++i];
@@ -86,6 +99,7 @@ int main(int argc, char* argv[]) {
     if (!inputRaw.empty()) Scaler::Get().SetFrameSource(std::make_unique<RawFileCapture>(inputRaw));
     else Scaler::Get().SetFrameSource(std::make_unique<SyntheticCapture>(stream));
     Scaler::Get().SetPipelined(!syncPresent);
+    if (!factors.empty()) Scaler::Get().SetInterpolationFactors(factors);
     FILE* rawOut = nullptr;
     if (!outputRaw.empty()) {
         rawOut = outputRaw == "-" ? stdout : fopen(outputRaw.c_str(), "wb");

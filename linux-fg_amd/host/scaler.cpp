@@ -20,10 +20,15 @@ bool Scaler::Initialize(const ScalerConfig& config) {
         LOG_ERROR("Failed to initialize frame source");
         return false;
     }
+    if (m_factors.empty()) m_factors.push_back(config.interpolationFactor);
+    if (m_factors.size() > LFG_MAX_FACTORS) {
+        LOG_ERROR("Scaler::Initialize: at most ", LFG_MAX_FACTORS, " interpolation factors per pair");
+        return false;
+    }
     const size_t inBytes = (size_t)config.inputWidth * config.inputHeight * 4;
     const size_t outBytes = (size_t)config.outputWidth * config.outputHeight * 4;
     if (lfg_ring_create(Ctx(), 3, inBytes, &m_uploadRing) != LFG_OK ||
-        lfg_ring_create(Ctx(), 6, outBytes, &m_readbackRing) != LFG_OK) {       // two calls' worth of frames + margin
+        lfg_ring_create(Ctx(), (uint32_t)(2 * (m_factors.size() + 1) + 2), outBytes, &m_readbackRing) != LFG_OK) {   // two calls' worth of frames + margin
         LOG_ERROR("Failed to create pinned frame rings: ", lfg_last_error(Ctx()));
         Cleanup();
         return false;
@@ -56,8 +61,10 @@ bool Scaler::CreateFrameResources() {
         }
     }
     if (m_config.enableInterpolation && !m_previousOutput.data) {
-        if (!fm.CreateFrame(m_previousOutput, m_config.outputWidth, m_config.outputHeight) ||
-            !fm.CreateFrame(m_interpolatedFrame, m_config.outputWidth, m_config.outputHeight)) {
+        bool ok = fm.CreateFrame(m_previousOutput, m_config.outputWidth, m_config.outputHeight);
+        m_interpolatedFrames.resize(m_factors.size());
+        for (Frame& f : m_interpolatedFrames) ok = ok && fm.CreateFrame(f, m_config.outputWidth, m_config.outputHeight);
+        if (!ok) {
             LOG_ERROR("Failed to create interpolation frames");
             return false;
         }
@@ -159,14 +166,25 @@ bool Scaler::ProcessFrame() {
     }
     const size_t inFlightBefore = m_pending.size();
     if (m_config.enableInterpolation && m_havePrevious) {
-        fenceBeforeWrite(m_interpolatedFrame);
+        for (Frame& f : m_interpolatedFrames) fenceBeforeWrite(f);
         auto& fm = FrameManager::Get();
-        if (!(m_pipelined ? fm.InterpolateFramesAsync(m_previousOutput, m_outputFrame, m_interpolatedFrame, m_config.interpolationFactor)
-                          : fm.InterpolateFrames(m_previousOutput, m_outputFrame, m_interpolatedFrame, m_config.interpolationFactor))) {
+        bool ok;
+        if (m_factors.size() == 1) {                          // the reference's own entry point
+            ok = m_pipelined ? fm.InterpolateFramesAsync(m_previousOutput, m_outputFrame, m_interpolatedFrames[0], m_factors[0])
+                             : fm.InterpolateFrames(m_previousOutput, m_outputFrame, m_interpolatedFrames[0], m_factors[0]);
+        } else {                                              // motion once, every factor in one pass
+            std::vector<Frame*> outs;
+            for (Frame& f : m_interpolatedFrames) outs.push_back(&f);
+            ok = m_pipelined ? fm.InterpolateFramesMultiAsync(m_previousOutput, m_outputFrame, outs, m_factors)
+                             : fm.InterpolateFramesMulti(m_previousOutput, m_outputFrame, outs, m_factors);
+        }
+        if (!ok) {
             LOG_ERROR("Failed to interpolate frame");
             return false;
         }
-        if (!QueueReadback(m_interpolatedFrame, true)) return false;     // generated frame first, then the real one
+        // Presentation order: previous real frame (presented by the last call), generated frames t1 .. tN, this real frame.
+        for (Frame& f : m_interpolatedFrames)
+            if (!QueueReadback(f, true)) return false;
     }
     if (!QueueReadback(m_outputFrame, false)) return false;
     // Pipelined: present what the previous call queued while this call's work runs; otherwise everything now.
@@ -193,7 +211,9 @@ void Scaler::Cleanup() {
     fm.DestroyFrame(m_previousFrame);
     fm.DestroyFrame(m_outputFrame);
     fm.DestroyFrame(m_previousOutput);
-    fm.DestroyFrame(m_interpolatedFrame);
+    for (Frame& f : m_interpolatedFrames) fm.DestroyFrame(f);
+    m_interpolatedFrames.clear();
+    m_factors.clear();
     m_havePrevious = false;
     m_frameTimings.clear();
     m_initialized = false;

@@ -50,6 +50,34 @@ def test_process_frame_sequence_matches_oracle(host_binary, oracle, tmp_path):
         assert (gen == oracle.interpolate(prev_up, curr_up, mv, 0.5)).all()
 
 
+def test_cadence_60_to_240_sequence_matches_oracle(host_binary, oracle, tmp_path):
+    """lfg_host --factors 0.25,0.5,0.75 (BASELINE config 5's cadence): per further input frame
+    three generated frames then the real one -- real, [t=1/4, t=1/2, t=3/4, real] ... -- motion once per pair, every
+    generated frame equal to the oracle's for its factor, in both presentation modes."""
+    w, h, n = 64, 36, 3
+    factors = [0.25, 0.5, 0.75]
+    for extra in ([], ["--sync-present"]):
+        d = tmp_path / ("cadence" + "".join(extra))
+        d.mkdir()
+        stats = run_host(["--input-width", str(w), "--input-height", str(h), "--output-width", str(2 * w), "--output-height", str(2 * h),
+                          "--frames", str(n), "--dump-dir", str(d), "--quiet", "--factors", "0.25,0.5,0.75", "2"] + extra)
+        assert stats["presented"] == n + 3 * (n - 1) and stats["interpolated"] == 3 * (n - 1)
+        files = sorted(os.listdir(d))
+        assert [f.split("_")[2] for f in files] == ["real"] + ["interp", "interp", "interp", "real"] * (n - 1)
+        frames = [np.fromfile(d / f, np.uint8).reshape(2 * h, 2 * w, 4) for f in files]
+        reals = frames[0::4]
+        seed = synth.BASE_SEED + 2
+        inputs = [synth.make_prev(w, h, seed)]
+        for k in range(1, n):
+            inputs.append(synth.translate(inputs[-1], (3, -2), seed + k))
+        for got, src in zip(reals, inputs):
+            assert np.abs(got.astype(np.int16) - oracle.scale(src, 2 * w, 2 * h).astype(np.int16)).max() <= 1
+        for i in range(n - 1):
+            mv = oracle.motion(reals[i], reals[i + 1], 8, 16.0)
+            for j, t in enumerate(factors):
+                assert (frames[4 * i + 1 + j] == oracle.interpolate(reals[i], reals[i + 1], mv, t)).all(), (i, t)
+
+
 def test_no_interpolation_and_aspect_ratio(host_binary):
     out = subprocess.run([host_binary, "--input-width", "80", "--input-height", "40", "--output-height", "100",
                           "--no-interpolation", "--frames", "4", "--quiet"], capture_output=True, text=True, check=True)

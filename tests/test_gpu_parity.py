@@ -97,6 +97,15 @@ def test_scale_identity_exact(ctx):
     assert (run_scale(ctx, f, 96, 50) == f).all()                # S-KAT2
 
 
+def test_scale_config1_540p_to_1080p_full_frame(ctx, oracle):
+    """BASELINE config 1 (960x540 -> 1920x1080, Lanczos only): every pixel against the oracle, on the benchmark's
+    synthetic frame and on uniform noise (SURVEY.md section 7 step 3 names this shape as the first parity case)."""
+    prev, _ = synth.make_pair(960, 540, stream=0)
+    for src in (prev, synth.noise_bytes(960, 540, 540960)):
+        got = run_scale(ctx, src, 1920, 1080)
+        assert_within_1lsb(got, oracle.scale(src, 1920, 1080))
+
+
 def test_scale_1080p_to_4k_roi(ctx, oracle):
     """BASELINE config 2 at full size: ROI spot checks against the oracle plus a 2x vs generic-kernel
     cross-check would need a second entry point; the ROIs cover corners, edges and the interior."""
@@ -401,6 +410,45 @@ def _mixed_pair(w, h, seed):
     return prev, curr
 
 
+def _full_hd_mixture():
+    """1920x1080 pair with everything the prefilter treats differently in one frame: a translation, a band of
+    sensor noise, patches of fresh noise (segments without a match, hand-over), patches that move on their own,
+    a static flat area (zero-cost ties), a flat area one grey level apart (non-zero ties: list overflow, exact-kernel
+    tiles), and one of each touching the image border (rim segment units, plateaus)."""
+    W, H = 1920, 1080
+    prev = synth.make_prev(W, H, seed=synth.BASE_SEED + 1080)
+    curr = synth.translate(prev, (-5, 9), synth.BASE_SEED + 1080)
+    n = synth.noise_bytes(W, H, 271828) % 5
+    noisy = np.clip(curr.astype(np.int16) + n.astype(np.int16) - 2, 0, 255).astype(np.uint8)
+    curr[300:520] = noisy[300:520]
+    fresh = synth.noise_bytes(W, H, 314159)
+    for (x0, y0, w, h) in [(200, 100, 150, 90), (1000, 640, 64, 200), (1700, 900, 220, 180), (0, 700, 40, 120)]:
+        curr[y0:y0 + h, x0:x0 + w] = fresh[y0:y0 + h, x0:x0 + w]
+    for (x0, y0, w, h, dx, dy) in [(600, 150, 120, 80, 7, -3), (1300, 400, 90, 140, -11, 6), (900, 950, 200, 60, 2, 12)]:
+        curr[y0:y0 + h, x0:x0 + w] = prev[y0 - dy:y0 - dy + h, x0 - dx:x0 - dx + w]
+    prev[560:680, 100:420] = 37; curr[560:680, 100:420] = 37                 # static flat area
+    prev[760:840, 1200:1330] = 50; curr[760:840, 1200:1330] = 51             # fade patch in the interior
+    prev[0:70, 1500:1640] = 200; curr[0:70, 1500:1640] = 201                 # fade patch on the top border
+    return prev, curr
+
+
+def test_motion_full_hd_both_modes_against_the_oracle(ctx, oracle):
+    """One full-frame ORACLE comparison at 1920x1080 (about a minute of CPU): whole-tile work units, rim segment
+    units, the hand-over queue, both partial-distortion tests, plateaus, the shared-tile merge and the exact-kernel
+    fallback are all checked against the oracle itself here, for both motion modes -- everywhere else frames of this
+    size are only compared HIP against HIP."""
+    from linux_fg_amd import capi
+    prev, curr = _full_hd_mixture()
+    want = as_int(oracle.motion(prev, curr))
+    a, stats = run_motion_mode(ctx, prev, curr, capi.MOTION_PREFILTERED)
+    assert (a == want).all(), f"prefiltered: {(a != want).any(-1).sum()} pixels differ from the oracle"
+    b, _ = run_motion_mode(ctx, prev, curr, capi.MOTION_EXACT_ONLY)
+    assert (b == want).all(), f"exact only: {(b != want).any(-1).sum()} pixels differ from the oracle"
+    assert 0 < stats[1] < stats[0] // 4, stats                 # the fade patches did go through the fallback
+    inner = want[540:556, 700:1100]                            # clean translation below the noise band
+    assert (inner[..., 0] == 5).all() and (inner[..., 1] == -9).all()
+
+
 @pytest.mark.parametrize("case", range(60))
 def test_motion_modes_agree_on_random_mixtures(ctx, case):
     """Seeded fuzz over frame sizes and content mixtures: small frames (tiles shared between workgroups), mid-size
@@ -602,6 +650,79 @@ def test_interpolate_4k_exact_rois(ctx, oracle):
 
 # ------------------------------------------------------------------------------ whole path
 
+def _run_interpolate_multi(ctx, prev, curr, mv_i8, factors):
+    from linux_fg_amd import capi
+    p, c = ctx.frame_from(prev), ctx.frame_from(curr)
+    m = ctx.frame_from(mv_i8, capi.FORMAT_MV_S8X2)
+    outs = [ctx.create_frame(prev.shape[1], prev.shape[0]) for _ in factors]
+    ctx.interpolate_multi(p, c, m, outs, factors)
+    got = [ctx.download(o) for o in outs]
+    for f in [p, c, m] + outs:
+        ctx.destroy_frame(f)
+    return got
+
+
+@pytest.mark.parametrize("wh,factors", [((128, 40), [0.25, 0.5, 0.75]), ((101, 7), [0.5, 0.3]), ((90, 52), [0.25, 0.5, 0.75, 0.9]),
+                                        ((66, 31), [0.1, 0.2, 0.4, 0.6, 0.8]), ((64, 16), [0.5])])
+def test_interpolate_multi_equals_the_oracle_per_factor(ctx, oracle, wh, factors):
+    """lfg_interpolate_multi (one pass, N frames: BASELINE config 5's t = 1/4, 1/2, 3/4) against the oracle's
+    interpolate for every factor, bit for bit: motion vectors mixed from zero (both sources in range for every t),
+    small ones (in range for some t only) and large ones (out of range), ragged widths, 1 to 5 factors (5 = 4 + 1)."""
+    w, h = wh
+    prev, curr = rand_frame(w, h), rand_frame(w, h)
+    mv = RNG.integers(-16, 17, size=(h, w, 2)).astype(np.int8)
+    mv[: h // 2, : w // 2] = 0
+    mv[h // 2:, : w // 3] = RNG.integers(-1, 2, size=(h - h // 2, w // 3, 2)).astype(np.int8)
+    got = _run_interpolate_multi(ctx, prev, curr, mv, factors)
+    for g, t in zip(got, factors):
+        assert (g == oracle.interpolate(prev, curr, mv.astype(np.float32), t)).all(), f"t = {t}"
+
+
+def test_interpolate_multi_intended_semantics_and_validation(intended, oracle):
+    from linux_fg_amd import capi
+    w, h = 90, 52
+    prev, curr = rand_frame(w, h), rand_frame(w, h)
+    mv = RNG.integers(-16, 17, size=(h, w, 2)).astype(np.int8)
+    mv[:10] = 0
+    factors = [0.25, 0.5, 0.75]
+    got = _run_interpolate_multi(intended, prev, curr, mv, factors)
+    for g, t in zip(got, factors):
+        one = run_interpolate(intended, prev, curr, mv, t)            # the single-factor kernel, same semantics
+        assert (g == one).all()
+        want = oracle.interpolate(prev, curr, mv.astype(np.float32), t, semantics=oracle.INTENDED)
+        assert np.abs(g.astype(np.int16) - want.astype(np.int16)).max() <= 1
+    a, b = intended.create_frame(w, h), intended.create_frame(w, h)
+    m = intended.create_frame(w, h, capi.FORMAT_MV_S8X2)
+    small = intended.create_frame(w // 2, h)
+    out = intended.create_frame(w, h)
+    with pytest.raises(capi.LfgError, match="alias each other"):
+        intended.interpolate_multi(a, b, m, [out, out], [0.25, 0.5])
+    with pytest.raises(capi.LfgError, match="bad output frame"):
+        intended.interpolate_multi(a, b, m, [small], [0.5])
+    with pytest.raises(capi.LfgError, match="aliases an input"):
+        intended.interpolate_multi(a, b, m, [a], [0.5])
+    with pytest.raises(capi.LfgError, match="count must be"):
+        intended.interpolate_multi(a, b, m, [], [])
+    for f in (a, b, m, small, out):
+        intended.destroy_frame(f)
+
+
+def test_interpolate_frames_multi_entry_point(ctx, oracle):
+    """lfg_interpolate_frames_multi: motion once, then all factors -- against oracle.motion + oracle.interpolate."""
+    w, h = 128, 72
+    prev, curr = synth.make_pair(w, h, stream=2, shift=(0, 0))        # static pair: vectors are (-16,-16) or ties...
+    curr = curr.copy(); curr[20:40, 30:90] = synth.noise_bytes(w, h, 5)[20:40, 30:90]
+    p, c = ctx.frame_from(prev), ctx.frame_from(curr)
+    factors = [0.25, 0.5, 0.75]
+    outs = [ctx.create_frame(w, h) for _ in factors]
+    ctx.interpolate_frames_multi(p, c, outs, factors)
+    mv = oracle.motion(prev, curr)
+    for o, t in zip(outs, factors):
+        assert (ctx.download(o) == oracle.interpolate(prev, curr, mv, t)).all()
+    for f in [p, c] + outs:
+        ctx.destroy_frame(f)
+
+
 def test_interpolate_frames_entry_point(ctx, oracle):
     """FrameManager::InterpolateFrames equivalent: motion(8,16) then interpolate, MV temp inside."""
     W, H = 128, 64
@@ -704,6 +825,101 @@ def test_all_stages_with_row_pitch_larger_than_width(ctx, oracle, pad):
     assert (ctx.download(bM)[:, W:] == 3).all()
     for b in (bp, bc, bP, bC, bO, bM):
         ctx.destroy_frame(b)
+
+
+def test_frame_copy_moves_the_bytes(ctx):
+    """lfg_frame_copy (FrameManager::CopyFrameData, src/frame_manager.cpp:83-145): tight -> tight, pitched -> tight,
+    tight -> pitched (padding untouched) and motion-vector frames."""
+    from linux_fg_amd import capi
+    w, h = 70, 33
+    a = rand_frame(w, h)
+    src, dst = ctx.frame_from(a), ctx.create_frame(w, h)
+    ctx.copy(src, dst)
+    assert (ctx.download(dst) == a).all()
+    big, view = _pitched(ctx, a, 12)                              # pitched source
+    dst2 = ctx.frame_from(np.zeros_like(a))
+    ctx.copy(view, dst2)
+    assert (ctx.download(dst2) == a).all()
+    bigd, viewd = _pitched(ctx, np.zeros_like(a), 4)              # pitched destination
+    ctx.copy(src, viewd)
+    got = ctx.download(bigd)
+    assert (got[:, :w] == a).all() and (got[:, w:] == 0x5A).all()
+    m = RNG.integers(-16, 17, size=(h, w, 2)).astype(np.int8)
+    ms, md = ctx.frame_from(m, capi.FORMAT_MV_S8X2), ctx.create_frame(w, h, capi.FORMAT_MV_S8X2)
+    ctx.copy(ms, md)
+    assert (ctx.download(md) == m).all()
+    with pytest.raises(capi.LfgError, match="dimensions do not match"):
+        ctx.copy(ms, dst)                                         # same size, different format
+    for f in (src, dst, big, dst2, bigd, ms, md):
+        ctx.destroy_frame(f)
+
+
+def test_mv_export_is_the_reference_rgba32f_image(ctx, oracle):
+    """lfg_mv_export_rgba32f reproduces what shaders/motion.comp:56 stores -- vec4(best, 0, 1) in an rgba32f image --
+    bit for bit from the oracle's float vectors, for a tight and a pitched motion-vector frame."""
+    from linux_fg_amd import capi
+    w, h = 96, 50
+    prev, curr = synth.make_pair(w, h, stream=3, shift=(4, -7))
+    want = oracle.motion(prev, curr)                              # (H, W, 2) float32
+    p, c = ctx.frame_from(prev), ctx.frame_from(curr)
+    mv = ctx.create_frame(w, h, capi.FORMAT_MV_S8X2)
+    ctx.motion(p, c, mv)
+    img = ctx.mv_export_rgba32f(mv)
+    assert img.dtype == np.float32 and img.shape == (h, w, 4)
+    assert (img[..., :2].view(np.uint32) == want.view(np.uint32)).all()
+    assert (img[..., 2] == 0.0).all() and (img[..., 3] == 1.0).all()
+    big, view = _pitched(ctx, ctx.download(mv), 6, capi.FORMAT_MV_S8X2)
+    assert (ctx.mv_export_rgba32f(view) == img).all()
+    for f in (p, c, mv, big):
+        ctx.destroy_frame(f)
+
+
+def test_staging_buffers_round_trip(ctx):
+    """lfg_staging_create / lfg_staging_destroy (FrameManager::CreateStagingBuffer, src/frame_manager.cpp:199-214):
+    pinned host memory, asynchronous upload from it and read-back into it."""
+    w, h = 200, 64
+    a = rand_frame(w, h)
+    up, down = ctx.staging_create(a.nbytes), ctx.staging_create(a.nbytes)
+    up[:] = a.reshape(-1)
+    down[:] = 0
+    f, g = ctx.create_frame(w, h), ctx.create_frame(w, h)
+    ctx.upload_async(f, up)
+    ctx.copy(f, g)
+    ctx.download_async(g, down)
+    ctx.sync()
+    assert (down.reshape(h, w, 4) == a).all()
+    ctx.staging_destroy(up); ctx.staging_destroy(down)
+    ctx.staging_destroy(ctx.staging_create(1))                    # smallest size; destroy is the only owner
+    with pytest.raises(capi_error(), match="bad argument"):
+        ctx.staging_create(0)
+    for fr in (f, g):
+        ctx.destroy_frame(fr)
+
+
+def capi_error():
+    from linux_fg_amd import capi
+    return capi.LfgError
+
+
+def test_motion_frames_of_2_gib_and_more_take_the_generic_kernel(ctx, oracle):
+    """The 8/16 kernels address with 32-bit byte offsets; a frame whose height x pitch reaches 2 GiB must not reach
+    them (it would alias rows silently).  A 64 x 40 view with rows 57.6 MB apart spans 2.3 GB: lfg_motion routes it
+    to the size_t-indexed generic kernel and the vectors still equal the oracle's."""
+    from linux_fg_amd import capi
+    w, h, pitch = 64, 40, 57_600_000
+    prev, curr = synth.make_pair(w, h, stream=6, shift=(-3, 2))
+    bigs, views = [], []
+    for host in (prev, curr):
+        big = ctx.create_frame(24000, 24000)                      # 2.304e9 bytes >= 39 * pitch + 256
+        v = capi.Context.wrap(big.data, w, h, capi.FORMAT_RGBA8, pitch=pitch)
+        assert v.height * v.pitch >= 2 ** 31
+        ctx.upload(v, host)
+        bigs.append(big); views.append(v)
+    mv = ctx.create_frame(w, h, capi.FORMAT_MV_S8X2)
+    ctx.motion(views[0], views[1], mv)
+    assert (ctx.download(mv) == as_int(oracle.motion(prev, curr))).all()
+    for f in bigs + [mv]:
+        ctx.destroy_frame(f)
 
 
 def test_argument_validation_on_device(ctx):
