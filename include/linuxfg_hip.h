@@ -228,6 +228,14 @@ int  lfg_mv_export_rgba32f(lfg_context *ctx, const lfg_frame *mv, void *device_r
  * in [lo_bits, hi_bits] and returns the number of mismatches (expected 0).  Test-suite use only. */
 int  lfg_selftest_sqrt(lfg_context *ctx, uint32_t lo_bits, uint32_t hi_bits, uint64_t *out_mismatches);
 
+/* The 2x scale kernel cuts the in_height + 1 row steps (2 .. in_height + 2; step r emits output rows 2r-5 and 2r-4)
+ * into one contiguous band per XCD and each band into strips of three lengths (csrc/scale.hip: scale_2x_strip_of, the
+ * same function the kernel evaluates).  This returns strip `index` of XCD `xcd`: its first step and its number of
+ * steps (0 = nothing left of the band) and how many strips an XCD has.  Host arithmetic only, no GPU needed.
+ * Test-suite use: every step must belong to exactly one strip. */
+int  lfg_diag_scale_2x_strip(uint32_t in_height, uint32_t xcd, uint32_t index, uint32_t *out_strips_per_xcd,
+                             int32_t *out_first_step, int32_t *out_steps);
+
 /* ---------------------------------------------------------------- measurement */
 
 /* When enabled, every stage launch is bracketed by HIP events on the context's stream; the

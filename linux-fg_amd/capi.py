@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblinuxfg_hip.so")
+# LFG_LIB: a diagnostic build of the same library (tools/build_variant.sh); never a different implementation.
+LIB_PATH = os.environ.get("LFG_LIB") or os.path.join(_HERE, "liblinuxfg_hip.so")
 
 FORMAT_RGBA8 = 0
 FORMAT_MV_S8X2 = 1
@@ -73,6 +74,7 @@ SIGNATURES = {
     "lfg_interpolate_frames_multi": (_i, [_vp, _FP, _FP, ctypes.POINTER(_FP), ctypes.POINTER(ctypes.c_float), _u32]),
     "lfg_mv_export_rgba32f": (_i, [_vp, _FP, _vp]),
     "lfg_selftest_sqrt": (_i, [_vp, _u32, _u32, ctypes.POINTER(ctypes.c_uint64)]),
+    "lfg_diag_scale_2x_strip": (_i, [_u32, _u32, _u32, ctypes.POINTER(_u32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "lfg_profile_enable": (_i, [_vp, _i]),
     "lfg_profile_reset": (_i, [_vp]),
     "lfg_profile_get": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]),

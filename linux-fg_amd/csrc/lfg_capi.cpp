@@ -86,13 +86,43 @@ int build_axis_table(lfg_context *ctx, int in_size, int out_size, lfg::AxisTable
         for (int k = 0; k < in_size; ++k)
             if (start[(size_t)(2 * k)] != k - 3 || start[(size_t)(2 * k + 1)] != k - 2) { t.pattern_2x = false; break; }
 
+    // The distinct weight rows of a 2x table and each column's class (lfg_internal.hpp: AxisTable).
+    std::vector<uint8_t> cls;
+    std::vector<float> palette;
+    if (t.pattern_2x) {
+        cls.assign(((size_t)out_size + 3u) & ~(size_t)3u, 0);
+        int rows = 0;
+        for (int p = 0; p < out_size && rows >= 0; ++p) {
+            const float *w = &weight[(size_t)p * 6u];
+            int c = 0;
+            while (c < rows && std::memcmp(&palette[(size_t)c * 8u], w, 6 * sizeof(float)) != 0) ++c;
+            if (c == rows) {
+                if (rows == 255) { rows = -1; break; }                       // not a palette any more: leave it out
+                palette.insert(palette.end(), w, w + 6);
+                palette.push_back(0.0f); palette.push_back(0.0f);
+                ++rows;
+            }
+            cls[(size_t)p] = (uint8_t)c;
+        }
+        t.palette_rows = rows > 0 ? rows : 0;
+    }
+
+    if (t.pattern_2x) t.strips_per_xcd = lfg::scale_2x_strips_per_xcd(in_size);
+
+    auto release = [&]() {
+        (void)hipFree(t.d_start); (void)hipFree(t.d_weight); (void)hipFree(t.d_class); (void)hipFree(t.d_palette);
+    };
     LFG_HIP(ctx, hipMalloc((void **)&t.d_start, start.size() * sizeof(int)));
     hipError_t e = hipMalloc((void **)&t.d_weight, weight.size() * sizeof(float));
-    if (e != hipSuccess) { (void)hipFree(t.d_start); return fail_hip(ctx, e, "hipMalloc(weights)"); }
+    if (e == hipSuccess && t.palette_rows) e = hipMalloc((void **)&t.d_class, cls.size());
+    if (e == hipSuccess && t.palette_rows) e = hipMalloc((void **)&t.d_palette, palette.size() * sizeof(float));
+    if (e != hipSuccess) { release(); return fail_hip(ctx, e, "hipMalloc(weights)"); }
     // Synchronous copies: pageable host vectors go out of scope when this function returns.
     e = hipMemcpy(t.d_start, start.data(), start.size() * sizeof(int), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(t.d_weight, weight.data(), weight.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(t.d_start); (void)hipFree(t.d_weight); return fail_hip(ctx, e, "hipMemcpy(tables)"); }
+    if (e == hipSuccess && t.palette_rows) e = hipMemcpy(t.d_class, cls.data(), cls.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess && t.palette_rows) e = hipMemcpy(t.d_palette, palette.data(), palette.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { release(); return fail_hip(ctx, e, "hipMemcpy(tables)"); }
     ctx->tables.push_back(t);
     *out = &ctx->tables.back();
     return LFG_OK;
@@ -103,7 +133,8 @@ int build_axis_table(lfg_context *ctx, int in_size, int out_size, lfg::AxisTable
 void trim_axis_tables(lfg_context *ctx) {
     while (ctx->tables.size() > 14) {
         (void)hipStreamSynchronize(ctx->stream);               // a queued kernel may still read it
-        (void)hipFree(ctx->tables.front().d_start); (void)hipFree(ctx->tables.front().d_weight);
+        lfg::AxisTable &old = ctx->tables.front();
+        (void)hipFree(old.d_start); (void)hipFree(old.d_weight); (void)hipFree(old.d_class); (void)hipFree(old.d_palette);
         ctx->tables.erase(ctx->tables.begin());
     }
 }
@@ -245,7 +276,7 @@ LFG_EXPORT void lfg_context_destroy(lfg_context *ctx) {
     if (ctx->stream != ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     for (auto &s : ctx->prof_pending) { (void)hipEventDestroy(s.begin); (void)hipEventDestroy(s.end); }
     for (auto &p : ctx->prof_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    for (auto &t : ctx->tables) { (void)hipFree(t.d_start); (void)hipFree(t.d_weight); }
+    for (auto &t : ctx->tables) { (void)hipFree(t.d_start); (void)hipFree(t.d_weight); (void)hipFree(t.d_class); (void)hipFree(t.d_palette); }
     if (ctx->mv_tmp.data && ctx->mv_tmp.owned) (void)hipFree(ctx->mv_tmp.data);
     if (ctx->motion_tables) (void)hipFree(ctx->motion_tables);
     if (ctx->motion_ws) (void)hipFree(ctx->motion_ws);
@@ -452,8 +483,7 @@ LFG_EXPORT int lfg_scale(lfg_context *ctx, const lfg_frame *in, lfg_frame *out) 
     if (rc != LFG_OK) return rc;
     rc = build_axis_table(ctx, (int)in->height, (int)out->height, &ty);
     if (rc != LFG_OK) return rc;
-    const bool fast = tx->pattern_2x && ty->pattern_2x && lfg::scale_2x_supported(*in, *out) && (in->pitch % 4u == 0) && (out->pitch % 8u == 0) &&
-                      ((uintptr_t)out->data % 8u == 0) && ((uintptr_t)in->data % 4u == 0);
+    const bool fast = tx->pattern_2x && ty->pattern_2x && tx->palette_rows > 0 && ty->strips_per_xcd > 0 && lfg::scale_2x_supported(*in, *out);
     StageTimer timer(ctx, LFG_STAGE_SCALE);
     hipError_t e = fast ? lfg::launch_scale_2x(ctx->stream, *in, *out, *tx, *ty)
                         : lfg::launch_scale_generic(ctx->stream, *in, *out, *tx, *ty);
@@ -653,6 +683,19 @@ LFG_EXPORT int lfg_selftest_sqrt(lfg_context *ctx, uint32_t lo_bits, uint32_t hi
     (void)hipFree(d);
     if (e != hipSuccess) return fail_hip(ctx, e, "sqrt selftest");
     *out_mismatches = (uint64_t)h;
+    return LFG_OK;
+}
+
+LFG_EXPORT int lfg_diag_scale_2x_strip(uint32_t in_height, uint32_t xcd, uint32_t index, uint32_t *out_strips_per_xcd,
+                                       int32_t *out_first_step, int32_t *out_steps) {
+    if (in_height == 0 || in_height > 32768u || xcd >= 8u) return LFG_ERR_INVALID;
+    const int per = lfg::scale_2x_strips_per_xcd((int)in_height);
+    if (out_strips_per_xcd) *out_strips_per_xcd = (uint32_t)per;
+    if ((int)index >= per) return LFG_ERR_INVALID;
+    int first = 0, steps = 0;
+    lfg::scale_2x_strip_host((int)in_height, (int)xcd, (int)index, first, steps);
+    if (out_first_step) *out_first_step = first;
+    if (out_steps) *out_steps = steps;
     return LFG_OK;
 }
 

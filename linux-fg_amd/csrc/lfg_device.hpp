@@ -90,6 +90,37 @@ __device__ __forceinline__ void load_rgba8_unorm_x10(f32x4 (&p)[10], const int (
         : "memory");
 }
 
+// ---- format-converting buffer loads the compiler DOES track (vmcnt bookkeeping, scheduling): the LLVM intrinsic
+// llvm.amdgcn.raw.ptr.buffer.load.format.v4f32, reached by declaring a function under its name -- hipcc has no
+// __builtin for the format loads.  The conversion comes from the descriptor (word 3): DST_SEL = R,G,B,A,
+// DATA_FORMAT = 8_8_8_8 (10), NUM_FORMAT = USCALED (2): each byte k arrives as the float (float)k, exactly
+// (tests/test_gpu_parity.py::test_format_load_uscaled_exact), so a kernel that wants its texels on a 0..255 scale
+// spends no VALU instruction on unpacking.
+constexpr int kRsrcRaw32 = 0x00020000;                                     // DATA_FORMAT = 32: plain raw buffer
+constexpr int kRsrcRgba8Uscaled = (int)(4u | (5u << 3) | (6u << 6) | (7u << 9) | (2u << 12) | (10u << 15));
+extern "C" __device__ f32x4 lfg_llvm_raw_ptr_buffer_load_format_v4f32(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.ptr.buffer.load.format.v4f32");
+// One RGBA8 texel at byte offset voffset (per lane, range-checked: out of range loads 0) + soffset (wave-uniform,
+// NOT range-checked) as four floats in 0..255.
+__device__ __forceinline__ f32x4 buffer_load_rgba8_format(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
+    return lfg_llvm_raw_ptr_buffer_load_format_v4f32(rsrc, voffset, soffset, 0);
+}
+
+// 16-byte buffer store + the wait states a store of more than 8 bytes needs before its data registers may be
+// rewritten.  The ISA manual asks for one wait state and exempts stores with a scalar offset; gfx950 showed the
+// exempted form losing that race (the following VALU write reached a few pixels per 4K frame, not every run).
+// Here the row offset travels in the vector offset (soffset = 0), so the compiler's hazard recogniser covers the
+// store as documented, two more wait states follow in any case, and csrc/Makefile's check_store_hazard.py fails the
+// build if any dwordx4 store in the object is not followed by them.
+typedef unsigned int u32x4_store __attribute__((ext_vector_type(4)));
+template <int AUX = 2>
+__device__ __forceinline__ void store_b128_guarded(u32x4_store q, __amdgpu_buffer_rsrc_t rsrc, int voffset) {
+    __builtin_amdgcn_raw_buffer_store_b128(q, rsrc, voffset, 0, AUX);
+    // The data registers are an INPUT of the wait states: the compiler must keep them intact until the s_nop has
+    // issued, and it does not move a volatile asm across the store.
+    asm volatile("s_nop 1" : : "v"(q));
+}
+
 // Orders this wave's LDS traffic for cross-lane exchange inside ONE wave: a wavefront-scope fence
 // keeps the compiler from moving a lane's LDS reads above its own LDS write (they never alias for
 // the same lane, but they do across lanes); the hardware executes one wave's LDS ops in order.

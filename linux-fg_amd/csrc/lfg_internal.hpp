@@ -22,6 +22,16 @@ struct AxisTable {
     bool pattern_2x = false;      // start[2k] == k-3 and start[2k+1] == k-2 for every k
     int *d_start = nullptr;       // [out_size]
     float *d_weight = nullptr;    // [out_size][6]
+    // pattern_2x tables only.  At exact 2x the shader's per-column fp32 arithmetic yields a handful of DISTINCT weight
+    // rows (the nominal phase row for ~97 % of the columns, a few rounding variants, the renormalised border rows:
+    // 31 rows at 1920 -> 3840), so the 2x kernel fetches a one-byte class per output column and the row from a small
+    // palette that stays in L1, instead of 96 bytes of table per lane: d_class[p] indexes d_palette[class][8]
+    // (six weights + two pad floats, 32-byte rows).  palette_rows == 0: too many distinct rows, not built.
+    uint8_t *d_class = nullptr;   // [out_size rounded up to 4]
+    float *d_palette = nullptr;   // [palette_rows][8]
+    int palette_rows = 0;
+    // pattern_2x tables of the VERTICAL axis: strips per XCD of the 2x kernel (scale.hip: scale_2x_strip_of).
+    int strips_per_xcd = 0;
 };
 
 struct MotionWorkspaceLayout { size_t list, umin, count, tileFlags, segDone, segMap, queueCount, order, plan, auxList, auxUmin, auxCount,
@@ -95,6 +105,8 @@ hipError_t launch_scale_generic(hipStream_t s, const lfg_frame &in, const lfg_fr
 hipError_t launch_scale_2x(hipStream_t s, const lfg_frame &in, const lfg_frame &out,
                            const AxisTable &tx, const AxisTable &ty);
 bool scale_2x_supported(const lfg_frame &in, const lfg_frame &out);
+int scale_2x_strips_per_xcd(int inH);
+void scale_2x_strip_host(int inH, int xcd, int index, int &first, int &steps);
 hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                     const lfg_frame &mv, const uint32_t *tileFlags, const uint32_t *rank2scan,
                                     unsigned long long *merge = nullptr, size_t mergeRowStride = 0,

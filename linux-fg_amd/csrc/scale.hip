@@ -12,16 +12,16 @@
 // Roofline: HBM.  Algorithmic bytes = 4*(Win*Hin + Wout*Hout).
 //
 // Two kernels:
-//   scale_2x_kernel      out == 2*in on both axes (every benchmark config).  One WAVE owns a strip
-//                        of 64 input columns (= 128 output columns) and walks down the rows:
-//                        coalesced uchar4 row loads -> LDS (one row, as float4) so each lane can
-//                        read its 7 horizontal neighbours -> horizontal 6-tap sums for its two
-//                        output columns -> a rolling six-row register window -> vertical 6-tap
-//                        sums -> 8-byte coalesced stores.  No workgroup barrier: waves are
-//                        independent, LDS is only the cross-lane exchange for the horizontal taps.
+//   scale_2x_kernel      out == 2*in on both axes (every benchmark config).  One WAVE owns a strip of 120 input
+//                        columns (= 240 output columns, two input columns per lane) and walks down a few rows:
+//                        format-converting row loads -> a rolling six-row register window of floats -> vertical
+//                        6-tap sums -> wave-private LDS exchange with the neighbouring lanes -> horizontal 6-tap
+//                        sums -> 16-byte coalesced stores.  No workgroup barrier: waves are independent.
 //   scale_generic_kernel any sizes (down-scaling included): one thread per output pixel, 36
 //                        table-weighted texel reads through L1/L2.
+#include <algorithm>
 #include <cstdio>
+#include <vector>
 
 #include "lfg_device.hpp"
 #include "lfg_internal.hpp"
@@ -77,22 +77,75 @@ hipError_t launch_scale_generic(hipStream_t s, const lfg_frame &in, const lfg_fr
 }
 
 // ------------------------------------------------------------------------------ exact 2x
+//
+// Work decomposition.  At exact 2x, output rows 2r-5 and 2r-4 both read input rows r-5..r, and
+// output columns 2c+1 and 2c+2 both read input columns c-2..c+3 (host-verified: AxisTable::pattern_2x).
+//
+//   lane   owns TWO adjacent input columns c0 = B-4+2L, c1 = c0+1 and therefore FOUR adjacent output columns
+//          2c0..2c0+3 = one 16-byte store per output row, no lane exchange for the store;
+//   wave   64 lanes = 128 input columns of which the middle 120 (lanes 2..61) are owned: the two lanes on either side
+//          only feed their columns to the horizontal taps of their neighbours (3 columns of halo per side);
+//   strip  S emitting steps; step r loads input row r, emits output rows 2r-5 and 2r-4.
+//
+// VERTICAL FIRST.  The rolling window holds the six most recent INPUT rows of the lane's two columns as floats (they
+// arrive as floats: buffer_load_format_xyzw through an 8_8_8_8 USCALED descriptor converts in the texture-address
+// unit, no v_cvt_f32_ubyte).  A step forms the vertical 6-tap sums of its two output rows at the lane's two input
+// columns (48 packed FMAs, weights wave-uniform), hands them to the neighbouring lanes through a wave-private LDS
+// slab (4 x ds_write_b128, 12 x ds_read_b128, no workgroup barrier: one wave's DS operations execute in order), and
+// finishes with the horizontal 6-tap sums of its 2 x 4 output pixels (96 packed FMAs), v_cvt_pk_u8_f32 (round half
+// to even + saturate) and two 16-byte stores.  Because the window holds raw input rows, the five rows a strip needs
+// before its first output cost five row loads and NO arithmetic -- strips can be short, a frame becomes several
+// thousand waves in more than one generation, and a wave that waits for its first rows shares its SIMD with waves
+// that are computing.  (The previous kernel filtered horizontally first: every strip recomputed five rows of
+// horizontal sums, so strips had to be long, all waves started together and spent the first 3.5 us waiting.)
+//
+// Cost per step and wave: 144 v_pk_fma_f32 + 32 v_cvt_pk_u8_f32 + ~10 other VALU for 2 x 240 owned output pixels =
+// 97 VALU cycles per 64 output pixels against a floor of 88 (36 FMAs + 4 conversions per pixel), 6.7 % of it the halo lanes.
+//
+// Everything is straight-line and branch-free per strip (out-of-range buffer offsets instead of predicates), so the
+// compiler's vmcnt bookkeeping is exact and each step waits only for the row it consumes.
 
-constexpr int kStripCols = 64;      // input columns per wave (one per lane)
-constexpr int kRowBuf = 72;         // 64 + 3 left + 3 right halo, rounded up to 72 float4
-constexpr int kOobOffset = (int)0x80000000;   // buffer offset that always fails the range check
+constexpr int kOwnedLanes = 60;                       // lanes 2..61
+constexpr int kOwnedCols = 2 * kOwnedLanes;           // input columns owned per wave
+constexpr int kOobOffset = (int)0x80000000;           // buffer offset that always fails the range check
 #ifndef LFG_STORE_AUX
 #define LFG_STORE_AUX 2
 #endif
-constexpr int kStoreAux = LFG_STORE_AUX;      // gfx940+ cache policy bits: 1 = sc0, 2 = nt, 16 = sc1
+constexpr int kStoreAux = LFG_STORE_AUX;              // gfx940+ cache policy bits: 1 = sc0, 2 = nt, 16 = sc1
+// Strip lengths (emitting steps) of the three dispatch layers, see scale_2x_strip_plan().
+#ifndef LFG_SCALE_L0
+#define LFG_SCALE_L0 7
+#endif
+#ifndef LFG_SCALE_L1
+#define LFG_SCALE_L1 6
+#endif
+#ifndef LFG_SCALE_L2
+#define LFG_SCALE_L2 4
+#endif
+#define LFG_SCALE_STEPS LFG_SCALE_L0                  // the longest strip: what the kernel is unrolled to
+#ifndef LFG_SCALE_STAGGER
+#define LFG_SCALE_STAGGER 0                           // x 64 clocks between the first loads of the waves sharing a SIMD
+#endif
+#ifndef LFG_SCALE_AHEAD
+#define LFG_SCALE_AHEAD 1                             // input rows requested beyond the six of the current step
+#endif
+#ifndef LFG_SCALE_PACKED_LOADS
+#define LFG_SCALE_PACKED_LOADS 0                      // 1: 8-byte row loads + v_cvt unpacking instead of format loads
+#endif
+#ifndef LFG_SCALE_WAVES
+#define LFG_SCALE_WAVES 3                             // waves per SIMD the register allocation aims at
+#endif
 
-// Four channels as two register pairs: the weighted sums are written on pairs so that they compile to
-// v_pk_fma_f32 (two FMAs per instruction).  Packed FMAs have no higher lane throughput than plain ones
-// on gfx950, but a wave issues one VALU instruction per 4 cycles on its own, and this kernel is bound
-// by per-wave issue latency, not by SIMD throughput: halving the instruction count of the FMA blocks
-// shortens every step.
+// Four channels as two register pairs, so the weighted sums compile to v_pk_fma_f32 / v_pk_mul_f32: the same lane
+// throughput as plain FMAs on gfx950 but half the issue slots, which the LDS and memory instructions need.
 struct F4 { f32x2 lo, hi; };          // lo = (r, g), hi = (b, a)
 
+__device__ __forceinline__ F4 to_f4(f32x4 v) { return F4{f32x2{v.x, v.y}, f32x2{v.z, v.w}}; }
+__device__ __forceinline__ f32x4 to_v4(const F4 &t) { return f32x4{t.lo.x, t.lo.y, t.hi.x, t.hi.y}; }
+__device__ __forceinline__ F4 mul4(float w, const F4 &t) {
+    const f32x2 ww = {w, w};
+    return F4{ww * t.lo, ww * t.hi};
+}
 __device__ __forceinline__ void fma4(F4 &acc, float w, const F4 &t) {
     const f32x2 ww = {w, w};
     acc.lo = __builtin_elementwise_fma(ww, t.lo, acc.lo);
@@ -100,229 +153,366 @@ __device__ __forceinline__ void fma4(F4 &acc, float w, const F4 &t) {
 }
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ F4 unpack255(uint32_t p) { return F4{f32x2{byte0(p), byte1(p)}, f32x2{byte2(p), byte3(p)}}; }
+// Strips of the 2x kernel for an input of inH rows.  The inH + 1 steps r = 2 .. inH + 2 are cut into eight contiguous
+// bands, one per XCD; a band into stripsPerXcd strips of three lengths, longest first, in the order their workgroups
+// are dispatched: strip i of XCD x starts at step `first` and has `steps` steps (0: nothing left of the band).
+// Why three lengths: the waves of a launch all start within half a microsecond and every one first needs six input
+// rows; the three workgroups a CU holds get going about 1.7 us apart (per-wave stamps: first vertical pass done at
+// 1.8 / 3.5 / 5.5 us -- the oldest wave of a SIMD wins the issue arbitration), so with equal strips the workgroups
+// that started last also finish last, alone on their SIMDs; with L0 > L1 > L2 the three finish together.  Nothing
+// depends on the dispatch order but the run time.  Host and device evaluate the same function.
+__host__ __device__ inline void scale_2x_strip_of(int inH, int x, int i, int stripsPerXcd, int &first, int &steps) {
+    const int total = inH + 1;
+    const int b0 = 2 + (total * x) / 8, b1 = 2 + (total * (x + 1)) / 8;
+    const int k = stripsPerXcd / 3;
+    const int i0 = i < k ? i : k, i1 = i < k ? 0 : (i < 2 * k ? i - k : k), i2 = i < 2 * k ? 0 : i - 2 * k;
+    first = b0 + i0 * LFG_SCALE_L0 + i1 * LFG_SCALE_L1 + i2 * LFG_SCALE_L2;
+    const int len = i < k ? LFG_SCALE_L0 : (i < 2 * k ? LFG_SCALE_L1 : LFG_SCALE_L2);
+    const int left = b1 - first;
+    steps = left < len ? (left > 0 ? left : 0) : len;
+}
 
-// At exact 2x, output columns 2k and 2k+1 (lane = input column k) read input columns k-3..k+2 and
-// k-2..k+3; output rows 2r-5 and 2r-4 both read input rows r-5..r (host-verified: AxisTable::pattern_2x).
-// Step r therefore loads input row r, forms the two horizontal sums, and emits those two output rows
-// from the six most recent horizontal rows.  A wave runs STEPS emitting steps after five warm-up
-// steps that fill the window.
-//
-// The whole strip is unrolled and BRANCH-FREE: every load and store is a raw buffer access whose
-// offset is pushed out of range when it must not happen (lanes past the right edge, rows outside
-// the image; the hardware drops out-of-range stores and returns 0 for loads).  Straight-line code
-// lets the compiler count outstanding memory operations exactly, so each step waits only for the
-// row it consumes (prefetched six steps earlier) instead of draining loads AND stores at every loop
-// back-edge, which is what made the looped version latency-bound.
+typedef f32x4 (*SlabPtr)[2][2][68];                    // [step parity][row A | row B][even | odd column][lane + 2]
+
+// One strip: STEPS unrolled steps of which the first n emit (n <= STEPS; the others' stores are switched off).
 template <int STEPS>
-__global__ __launch_bounds__(256, 3) void scale_2x_kernel(
+__device__ __forceinline__ void scale_2x_strip(
     const uint8_t *__restrict__ in, int inW, int inH, int inPitch,
     uint8_t *__restrict__ out, int outW, int outH, int outPitch,
-    const float *__restrict__ weightX, const float *__restrict__ weightY,
-    int colGroups, int strips
+    const uint8_t *__restrict__ classX, const float *__restrict__ paletteX, const float *__restrict__ weightY,
+    int rBegin, int n, int cg, int lane, SlabPtr slabW
 #ifdef LFG_DIAG_STAMPS
-    , unsigned long long *stamps     // diagnostic build only: per-wave {start, after prologue, end} s_memrealtime
+    , unsigned long long *stamps, unsigned long long tStart, unsigned long long clk0, int st, int wv
 #endif
     ) {
-    constexpr int T = STEPS + 5;
 #ifdef LFG_DIAG_STAMPS
-    const unsigned long long tStart = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tS[LFG_SCALE_STEPS + 2] = {};
+    tS[0] = tStart;
 #endif
-    __shared__ __attribute__((aligned(16))) F4 rowbuf[4][kRowBuf];
-    __shared__ __attribute__((aligned(16))) float wyS[4][STEPS * 2 * 6];
-
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int gw = (int)blockIdx.x * 4 + wv;              // global wave id, wave-uniform
-    if (gw >= colGroups * strips) return;                 // no workgroup barrier below: safe
-    const int cg = gw % colGroups, st = gw / colGroups;
-    const int icx0 = cg * kStripCols;
-    const int k = icx0 + lane;                            // this lane's input column
-    // Emitting steps r = rBegin .. rBegin+STEPS-1 out of 2 .. inH+2; the last strip is shifted up
-    // to full length (it re-emits a few rows of its neighbour with identical values).
-    const int rBegin = min(2 + st * STEPS, inH + 3 - STEPS);
+    // (a strip reads n + 5 input rows; the unrolled sequence requests rows as if it had STEPS steps)
+    constexpr int T = STEPS + 5;
+    const int c0 = cg * kOwnedCols - 4 + 2 * lane;        // the lane's even input column (c1 = c0 + 1)
+    const bool owned = lane >= 2 && lane < 2 + kOwnedLanes && c0 < inW;
     const int rFirst = rBegin - 5;
-    F4 *buf = rowbuf[wv];
-    float *wys = wyS[wv];
 
     const __amdgpu_buffer_rsrc_t rIn = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint8_t *>(in), 0, inH * inPitch, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rOut = __builtin_amdgcn_make_buffer_rsrc(out, 0, outH * outPitch, 0x00020000);
+        const_cast<uint8_t *>(in), 0, inH * inPitch, kRsrcRgba8Uscaled);
+    const __amdgpu_buffer_rsrc_t rOut = __builtin_amdgcn_make_buffer_rsrc(out, 0, outH * outPitch, kRsrcRaw32);
 
-    // Vertical weights of the strip's 2*STEPS output rows -> wave-private LDS once; the steps read them
-    // with broadcast LDS reads (a scalar load per output row would sit on the critical path).
+    // Input columns outside the image carry weight 0 in every tap that reaches them; they only have to load something
+    // finite, and an out-of-range offset loads 0.  (Rows are clamped instead: the scalar row offset is not part of
+    // the hardware's range check.)
+    const int voff0 = (c0 >= 0 && c0 < inW) ? c0 * 4 : kOobOffset;
+    const int voff1 = (c0 + 1 >= 0 && c0 + 1 < inW) ? (c0 + 1) * 4 : kOobOffset;
+    const uint32_t cls = *reinterpret_cast<const uint32_t *>(classX + 2 * clampi(c0, 0, inW - 2));   // lanes outside the image never store
+#if LFG_SCALE_PACKED_LOADS
+    // One 8-byte load per lane and row (both columns, 512 contiguous bytes per wave) into a two-register staging
+    // slot; the row is unpacked (8 x v_cvt_f32_ubyte) when it enters the window.
+    const __amdgpu_buffer_rsrc_t rInRaw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(in), 0, inH * inPitch, kRsrcRaw32);
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    constexpr int W = 6;                                   // float rows of the window
+    constexpr int kStage = 1 + LFG_SCALE_AHEAD;            // packed rows in flight
+    u32x2 stage[kStage];
+    auto request_row = [&](int t) {                       // strip row t -> staging slot t % kStage
+        const int rowOff = clampi(rFirst + t, 0, inH - 1) * inPitch;
+        stage[t % kStage] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rInRaw, voff0, rowOff, 0));
+    };
+    F4 win[W][2];
+    auto admit_row = [&](int t) {                         // staging -> window slot t % W, as floats in 0..255
+        const u32x2 p = stage[t % kStage];
+        win[t % W][0] = F4{f32x2{byte0(p.x), byte1(p.x)}, f32x2{byte2(p.x), byte3(p.x)}};
+        win[t % W][1] = F4{f32x2{byte0(p.y), byte1(p.y)}, f32x2{byte2(p.y), byte3(p.y)}};
+    };
+    // the first six rows go straight into the window
     {
-        const int oyFirst = 2 * rBegin - 5;
-        constexpr int kChunks = (STEPS * 12 + 63) / 64;
-        float wv_[kChunks];
+        u32x2 first[6];
 #pragma unroll
-        for (int c = 0; c < kChunks; ++c) {             // all loads first: one memory latency, not kChunks
-            const int i = c * 64 + lane;
-            const int oy = min(max(oyFirst + i / 6, 0), outH - 1);
-            wv_[c] = weightY[(size_t)oy * 6u + (size_t)(i % 6)];
+        for (int t = 0; t < 6; ++t) {
+            const int rowOff = clampi(rFirst + t, 0, inH - 1) * inPitch;
+            first[t] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rInRaw, voff0, rowOff, 0));
         }
 #pragma unroll
-        for (int c = 0; c < kChunks; ++c) {
-            const int i = c * 64 + lane;
-            const int oy = oyFirst + i / 6;
-            if (i < STEPS * 12) wys[i] = (oy >= 0 && oy < outH) ? wv_[c] : 0.0f;
+        for (int t = 6; t < 6 + kStage && t < T; ++t) request_row(t);
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            win[t][0] = F4{f32x2{byte0(first[t].x), byte1(first[t].x)}, f32x2{byte2(first[t].x), byte3(first[t].x)}};
+            win[t][1] = F4{f32x2{byte0(first[t].y), byte1(first[t].y)}, f32x2{byte2(first[t].y), byte3(first[t].y)}};
         }
     }
-
-    // Horizontal weights of the lane's two output columns: 12 consecutive floats, three 16-byte loads
-    // (clamped for lanes past the right edge; those lanes never store).
-    const int kc = min(k, inW - 1);
-    float wa[6], wb[6];
-    {
-        const float4 *wp = reinterpret_cast<const float4 *>(weightX + (size_t)(2 * kc) * 6u);
-        const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2];
-        wa[0] = w0.x; wa[1] = w0.y; wa[2] = w0.z; wa[3] = w0.w; wa[4] = w1.x; wa[5] = w1.y;
-        wb[0] = w1.z; wb[1] = w1.w; wb[2] = w2.x; wb[3] = w2.y; wb[4] = w2.z; wb[5] = w2.w;
-    }
-
-    // Row-buffer slot i holds input column icx0 - 3 + i: every lane loads slot `lane`, lanes 0..7 also
-    // slot 64 + lane (the other lanes' second load is out of range and returns 0).
-    const int offA = clampi(icx0 - 3 + lane, 0, inW - 1) * 4;
-    const int offB = lane < kRowBuf - 64 ? clampi(icx0 - 3 + 64 + lane, 0, inW - 1) * 4 : kOobOffset;
-    // Store offsets of the lane pair (2j, 2j+1): the even lane writes 16 bytes of the upper output row
-    // of a step at column 4j, the odd lane 16 bytes of the lower row at the same column.  The scalar
-    // part of the address is the upper row's offset.
-    const bool odd = (lane & 1) != 0;
-    const int offLane = k < inW ? (odd ? (k - 1) * 8 + outPitch : k * 8) : kOobOffset;
-    auto load_row = [&](int r, uint32_t &pa, uint32_t &pb) {
-        const int rowOff = clampi(r, 0, inH - 1) * inPitch;              // wave-uniform
-        pa = __builtin_amdgcn_raw_buffer_load_b32(rIn, offA, rowOff, 0);
-        pb = __builtin_amdgcn_raw_buffer_load_b32(rIn, offB, rowOff, 0);
+    // called once the vertical pass of step s has consumed row s: rows up to s+5 are in the window; admit row s+6 into
+    // the freed slot (it was requested kStage steps ago) and request row s+6+kStage.
+    auto advance = [&](int s) {
+        if (s + 6 < T) admit_row(s + 6);
+        if (s + 6 + kStage < T) request_row(s + 6 + kStage);
+    };
+#else
+    auto load_row = [&](int r, F4 &a, F4 &b) {
+        const int rowOff = clampi(r, 0, inH - 1) * inPitch;                 // wave-uniform
+        a = to_f4(buffer_load_rgba8_format(rIn, voff0, rowOff));
+        b = to_f4(buffer_load_rgba8_format(rIn, voff1, rowOff));
     };
 
-    constexpr int kAhead = 3;                              // rows in flight per wave
-#ifdef LFG_DIAG_STAMPS
-    const unsigned long long tPro = __builtin_amdgcn_s_memrealtime();
-#endif
-    F4 win[6][2];
-    uint32_t pa[kAhead], pb[kAhead];
+    // The window: six input rows x two columns, plus LFG_SCALE_AHEAD rows in flight behind them.  Everything the
+    // first steps need is requested before anything else.
+    constexpr int W = 6 + LFG_SCALE_AHEAD;
+    F4 win[W][2];
 #pragma unroll
-    for (int u = 0; u < kAhead; ++u) load_row(rFirst + u, pa[u], pb[u]);
+    for (int t = 0; t < W && t < T; ++t) load_row(rFirst + t, win[t][0], win[t][1]);
+    // called once the vertical pass of step s has consumed row s: its slot takes row s + W.
+    auto advance = [&](int s) {
+        if (s + W < T) load_row(rFirst + s + W, win[s % W][0], win[s % W][1]);
+    };
+#endif
+
+    // Horizontal weights of the lane's four output columns 2c0 .. 2c0+3: one class byte per column (a 4-byte load,
+    // requested before anything else: its answer is the address of the next loads), then the class's row of the
+    // palette -- 31 distinct rows at 1920 -> 3840, one of them for 97 % of the columns, so nearly every lane of every
+    // wave reads the same 32 bytes (L1) instead of its own 96 bytes of table.
+    float wx[4][6];
+    {
+        float4 lo[4]; float2 hi[4];
+#pragma unroll
+        for (int oc = 0; oc < 4; ++oc) {
+            const float *row = paletteX + ((cls >> (8 * oc)) & 0xffu) * 8u;
+            lo[oc] = *reinterpret_cast<const float4 *>(row);
+            hi[oc] = *reinterpret_cast<const float2 *>(row + 4);
+        }
+#pragma unroll
+        for (int oc = 0; oc < 4; ++oc) {
+            wx[oc][0] = lo[oc].x; wx[oc][1] = lo[oc].y; wx[oc][2] = lo[oc].z; wx[oc][3] = lo[oc].w;
+            wx[oc][4] = hi[oc].x; wx[oc][5] = hi[oc].y;
+        }
+    }
+
+    const int offLane = owned ? c0 * 8 : kOobOffset;       // byte offset of output column 2 * c0
+
+    // Vertical weights are wave-uniform: scalar loads, twelve floats per step (six per output row), requested a step
+    // ahead (scalar loads return out of order with LDS traffic, so a wait while one is in flight is a full lgkmcnt(0)).
+    auto load_wy = [&](int r, float (&a)[6], float (&b)[6]) {
+        const float *pa = weightY + (size_t)clampi(2 * r - 5, 0, outH - 1) * 6u;
+        const float *pb = weightY + (size_t)clampi(2 * r - 4, 0, outH - 1) * 6u;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { a[j] = pa[j]; b[j] = pb[j]; }
+    };
+    // Vertical 6-tap sums of step s (output rows 2r-5 | 2r-4) at the lane's two input columns.  Window rows r-5 .. r
+    // are the strip's rows s .. s+5, held in slots (s + j) % W.
+    auto vertical = [&](int s, const float (&wyA)[6], const float (&wyB)[6], F4 (&vA)[2], F4 (&vB)[2]) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#ifdef LFG_DIAG_NO_MATH        // timing experiments only: the loads stay alive, the arithmetic goes
+#pragma unroll
+            for (int j = 0; j < 6; ++j) asm volatile("" : : "v"(win[(s + j) % W][c].lo), "v"(win[(s + j) % W][c].hi));
+            vA[c] = mul4(wyA[0], win[s % W][c]); vB[c] = mul4(wyB[5], win[(s + 5) % W][c]);
+#else
+            vA[c] = mul4(wyA[0], win[s % W][c]);
+            vB[c] = mul4(wyB[0], win[s % W][c]);
+#pragma unroll
+            for (int j = 1; j < 6; ++j) {
+                fma4(vA[c], wyA[j], win[(s + j) % W][c]);
+                fma4(vB[c], wyB[j], win[(s + j) % W][c]);
+            }
+#endif
+        }
+    };
+    // Exchange slab of step s: [step parity][row A | row B][even | odd column][lane + 2].
+    auto slab_of = [&](int s, int half, int odd) -> f32x4 * { return &slabW[s & 1][half][odd][2]; };
+    auto publish = [&](int s, const F4 (&vA)[2], const F4 (&vB)[2]) {
+        slab_of(s, 0, 0)[lane] = to_v4(vA[0]); slab_of(s, 0, 1)[lane] = to_v4(vA[1]);
+        slab_of(s, 1, 0)[lane] = to_v4(vB[0]); slab_of(s, 1, 1)[lane] = to_v4(vB[1]);
+    };
+
+    // Software pipeline: while the sums of step s travel through the slab, the vertical pass of step s+1 runs; the
+    // two slabs alternate, so nothing waits for a write to be read back except the very first step.
+    float wy[2][2][6];                                     // [step parity][row A | row B][tap]
+    F4 v[2][2][2];                                         // [step parity][row A | row B][column]
+    load_wy(rBegin, wy[0][0], wy[0][1]);
+    if (STEPS > 1) load_wy(rBegin + 1, wy[1][0], wy[1][1]);
+    vertical(0, wy[0][0], wy[0][1], v[0][0], v[0][1]);
+#ifdef LFG_DIAG_STAMPS
+    asm volatile("" : "+v"(v[0][0][0].lo), "+v"(v[0][1][1].hi)); tS[1] = __builtin_amdgcn_s_memrealtime();
+#endif
+    advance(0);                                            // the oldest row is dead: its slot takes a later row
+    publish(0, v[0][0], v[0][1]);
 
 #pragma unroll
-    for (int s = 0; s < T; ++s) {
-        const int r = rFirst + s;
-        const int u = s % 6;                               // window slot of this step
-        // 1. this row's pixels -> LDS as floats (0..255 scale); request the row kAhead steps ahead.
-        const int v = s % kAhead;
-        buf[lane] = unpack255(pa[v]);
-        if (lane < kRowBuf - 64) buf[64 + lane] = unpack255(pb[v]);
-        if (s + kAhead < T) load_row(r + kAhead, pa[v], pb[v]);
+    for (int s = 0; s < STEPS; ++s) {
+        const int r = rBegin + s;
+        const int oyA = 2 * r - 5, oyB = 2 * r - 4;        // wave-uniform; oyA >= -1, oyB <= outH
+        const int p = s & 1, q = p ^ 1;
         wave_lds_sync();
-        // 2. the lane's 7 horizontal neighbours (input columns k-3 .. k+3).
-        F4 t[7];
+        // neighbours' sums of row A of this step: input columns c0-3 .. c0+4 are
+        //   o[L-2] e[L-1] o[L-1] | own e, own o | e[L+1] o[L+1] e[L+2]
+        F4 x[2][8];
 #pragma unroll
-        for (int j = 0; j < 7; ++j) t[j] = buf[lane + j];
-        wave_lds_sync();
-        F4 h0{f32x2{0, 0}, f32x2{0, 0}}, h1{f32x2{0, 0}, f32x2{0, 0}};
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            fma4(h0, wa[j], t[j]);
-            fma4(h1, wb[j], t[j + 1]);
+        for (int half = 0; half < 2; ++half) {
+            const f32x4 *se = slab_of(s, half, 0), *so = slab_of(s, half, 1);
+            x[half][0] = to_f4(so[lane - 2]); x[half][1] = to_f4(se[lane - 1]); x[half][2] = to_f4(so[lane - 1]);
+            x[half][3] = v[p][half][0]; x[half][4] = v[p][half][1];
+            x[half][5] = to_f4(se[lane + 1]); x[half][6] = to_f4(so[lane + 1]); x[half][7] = to_f4(se[lane + 2]);
         }
-        win[u][0] = h0; win[u][1] = h1;
-        // 3. emit output rows 2r-5 and 2r-4 from window rows r-5..r = slots (u+1+j)%6.
-        if (s >= 5) {
-            uint32_t px[2][2];                                         // [output row half][column]
+        // the next step's vertical pass, its row request and its hand-over, while those reads are in flight
+        if (s + 1 < STEPS) {                               // (also for the last step of a shorter strip: cheaper than a branch)
+            vertical(s + 1, wy[q][0], wy[q][1], v[q][0], v[q][1]);
+            advance(s + 1);
+            publish(s + 1, v[q][0], v[q][1]);
+            if (s + 2 < STEPS) load_wy(r + 2, wy[p][0], wy[p][1]);
+        }
+        // horizontal 6-tap sums, rounding, store
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const float2 *wyp = reinterpret_cast<const float2 *>(wys + (2 * (s - 5) + half) * 6);
-                const float2 wy01 = wyp[0], wy23 = wyp[1], wy45 = wyp[2];
-                const float wy[6] = {wy01.x, wy01.y, wy23.x, wy23.y, wy45.x, wy45.y};
-                F4 o0{f32x2{0, 0}, f32x2{0, 0}}, o1{f32x2{0, 0}, f32x2{0, 0}};
+        for (int half = 0; half < 2; ++half) {
+            uint32_t px[4];
 #pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    fma4(o0, wy[j], win[(u + 1 + j) % 6][0]);
-                    fma4(o1, wy[j], win[(u + 1 + j) % 6][1]);
-                }
-                px[half][0] = pack_rgba8_255(o0.lo.x, o0.lo.y, o0.hi.x, o0.hi.y);
-                px[half][1] = pack_rgba8_255(o1.lo.x, o1.lo.y, o1.hi.x, o1.hi.y);
+            for (int oc = 0; oc < 4; ++oc) {
+                const int first = (oc + 1) >> 1;           // output column 2c0+oc reads x[first .. first+5]
+                F4 o = mul4(wx[oc][0], x[half][first]);
+#ifdef LFG_DIAG_NO_MATH
+#pragma unroll
+                for (int j = 1; j < 6; ++j) asm volatile("" : : "v"(x[half][first + j].lo), "v"(x[half][first + j].hi), "v"(wx[oc][j]));
+#else
+#pragma unroll
+                for (int j = 1; j < 6; ++j) fma4(o, wx[oc][j], x[half][first + j]);
+#endif
+                px[oc] = pack_rgba8_255(o.lo.x, o.lo.y, o.hi.x, o.hi.y);
             }
-            // One 16-byte store per lane instead of two 8-byte ones (8-byte-per-lane stores are
-            // issue-bound at ~7 B/clk/CU on gfx950, which capped this kernel at ~7.5 us).  Lanes pair up:
-            // the even lane takes both lanes' pixels of the upper row (4 adjacent columns), the odd
-            // lane both lanes' pixels of the lower row.  The exchange is one DPP quad_perm [1,0,3,2]
-            // (swap neighbours) per dword of the pair each lane gives away.
-            const uint32_t g0 = odd ? px[0][0] : px[1][0], g1 = odd ? px[0][1] : px[1][1];
-            const uint32_t x0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)g0, 0xB1, 0xF, 0xF, false);
-            const uint32_t x1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)g1, 0xB1, 0xF, 0xF, false);
-            u32x4 q;
-            q.x = odd ? x0 : px[0][0]; q.y = odd ? x1 : px[0][1];
-            q.z = odd ? px[1][0] : x0; q.w = odd ? px[1][1] : x1;
-            const int oy0 = 2 * r - 5;                                 // upper row (wave-uniform), >= -1
-            // Only two steps of a frame are special: oy0 == -1 (no upper row; the lower row is row 0, so
-            // the odd lanes drop the extra pitch) and oy0 + 1 == outH (no lower row).
-            const int sub = oy0 < 0 ? outPitch : 0;                    // scalar
-            const bool ok = odd ? (oy0 + 1 < outH) : (oy0 >= 0);
-            const int voff = ok ? offLane - sub : kOobOffset;
-            __builtin_amdgcn_raw_buffer_store_b128(q, rOut, voff, max(oy0, 0) * outPitch, kStoreAux);
-            // A buffer store of more than 8 bytes reads its data registers over several cycles after issue; a VALU
-            // write to them in the next slots wins the race (seen on gfx950 as the next row's unpacked float in
-            // the first pixel of lanes 12/14 mod 16, a few dozen pixels per 4K frame, not every run).  The
-            // compiler's hazard recogniser leaves the case "scalar register in the soffset field" out, so the
-            // wait states are spelled out here.
-            asm volatile("s_nop 7");
+            const int oy = half ? oyB : oyA;
+            const bool rowOk = s < n && (half ? (oyB < outH) : (oyA >= 0));      // scalar
+            const int voff = rowOk ? offLane + oy * outPitch : kOobOffset;
+#ifdef LFG_DIAG_NO_STORE
+            asm volatile("" : : "v"(px[0]), "v"(px[1]), "v"(px[2]), "v"(px[3]), "v"(voff));
+#else
+            store_b128_guarded<kStoreAux>(u32x4{px[0], px[1], px[2], px[3]}, rOut, voff);
+#endif
         }
-        __builtin_amdgcn_sched_barrier(0);     // keep each step's registers local
+#ifdef LFG_DIAG_STAMPS
+        tS[2 + s] = __builtin_amdgcn_s_memrealtime();
+#endif
     }
 #ifdef LFG_DIAG_STAMPS
     if (stamps && lane == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        stamps[(size_t)gw * 4 + 0] = tStart; stamps[(size_t)gw * 4 + 1] = tPro;
-        stamps[(size_t)gw * 4 + 2] = __builtin_amdgcn_s_memrealtime();
-        stamps[(size_t)gw * 4 + 3] = 0;
+        const size_t wid = ((size_t)blockIdx.x * 4 + wv) * (LFG_SCALE_STEPS + 4);
+        unsigned hw = 0;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc = 0;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        for (int i = 0; i < LFG_SCALE_STEPS + 2; ++i) stamps[wid + i] = i < n + 2 ? tS[i] : tS[n + 1];
+        stamps[wid + LFG_SCALE_STEPS + 2] = ((unsigned long long)xcc << 32) | hw;
+        // shader clocks over the wave's life (s_memtime) in the upper half: clock = that / (end - start) x 100 MHz
+        stamps[wid + LFG_SCALE_STEPS + 3] = ((__builtin_amdgcn_s_memtime() - clk0) << 32) | ((unsigned)n << 24) | ((unsigned)st << 8) | (unsigned)cg;
     }
 #endif
 }
 
-constexpr int kScaleSteps = 11;
+__global__ __launch_bounds__(256, LFG_SCALE_WAVES) void scale_2x_kernel(
+    const uint8_t *__restrict__ in, int inW, int inH, int inPitch,
+    uint8_t *__restrict__ out, int outW, int outH, int outPitch,
+    const uint8_t *__restrict__ classX, const float *__restrict__ paletteX, const float *__restrict__ weightY,
+    int colGroups, int stripsPerXcd
+#ifdef LFG_DIAG_STAMPS
+    , unsigned long long *stamps     // diagnostic build only: per wave {start, first rows in, each step's end} s_memrealtime + hw id
+#endif
+    ) {
+#ifdef LFG_DIAG_STAMPS
+    const unsigned long long tStart = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
+#endif
+    // Wave-private exchange slabs: [wave][step parity][row A | row B][even column of a lane | odd column][lane + 2].
+    __shared__ __attribute__((aligned(16))) f32x4 slab[4][2][2][2][68];
+
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 share an L2) and, within an XCD, start in the
+    // order of blockIdx.  The strip plan (scale_2x_strip_plan) leans on both, for speed only: XCD x works on one
+    // contiguous band of rows (a strip re-reads the last five input rows of the strip above it: L2 hits), and the
+    // strips that start first are the longest.
+    const int groupsPerRow = (colGroups + 3) >> 2;
+    const int j = (int)(blockIdx.x >> 3);
+    const int sj = j / groupsPerRow;                       // strip within the XCD's band, in dispatch order
+    const int cg = (j - sj * groupsPerRow) * 4 + wv;
+    int rBegin, n;                                         // emitting steps r = rBegin .. rBegin+n-1 (out of 2 .. inH+2)
+    scale_2x_strip_of(inH, (int)(blockIdx.x & 7u), sj, stripsPerXcd, rBegin, n);   // scalar arithmetic, no table to wait for
+    if (n <= 0 || cg >= colGroups) return;                 // wave-uniform; there is no workgroup barrier below
+#ifdef LFG_DIAG_STAMPS
+#define LFG_STAMP_ARGS , stamps, tStart, clk0, (int)(blockIdx.x & 7u) * stripsPerXcd + sj, wv
+#else
+#define LFG_STAMP_ARGS
+#endif
+    // Three straight-line bodies, one per strip length of the plan; a strip cut short at the end of its band runs the
+    // next longer body with the surplus steps' stores switched off.
+    if (n > LFG_SCALE_L1)
+        scale_2x_strip<LFG_SCALE_L0>(in, inW, inH, inPitch, out, outW, outH, outPitch, classX, paletteX, weightY, rBegin, n, cg, lane, slab[wv] LFG_STAMP_ARGS);
+    else if (n > LFG_SCALE_L2)
+        scale_2x_strip<LFG_SCALE_L1>(in, inW, inH, inPitch, out, outW, outH, outPitch, classX, paletteX, weightY, rBegin, n, cg, lane, slab[wv] LFG_STAMP_ARGS);
+    else
+        scale_2x_strip<LFG_SCALE_L2>(in, inW, inH, inPitch, out, outW, outH, outPitch, classX, paletteX, weightY, rBegin, n, cg, lane, slab[wv] LFG_STAMP_ARGS);
+#undef LFG_STAMP_ARGS
+}
 
 #ifdef LFG_DIAG_STAMPS
-// Diagnostic build only (-DLFG_DIAG_STAMPS, never the shipped library): a device buffer for the
-// per-wave time stamps, dumped to $LFG_STAMPS_FILE by lfg_diag_dump_stamps().
+// Diagnostic build only (-DLFG_DIAG_STAMPS, never the shipped library): a device buffer for the per-wave time
+// stamps of the LAST launch, dumped to a file by lfg_diag_dump_stamps().
 static unsigned long long *g_stamps = nullptr;
-static size_t g_stampWaves = 0;
-static unsigned long long *diag_stamp_buffer(size_t waves) {
-    if (!g_stamps) { (void)hipMalloc((void **)&g_stamps, waves * 4 * sizeof(unsigned long long)); g_stampWaves = waves; }
+static size_t g_stampWords = 0, g_stampWaves = 0;
+static unsigned long long *diag_stamp_buffer(size_t waves, size_t perWave) {
+    if (g_stampWords < waves * perWave) {
+        if (g_stamps) (void)hipFree(g_stamps);
+        (void)hipMalloc((void **)&g_stamps, waves * perWave * sizeof(unsigned long long));
+        g_stampWords = waves * perWave;
+    }
+    (void)hipMemset(g_stamps, 0, waves * perWave * sizeof(unsigned long long));
+    g_stampWaves = waves;
     return g_stamps;
 }
 extern "C" __attribute__((visibility("default"))) int lfg_diag_dump_stamps(const char *path) {
     if (!g_stamps) return -1;
-    std::vector<unsigned long long> h(g_stampWaves * 4);
+    constexpr int per = LFG_SCALE_STEPS + 4;
+    std::vector<unsigned long long> h(g_stampWaves * per);
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(h.data(), g_stamps, h.size() * 8, hipMemcpyDeviceToHost);
     FILE *f = fopen(path, "w");
     if (!f) return -2;
-    for (size_t i = 0; i < g_stampWaves; ++i) fprintf(f, "%zu %llu %llu %llu\n", i, h[4 * i], h[4 * i + 1], h[4 * i + 2]);
+    for (size_t i = 0; i < g_stampWaves; ++i) {
+        if (!h[per * i]) continue;                        // wave exited before stamping (surplus workgroup)
+        fprintf(f, "%zu", i);
+        for (int j = 0; j < per; ++j) fprintf(f, " %llu", h[per * i + j]);
+        fprintf(f, "\n");
+    }
     fclose(f);
     return 0;
 }
 #endif
 
 bool scale_2x_supported(const lfg_frame &in, const lfg_frame &out) {
-    return (int)in.height + 1 >= kScaleSteps && in.width % 2u == 0 && out.pitch % 16u == 0 &&
-           (uintptr_t)out.data % 16u == 0 && (uint64_t)in.height * in.pitch < 0x7fffffffull &&
-           (uint64_t)out.height * out.pitch < 0x7fffffffull;
+    return in.width % 2u == 0 && out.pitch % 16u == 0 &&
+           (uintptr_t)out.data % 16u == 0 && in.pitch % 4u == 0 && (uintptr_t)in.data % 4u == 0 &&
+           (uint64_t)in.height * in.pitch < 0x7fffffffull && (uint64_t)out.height * out.pitch < 0x7fffffffull;
+}
+
+int scale_2x_strips_per_xcd(int inH) {
+    const int total = inH + 1, sum = LFG_SCALE_L0 + LFG_SCALE_L1 + LFG_SCALE_L2;
+    int perXcd = 0;
+    for (int x = 0; x < 8; ++x) {
+        const int band = (total * (x + 1)) / 8 - (total * x) / 8;
+        perXcd = std::max(perXcd, 3 * ((band + sum - 1) / sum));
+    }
+    return perXcd;
+}
+
+void scale_2x_strip_host(int inH, int xcd, int index, int &first, int &steps) {
+    scale_2x_strip_of(inH, xcd, index, scale_2x_strips_per_xcd(inH), first, steps);
 }
 
 hipError_t launch_scale_2x(hipStream_t s, const lfg_frame &in, const lfg_frame &out,
                            const AxisTable &tx, const AxisTable &ty) {
-    const int colGroups = ((int)in.width + kStripCols - 1) / kStripCols;
-    const int totalSteps = (int)in.height + 1;            // steps r = 2 .. inH + 2
-    const int strips = (totalSteps + kScaleSteps - 1) / kScaleSteps;
-    const int waves = colGroups * strips;
-    dim3 grid((waves + 3) / 4);
-    hipLaunchKernelGGL(scale_2x_kernel<kScaleSteps>, grid, dim3(256), 0, s,
+    const int colGroups = ((int)in.width + kOwnedCols - 1) / kOwnedCols;
+    const int groupsPerRow = (colGroups + 3) / 4;         // workgroups of four waves (four adjacent column groups)
+    dim3 grid(8 * ty.strips_per_xcd * groupsPerRow);
+    hipLaunchKernelGGL(scale_2x_kernel, grid, dim3(256), 0, s,
                        (const uint8_t *)in.data, (int)in.width, (int)in.height, (int)in.pitch,
                        (uint8_t *)out.data, (int)out.width, (int)out.height, (int)out.pitch,
-                       tx.d_weight, ty.d_weight, colGroups, strips
+                       tx.d_class, tx.d_palette, ty.d_weight, colGroups, ty.strips_per_xcd
 #ifdef LFG_DIAG_STAMPS
-                       , diag_stamp_buffer((size_t)waves)
+                       , diag_stamp_buffer((size_t)grid.x * 4, LFG_SCALE_STEPS + 4)
 #endif
                        );
     return hipGetLastError();

@@ -92,6 +92,18 @@ def test_scale_constant_colour(ctx):
         assert (run_scale(ctx, f, ow, oh) == f[0, 0]).all()      # S-KAT1, both kernels
 
 
+def test_format_load_uscaled_exact(ctx):
+    """The 2x kernel takes its texels through buffer_load_format_xyzw with an 8_8_8_8 USCALED descriptor: the texture
+    address unit converts byte k to (float)k.  A CONSTANT frame must come back as the same constant (the taps' weights
+    sum to 1 within a few ulp; S-KAT1), which only holds for all 256 byte values, in every channel position, if that
+    conversion is exact."""
+    src = np.empty((16, 256, 4), np.uint8)
+    for k in range(256):
+        src[:] = (k, 255 - k, k ^ 0x55, (37 * k) & 0xFF)
+        got = run_scale(ctx, src, 512, 32)
+        assert (got == src[0, 0]).all(), f"byte value {k}"
+
+
 def test_scale_identity_exact(ctx):
     f = rand_frame(96, 50)
     assert (run_scale(ctx, f, 96, 50) == f).all()                # S-KAT2

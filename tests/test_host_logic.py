@@ -82,3 +82,31 @@ def test_single_rank_broadcaster_is_a_pass_through():
         assert b.acquire(k) is slot
     b.drain()
     assert calls == [(0, 0), (1, 0), (2, 0)]
+
+
+@pytest.mark.parametrize("in_h", [1, 2, 5, 16, 17, 36, 135, 540, 1080, 1081, 2160, 4320, 32768])
+def test_scale_2x_strip_plan_covers_every_step_once(in_h):
+    """csrc/scale.hip: scale_2x_strip_of (read through lfg_diag_scale_2x_strip; host arithmetic, no GPU): the
+    in_h + 1 row steps 2 .. in_h + 2 of the 2x kernel fall into exactly one strip each, XCD bands are contiguous and in
+    order, strips inside a band are contiguous, never longer than the kernel's unrolled length and never grow with
+    the dispatch index (longest first)."""
+    import ctypes
+    from linux_fg_amd import capi
+    lib = capi.load()
+    per, first, steps = ctypes.c_uint32(), ctypes.c_int32(), ctypes.c_int32()
+    assert lib.lfg_diag_scale_2x_strip(in_h, 0, 0, ctypes.byref(per), ctypes.byref(first), ctypes.byref(steps)) == 0
+    assert per.value % 3 == 0 and per.value >= 3
+    nxt, longest = 2, 8                                             # (the kernel is unrolled to at most 8 steps)
+    for x in range(8):
+        last_len = None
+        for i in range(per.value):
+            assert lib.lfg_diag_scale_2x_strip(in_h, x, i, None, ctypes.byref(first), ctypes.byref(steps)) == 0
+            if steps.value == 0:
+                continue
+            assert first.value == nxt and 0 < steps.value <= longest
+            assert last_len is None or steps.value <= last_len
+            last_len = steps.value
+            nxt += steps.value
+    assert nxt == in_h + 3                                          # one past the last step, in_h + 2
+    assert lib.lfg_diag_scale_2x_strip(in_h, 8, 0, None, None, None) != 0
+    assert lib.lfg_diag_scale_2x_strip(in_h, 0, per.value, None, None, None) != 0

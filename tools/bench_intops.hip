@@ -56,6 +56,23 @@ CHAIN_KERNEL(k_dot_salu, "v_dot4_u32_u8 %0, %1, %2, %0\n s_add_u32 s40, s40, 1")
 CHAIN_KERNEL(k_add_nop, "v_add_f32 %0, %0, %1\n s_nop 0")
 CHAIN_KERNEL(k_add_branch, "v_add_f32 %0, %0, %1\n s_cbranch_execz 1f\n 1:")
 CHAIN_KERNEL(k_cmp_saveexec, "v_cmp_le_f32 vcc, %0, %1\n s_and_saveexec_b64 s[42:43], vcc\n s_cbranch_execz 2f\n 2: s_or_b64 exec, exec, s[42:43]")
+// round 2: candidates for the scale kernel's filter arithmetic and packing
+CHAIN_KERNEL(k_dot2_f32_f16, "v_dot2_f32_f16 %0, %1, %2, %0")
+CHAIN_KERNEL(k_dot2_i32_i16, "v_dot2_i32_i16 %0, %1, %2, %0")
+CHAIN_KERNEL(k_dot4_i32_i8, "v_dot4_i32_i8 %0, %1, %2, %0")
+CHAIN_KERNEL(k_dot2c_f32_f16, "v_dot2c_f32_f16 %0, %1, %2")
+CHAIN_KERNEL(k_pk_fma_f16, "v_pk_fma_f16 %0, %1, %2, %0")
+CHAIN_KERNEL(k_pk_mul_f16, "v_pk_mul_f16 %0, %0, %1")
+CHAIN_KERNEL(k_pk_mad_i16, "v_pk_mad_i16 %0, %1, %2, %0")
+CHAIN_KERNEL(k_fmac_f32, "v_fmac_f32 %0, %1, %2")
+CHAIN_KERNEL(k_cvt_pk_u8, "v_cvt_pk_u8_f32 %0, %1, 1, %0")
+CHAIN_KERNEL(k_perm, "v_perm_b32 %0, %0, %1, %2")
+CHAIN_KERNEL(k_med3, "v_med3_f32 %0, %0, %1, %2")
+CHAIN_KERNEL(k_cvt_ub1, "v_cvt_f32_ubyte1 %0, %0")
+CHAIN_KERNEL(k_cvt_pkrtz, "v_cvt_pkrtz_f16_f32 %0, %0, %1")
+CHAIN_KERNEL(k_fma_mix, "v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,1,0]")
+CHAIN_KERNEL(k_mad_u32_u16, "v_mad_u32_u16 %0, %1, %2, %0")
+CHAIN_KERNEL(k_fma_dpp, "v_fmac_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
 CHAIN_KERNEL(k_dot4_add, "v_dot4_u32_u8 %0, %1, %2, %0\n v_add_u32 %0, %0, %1")
 
 template <typename K>
@@ -90,6 +107,9 @@ int main() {
         RUN(k_mul_f32, 1) RUN(k_fma_f32, 1) RUN(k_sub_f32, 1) RUN(k_sub_u32, 1) RUN(k_lshlrev, 1) RUN(k_and, 1) RUN(k_max_f32, 1)
         RUN(k_mov, 1) RUN(k_add3, 1) RUN(k_cvt_i32, 1) RUN(k_cvt_ub0, 1) RUN(k_cmp_vcc, 1) RUN(k_cmp_sgpr, 1) RUN(k_cnd_sgpr, 1)
         RUN(k_cmp_cnd, 2) RUN(k_min3, 1)
+        RUN(k_dot2_f32_f16, 1) RUN(k_dot2_i32_i16, 1) RUN(k_dot4_i32_i8, 1) RUN(k_dot2c_f32_f16, 1) RUN(k_pk_fma_f16, 1) RUN(k_pk_mul_f16, 1)
+        RUN(k_pk_mad_i16, 1) RUN(k_fmac_f32, 1) RUN(k_cvt_pk_u8, 1) RUN(k_perm, 1) RUN(k_med3, 1) RUN(k_cvt_ub1, 1) RUN(k_cvt_pkrtz, 1)
+        RUN(k_fma_mix, 1) RUN(k_mad_u32_u16, 1) RUN(k_fma_dpp, 1)
         RUN(k_add_salu, 1) RUN(k_add_2salu, 1) RUN(k_dot_salu, 1) RUN(k_add_nop, 1) RUN(k_add_branch, 1) RUN(k_cmp_saveexec, 1)
     }
     return 0;

@@ -1,0 +1,13 @@
+#!/bin/bash
+# build_variants/lib_NAME.so = the library with scale.hip recompiled with extra flags:  tools/build_scale_variant.sh NAME -DLFG_SCALE_STEPS=6 ...
+# Run with LFG_LIB=build_variants/lib_NAME.so python bench.py --workload scale
+set -e
+R=$(cd "$(dirname "$0")/.." && pwd)
+name=$1; shift
+C=$R/linux-fg_amd/csrc
+mkdir -p $R/build_variants
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fvisibility=hidden -I$R/include -Wall -Wno-unused-function"
+/opt/rocm/bin/hipcc $FLAGS "$@" -c $C/scale.hip -o /tmp/scale_$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/build_variants/lib_$name.so $C/lfg_capi.cpp.o /tmp/scale_$name.o $C/interpolate.hip.o $C/motion.hip.o
+python3 $C/check_store_hazard.py $R/build_variants/lib_$name.so
+echo built build_variants/lib_$name.so
