@@ -24,6 +24,12 @@ the one the path really has: the batch's shared previous frame is broadcast from
 every rank upscales itself (one more 17 us scale per step than at N = 1; 33 MB of upscaled frame per
 0.8 ms step would cost more on xGMI than that).  Weak scaling.
 
+Besides the headline line's `value`, rank 0 at N = 1 measures in the same run (short, after the timed region): the
+scale-only (BASELINE config 2) and scale + interpolate rates -- the two configurations SURVEY.md 8(d) says HBM is
+the right bound for -- and `content_sweep`, the pipeline on every other synthetic content, because the motion
+stage's run time depends on the content by more than an order of magnitude (results never do) and the default
+content, a pure pan, is its best case.
+
 The CPU baseline is the oracle (oracle/lfg_oracle.c, a restatement of the reference shaders -- NOT
 lavapipe, which this image lacks) timed on a bounded sample on the host cores, rank 0, N = 1 only.
 """
@@ -47,6 +53,9 @@ FP32_VALU_PEAK_TFLOPS = 157.3  # ibid. :41 (counts an FMA as 2; an add-only stre
 SIZES = {"540p": (960, 540), "1080p": (1920, 1080), "4k": (3840, 2160), "8k": (7680, 4320)}
 
 
+CONTENTS = ["translated", "occluded", "objects", "noisy", "uncorrelated", "static", "fade"]
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -55,12 +64,53 @@ def parse_args():
     ap.add_argument("--workload", choices=["pipeline", "scale", "pipeline_input_res"], default="pipeline")
     ap.add_argument("--input", choices=list(SIZES), default="1080p", help="input size; output is 2x")
     ap.add_argument("--factors", default="0.5", help="comma-separated interpolation factors per pair")
-    ap.add_argument("--content", choices=["translated", "occluded", "objects", "noisy", "uncorrelated", "static", "fade"], default="translated",
-                    help="translated (default: curr = prev shifted by (3,-2)), occluded (the same with patches of fresh noise), objects (the same with patches that move on their own), noisy (the same with +-2 levels of noise everywhere), uncorrelated (independent noise frames), "
+    ap.add_argument("--content", choices=CONTENTS, default="translated",
+                    help="translated (default, SURVEY.md 8(d): curr = prev shifted by (3,-2)), occluded (the same with patches of fresh noise), objects (the same with patches that move on their own), noisy (the same with +-2 levels of noise everywhere), uncorrelated (independent noise frames), "
                          "static (curr = prev), fade (flat grey frames one level apart: every candidate ties at a "
-                         "non-zero cost, the prefilter's worst case -- all tiles fall back to the literal kernel)")
+                         "non-zero cost, the prefilter's worst case -- the rim tiles fall back to the literal kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip scale_only / scale_interpolate / content_sweep (profiling runs)")
     return ap.parse_args()
+
+
+def make_content(name: str, w_in: int, h_in: int, rank: int, content_rank: int):
+    """(prev_in, curr_in) of one synthetic content at input resolution.  The previous frame is shared by all ranks (seed
+    of stream 0) except for `fade`; a rank's current frame is derived from it."""
+    from linux_fg_amd import synth
+    prev_in = synth.make_prev(w_in, h_in, synth.BASE_SEED)
+    rank_shift = rank_motion(content_rank)
+    if name == "translated":
+        curr_in = synth.translate(prev_in, rank_shift, synth.BASE_SEED + rank)
+    elif name == "uncorrelated":
+        curr_in = synth.noise_bytes(w_in, h_in, (synth.BASE_SEED + 7919 * (rank + 1)) & 0xFFFFFFFF)
+    elif name == "occluded":                       # the translated pair with 24 patches of fresh noise (2 % of the frame)
+        curr_in = synth.translate(prev_in, rank_shift, synth.BASE_SEED + rank)
+        fresh = synth.noise_bytes(w_in, h_in, (synth.BASE_SEED + 104729 * (rank + 1)) & 0xFFFFFFFF)
+        rng = np.random.default_rng(20240 + rank)
+        for _ in range(24):
+            pw, ph = int(rng.integers(w_in // 60, w_in // 12)), int(rng.integers(h_in // 60, h_in // 12))
+            x0, y0 = int(rng.integers(40, w_in - 40 - pw)), int(rng.integers(40, h_in - 40 - ph))
+            curr_in[y0:y0 + ph, x0:x0 + pw] = fresh[y0:y0 + ph, x0:x0 + pw]
+    elif name == "objects":                        # the translated pair with 24 patches that move on their own
+        curr_in = synth.translate(prev_in, rank_shift, synth.BASE_SEED + rank)
+        rng = np.random.default_rng(30240 + rank)
+        for _ in range(24):
+            pw, ph = int(rng.integers(w_in // 60, w_in // 12)), int(rng.integers(h_in // 60, h_in // 12))
+            x0, y0 = int(rng.integers(40, w_in - 40 - pw)), int(rng.integers(40, h_in - 40 - ph))
+            dx, dy = int(rng.integers(-7, 8)), int(rng.integers(-7, 8))
+            curr_in[y0:y0 + ph, x0:x0 + pw] = prev_in[y0 - dy:y0 - dy + ph, x0 - dx:x0 - dx + pw]
+    elif name == "noisy":                          # the translated pair plus sensor-like noise: +-2 levels per channel
+        curr_in = synth.translate(prev_in, rank_shift, synth.BASE_SEED + rank)
+        n = synth.noise_bytes(w_in, h_in, (synth.BASE_SEED + 15485863 * (rank + 1)) & 0xFFFFFFFF) % 5
+        curr_in = np.clip(curr_in.astype(np.int16) + n.astype(np.int16) - 2, 0, 255).astype(np.uint8)
+    elif name == "static":
+        curr_in = prev_in.copy()
+    elif name == "fade":
+        prev_in = np.full((h_in, w_in, 4), 100, np.uint8)
+        curr_in = np.full((h_in, w_in, 4), 101, np.uint8)
+    else:
+        raise ValueError(name)
+    return prev_in, curr_in
 
 
 def algorithmic_bytes(stage: str, w_in: int, h_in: int, w: int, h: int) -> int:
@@ -75,68 +125,75 @@ def algorithmic_bytes(stage: str, w_in: int, h_in: int, w: int, h: int) -> int:
     raise ValueError(stage)
 
 
-PREFILTER_LAUNCHES_PER_CALL = 2          # motion_prefilter_kernel: the plan's units, then the queue of segments handed over
+def library_sha16():
+    """First 16 hex digits of the sha256 of the HIP library this process loaded: profiles record it, and a profile
+    taken with another build is not quoted."""
+    import hashlib
+    from linux_fg_amd import capi
+    with open(capi.LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
-def pmc_traffic(kernel_prefixes):
-    """HBM bytes per launch of the kernels whose names start with one of `kernel_prefixes`, summed, from the
-    newest committed two-pass PMC summary (profiles/rNN_hbm_traffic_pmc.txt: FETCH_SIZE and WRITE_SIZE
-    collected in separate rocprofv3 passes, values in KB).  bench.py cannot run the profiler on itself;
-    None if no summary exists."""
+def read_profile(pattern):
+    """The newest committed counter table profiles/<pattern> (written by tools/pmc_per_step.py over
+    `tools/run_stage.py pipeline N` under rocprofv3 --kernel-trace --pmc ...; bench.py cannot run the profiler on
+    itself).  Returns (table, source, None) or (None, source, reason): a table taken with another build of the library
+    (`# lib_sha16`) is not quoted.  table = {"kernels": {name: {...}}, "per_step": {COUNTER: value}}."""
     import glob
-    import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.txt")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
     if not files:
-        return None, None
-    if isinstance(kernel_prefixes, str):
-        kernel_prefixes = [kernel_prefixes]
-    vals, cur = {}, None
+        return None, None, f"no profiles/{pattern}"
+    src = os.path.relpath(files[-1], ROOT)
+    sha, table = None, {"kernels": {}, "per_step": {}}
     for line in open(files[-1]):
-        if ": launches" in line and not line.startswith(" "):        # any kernel header line starts a new block
-            cur = line.split(": launches")[0].replace("void ", "").split("<")[0].split("(")[0].strip()
-        m = re.match(r"^\s+(FETCH_SIZE|WRITE_SIZE)\s+([0-9.e+]+)", line)
-        if m and cur and any(cur.startswith(k) for k in kernel_prefixes):
-            # (the summary averages over launches; lfg_motion launches the prefilter twice: the tiles, then the segments
-            #  handed over -- an almost empty launch on the benchmark frames -- so a call is two launches)
-            per_call = PREFILTER_LAUNCHES_PER_CALL if cur.startswith("lfg::motion_prefilter") else 1
-            vals[(cur, m.group(1))] = float(m.group(2)) * 1024.0 * per_call       # the last block of a kernel wins
-    have = {k for k, _ in vals}
-    if have and all((k, c) in vals for k in have for c in ("FETCH_SIZE", "WRITE_SIZE")):
-        return int(sum(vals.values())), os.path.relpath(files[-1], ROOT)
-    return None, None
+        t = line.split()
+        if line.startswith("# lib_sha16"):
+            sha = t[2]
+        elif t and t[0] == "kernel":
+            table["kernels"][t[1]] = {t[i]: float(t[i + 1]) for i in range(2, len(t) - 1, 2)}
+        elif t and t[0] == "per_step":
+            table["per_step"] = {t[i]: float(t[i + 1]) for i in range(1, len(t) - 1, 2)}
+    if sha != library_sha16():
+        return None, src, f"{src} was collected with library {sha}, this run loaded {library_sha16()}: not quoted"
+    return table, src, None
 
 
-def pmc_executed(kernel_prefix):
-    """What the dominant kernel actually executed per launch, from the newest committed SQ counter summary
-    (profiles/rNN_motion_sq_counters.txt, one rocprofv3 --pmc pass over tools/run_stage.py motion): wave-level
-    VALU / LDS / SALU instruction counts and the kernel's mean duration in that pass.  None if absent."""
-    import glob
-    import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_motion_sq_counters.txt")))
-    if not files:
+def pmc_traffic(prefix="lfg::"):
+    """HBM-side bytes per pipeline step of the kernels whose names start with `prefix`: FETCH_SIZE + WRITE_SIZE (KB per
+    launch, two separate rocprofv3 passes) x launches per step.  (bytes, source) or (None, reason)."""
+    table, src, why = read_profile("r*_hbm_traffic_pmc.txt")
+    if table is None:
+        return None, why
+    total = 0.0
+    for k, v in table["kernels"].items():
+        if k.startswith(prefix):
+            if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
+                return None, f"{src}: {k} lacks one of the two passes"
+            total += (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 * v["launches_per_step"]
+    return int(total), src
+
+
+def pmc_executed(prefix="lfg::motion_"):
+    """What the kernels whose names start with `prefix` executed per pipeline step, from the newest committed SQ
+    counter table: wave-level VALU / LDS / SALU instruction counts, and the share of the chip's VALU issue slots they
+    filled while they ran (4 cycles per VALU wave-instruction, 1024 SIMDs, 2.4 GHz peak clock).  None if unusable."""
+    table, src, why = read_profile("r*_sq_counters.txt")
+    if table is None:
         return None
-    out, cur = {}, None
-    for line in open(files[-1]):
-        if ": launches" in line and not line.startswith(" "):
-            cur = line.split(": launches")[0].replace("void ", "").split("<")[0].split("(")[0].strip()
-            m = re.search(r"mean ([0-9.]+) us", line)
-            if cur.startswith(kernel_prefix) and m:
-                out = {"mean_us": float(m.group(1))}
-        m = re.match(r"^\s+(SQ_\w+)\s+([0-9.e+]+)", line)
-        if m and cur and cur.startswith(kernel_prefix):
-            out[m.group(1)] = float(m.group(2))
-    if not {"mean_us", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU"} <= set(out):
+    valu = lds = salu = us = 0.0
+    for k, v in table["kernels"].items():
+        if k.startswith(prefix) and "SQ_INSTS_VALU" in v:
+            n = v["launches_per_step"]
+            valu += v["SQ_INSTS_VALU"] * n; lds += v.get("SQ_INSTS_LDS", 0.0) * n; salu += v.get("SQ_INSTS_SALU", 0.0) * n
+            us += v["mean_us"] * n
+    if us <= 0:
         return None
-    simds, clock_hz = 1024, 2.4e9                       # 256 CUs x 4 SIMDs, peak engine clock
-    n = PREFILTER_LAUNCHES_PER_CALL if kernel_prefix.startswith("lfg::motion_prefilter") else 1   # the summary averages over launches
-    slots = out["mean_us"] * 1e-6 * clock_hz * simds
-    return {"source": os.path.relpath(files[-1], ROOT), "kernel_us_per_call_in_that_pass": round(out["mean_us"] * n, 2),
-            "launches_per_call": n,
-            "valu_wave_instructions": out["SQ_INSTS_VALU"] * n, "lds_wave_instructions": out["SQ_INSTS_LDS"] * n,
-            "salu_wave_instructions": out["SQ_INSTS_SALU"] * n,
-            "valu_issue_utilisation": round(out["SQ_INSTS_VALU"] * 4.0 / slots, 3),
-            "how": "VALU wave-instructions x 4 cycles / (duration x 2.4 GHz x 1024 SIMDs): the share of the VALU issue "
-                   "slots the kernel filled -- the utilisation figure that `frac` (an algorithmic rate) is not"}
+    slots = us * 1e-6 * 2.4e9 * 1024
+    return {"source": src, "kernels": prefix + "*", "kernel_us_per_step_in_that_pass": round(us, 2),
+            "valu_wave_instructions": valu, "lds_wave_instructions": lds, "salu_wave_instructions": salu,
+            "valu_issue_utilisation": round(valu * 4.0 / slots, 3),
+            "how": "VALU wave-instructions x 4 cycles / (kernel time x 2.4 GHz x 1024 SIMDs): the share of the VALU issue "
+                   "slots those kernels filled"}
 
 
 def rank_motion(rank: int):
@@ -205,30 +262,33 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    # One rank per GPU.  LFG_BENCH_BACKEND=gloo (rehearsal only) lets several ranks share one card so the
-    # N > 1 code path can be exercised on a one-GPU box; RCCL itself needs one device per rank.
-    backend = os.environ.get("LFG_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    # One rank per GPU.  torch.distributed (gloo, CPU tensors) is the CONTROL plane only: it carries the 128-byte
+    # communicator id, the barriers and the max-over-ranks of the elapsed time.  The data path's one collective --
+    # the shared previous frame -- is the C-ABI's lfg_broadcast_frame (RCCL over xGMI).  LFG_BENCH_SHARE_GPU=1
+    # (rehearsal only) lets several ranks share one card with torch carrying the frame too: RCCL itself needs one
+    # device per rank.
+    share_gpu = os.environ.get("LFG_BENCH_SHARE_GPU") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if share_gpu else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from linux_fg_amd import capi, sharding, synth
 
     w_in, h_in = SIZES[args.input]
     w, h = 2 * w_in, 2 * h_in
     factors = [float(x) for x in args.factors.split(",") if x]
-    steps = args.steps if args.steps is not None else (200 if args.workload == "scale" else 20)
-    warmup = args.warmup if args.warmup is not None else (20 if args.workload == "scale" else 3)
+    # defaults: a timed region of about a second (0.7 ms per pipeline step, 13 us per scale step at 1080p -> 4K)
+    steps = args.steps if args.steps is not None else (40000 if args.workload == "scale" else 1000)
+    warmup = args.warmup if args.warmup is not None else (500 if args.workload == "scale" else 20)
 
     ctx = capi.Context(dev_index)
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
+    if world > 1 and not share_gpu:
+        ctx.comm_init(world, rank, sharding.exchange_comm_id(dist, capi.Context.comm_unique_id, src=0))
 
     def dev_frame(host: np.ndarray):
         t = torch.from_numpy(np.ascontiguousarray(host)).to(dev)
@@ -239,53 +299,23 @@ def main():
         t = torch.empty((height, width, ch), dtype=torch.uint8, device=dev)
         return t, capi.Context.wrap(t.data_ptr(), width, height, fmt)
 
-    # Synthetic inputs, uploaded once before timing.  The previous frame is shared by all ranks
-    # (seed of stream 0); each rank's current frame is that frame translated by its own vector.
-    prev_in = synth.make_prev(w_in, h_in, synth.BASE_SEED)
-    # Every rank's own motion, inside the search range after the 2x upscale (|2 dx|, |2 dy| <= 16): (3, -2) on rank 0,
-    # then (4, -2) ... (7, -2), (3, -3) ...
+    # Synthetic inputs, uploaded once before timing.  The previous frame is shared by all ranks (seed of stream 0);
+    # each rank's current frame is that frame translated by its own vector, inside the search range after the 2x
+    # upscale (|2 dx|, |2 dy| <= 16): (3, -2) on rank 0, then (4, -2) ... (7, -2), (3, -3) ...
     content_rank = int(os.environ.get("LFG_BENCH_CONTENT_RANK", rank))       # (diagnostic: another rank's frames on this GPU)
-    rank_shift = rank_motion(content_rank)
-    if args.content == "translated":
-        curr_in = synth.translate(prev_in, rank_shift, synth.BASE_SEED + rank)
-    elif args.content == "uncorrelated":
-        curr_in = synth.noise_bytes(w_in, h_in, (synth.BASE_SEED + 7919 * (rank + 1)) & 0xFFFFFFFF)
-    elif args.content == "occluded":                       # the translated pair with 24 patches of fresh noise (2 % of the frame)
-        curr_in = synth.translate(prev_in, rank_shift, synth.BASE_SEED + rank)
-        fresh = synth.noise_bytes(w_in, h_in, (synth.BASE_SEED + 104729 * (rank + 1)) & 0xFFFFFFFF)
-        rng = np.random.default_rng(20240 + rank)
-        for _ in range(24):
-            pw, ph = int(rng.integers(w_in // 60, w_in // 12)), int(rng.integers(h_in // 60, h_in // 12))
-            x0, y0 = int(rng.integers(40, w_in - 40 - pw)), int(rng.integers(40, h_in - 40 - ph))
-            curr_in[y0:y0 + ph, x0:x0 + pw] = fresh[y0:y0 + ph, x0:x0 + pw]
-    elif args.content == "objects":                        # the translated pair with 24 patches that move on their own
-        curr_in = synth.translate(prev_in, rank_shift, synth.BASE_SEED + rank)
-        rng = np.random.default_rng(30240 + rank)
-        for _ in range(24):
-            pw, ph = int(rng.integers(w_in // 60, w_in // 12)), int(rng.integers(h_in // 60, h_in // 12))
-            x0, y0 = int(rng.integers(40, w_in - 40 - pw)), int(rng.integers(40, h_in - 40 - ph))
-            dx, dy = int(rng.integers(-7, 8)), int(rng.integers(-7, 8))
-            curr_in[y0:y0 + ph, x0:x0 + pw] = prev_in[y0 - dy:y0 - dy + ph, x0 - dx:x0 - dx + pw]
-    elif args.content == "noisy":                          # the translated pair plus sensor-like noise: +-2 levels per channel
-        curr_in = synth.translate(prev_in, rank_shift, synth.BASE_SEED + rank)
-        n = synth.noise_bytes(w_in, h_in, (synth.BASE_SEED + 15485863 * (rank + 1)) & 0xFFFFFFFF) % 5
-        curr_in = np.clip(curr_in.astype(np.int16) + n.astype(np.int16) - 2, 0, 255).astype(np.uint8)
-    elif args.content == "static":
-        curr_in = prev_in.copy()
-    else:                                                   # fade
-        prev_in = np.full((h_in, w_in, 4), 100, np.uint8)
-        curr_in = np.full((h_in, w_in, 4), 101, np.uint8)
+    prev_in, curr_in = make_content(args.content, w_in, h_in, rank, content_rank)
     t_prev_in, f_prev_in = dev_frame(prev_in)
     t_curr_in, f_curr_in = dev_frame(curr_in)
     t_curr4, f_curr4 = empty_frame(w, h)
-    t_out, f_out = empty_frame(w, h)
+    outs = [empty_frame(w, h) for _ in factors]
+    f_outs = [f for _, f in outs]
     t_mv, f_mv = empty_frame(w, h, capi.FORMAT_MV_S8X2)
     if args.workload == "pipeline_input_res":
         t_mv_in, f_mv_in = empty_frame(w_in, h_in, capi.FORMAT_MV_S8X2)
         t_mid_in, f_mid_in = empty_frame(w_in, h_in)
     # The previous frame.  One GPU: upscaled once, before the timed region (in a stream it is the last step's current
     # frame).  Several GPUs: the batch shares its previous frame, which travels as the 8.3 MB INPUT frame -- one
-    # broadcast per step, double-buffered -- and every rank upscales it (17 us) rather than 33 MB of upscaled frame
+    # broadcast per step, double-buffered -- and every rank upscales it (13 us) rather than 33 MB of upscaled frame
     # crossing xGMI under a 0.8 ms step.  LFG_BENCH_SHARE_INPUT=1 runs that data flow on one GPU (no collective).
     share_input = world > 1 or os.environ.get("LFG_BENCH_SHARE_INPUT") == "1"
     t_prev4, f_prev4 = empty_frame(w, h)
@@ -293,34 +323,49 @@ def main():
     prev_slots = [dev_frame(prev_in) for _ in range(2)] if share_input else [(t_prev4, f_prev4)]
     torch.cuda.synchronize(dev)
 
-    shared_prev = sharding.SharedFrameBroadcaster([t for t, _ in prev_slots], src=0, dist=dist if world > 1 else None,
-                                                  world_size=world)
+    transport = None
+    if world > 1:
+        transport = (sharding.TorchTransport(dist, [t for t, _ in prev_slots], src=0) if share_gpu
+                     else sharding.CapiTransport(ctx, [f for _, f in prev_slots], src=0))
+    shared_prev = sharding.SharedFrameBroadcaster(len(prev_slots), transport, world_size=world, is_source=rank == 0)
+
+    def interpolate_all(fp, fc, fm):
+        if len(factors) == 1:
+            ctx.interpolate(fp, fc, fm, f_outs[0], factors[0])
+        else:
+            ctx.interpolate_multi(fp, fc, fm, f_outs, factors)        # one pass over prev / curr / mv, every factor
 
     def step(k):
-        # the shared previous frame of this step (waits for its RCCL broadcast, issues the next one)
-        t_shared = shared_prev.acquire(k)
-        f_shared = prev_slots[[t.data_ptr() for t, _ in prev_slots].index(t_shared.data_ptr())][1]
+        # the shared previous frame of this step (waits for its broadcast, issues the next one)
+        f_shared = prev_slots[shared_prev.acquire(k)][1]
         f_prev_step = f_shared if share_input else f_prev_in
         if share_input and args.workload == "pipeline":
             ctx.scale(f_shared, f_prev4)
         if args.workload == "pipeline_input_res":
             ctx.motion(f_prev_step, f_curr_in, f_mv_in, 8, 16.0)
             ctx.scale(f_curr_in, f_curr4)
-            for t in factors:
+            for t, fo in zip(factors, f_outs):
                 ctx.interpolate(f_prev_step, f_curr_in, f_mv_in, f_mid_in, t)
-                ctx.scale(f_mid_in, f_out)
+                ctx.scale(f_mid_in, fo)
             return
         ctx.scale(f_curr_in, f_curr4)
         if args.workload == "pipeline":
             ctx.motion(f_prev4, f_curr4, f_mv, 8, 16.0)
-            for t in factors:
-                ctx.interpolate(f_prev4, f_curr4, f_mv, f_out, t)
+            interpolate_all(f_prev4, f_curr4, f_mv)
 
     def barrier_sync():
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
+
+    def timed(fn, n):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for k in range(n):
+            fn(k)
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0
 
     shared_prev.start(0)
     for k in range(warmup):
@@ -340,11 +385,12 @@ def main():
         # kernel duration from a second, event-bracketed pass: per-launch events would dominate the
         # wall clock of a ~10 us kernel, so they stay out of the pass `value` is computed from.
         ctx.profile_enable(True)
-        for k in range(steps):
+        for k in range(min(steps, 2000)):
             step(k)
         torch.cuda.synchronize(dev)
     motion_stats = None
-    if args.workload != "scale" and os.environ.get("LFG_MOTION_MODE", "0") != "1":
+    exact_only = os.environ.get("LFG_MOTION_MODE", "0") == "1"
+    if args.workload != "scale" and not exact_only:
         motion_stats = ctx.motion_last_stats()        # after the timed region: it synchronises and copies counters
     stage_ms = {}
     for name, sid in (("scale", capi.STAGE_SCALE), ("motion", capi.STAGE_MOTION), ("interpolate", capi.STAGE_INTERPOLATE)):
@@ -354,7 +400,7 @@ def main():
     ctx.profile_enable(False)
 
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -363,64 +409,122 @@ def main():
     mw, mh = (w_in, h_in) if in_res else (w, h)        # resolution motion and interpolate run at
     value = world * steps * units_per_step / elapsed
 
+    # ---- the same run, rank 0, one GPU: the two HBM-bound configurations and the other contents
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras and args.workload == "pipeline" and args.input == "1080p":
+        n2 = 4000
+        b_scale = algorithmic_bytes("scale", w_in, h_in, w, h)
+        b_interp = algorithmic_bytes("interpolate", w_in, h_in, w, h) + 4 * w * h * (len(factors) - 1)
+        t_s = timed(lambda k: ctx.scale(f_curr_in, f_curr4), n2)
+        def scale_interp(k):
+            ctx.scale(f_curr_in, f_curr4)
+            interpolate_all(f_prev4, f_curr4, f_mv)
+        t_si = timed(scale_interp, n2)
+        extras["scale_only"] = {"workload": "BASELINE config 2: 1080p->4K Lanczos only", "steps": n2, "frames_per_s": round(n2 / t_s, 1),
+                                "us_per_step": round(t_s / n2 * 1e6, 3), "algorithmic_bytes": b_scale,
+                                "hbm_gbs": round(b_scale * n2 / t_s / 1e9, 1), "hbm_frac": round(b_scale * n2 / t_s / 1e9 / HBM_PEAK_GBS, 4),
+                                "how": "wall clock over back-to-back launches (includes the ~1.5 us between dependent kernels); "
+                                       "rocprof's GPU-side duration of the kernel is in profiles/"}
+        extras["scale_interpolate"] = {"workload": "scale + interpolate (motion vectors given)", "steps": n2, "frames_per_s": round(n2 / t_si, 1),
+                                       "us_per_step": round(t_si / n2 * 1e6, 3), "algorithmic_bytes": b_scale + b_interp,
+                                       "hbm_gbs": round((b_scale + b_interp) * n2 / t_si / 1e9, 1),
+                                       "hbm_frac": round((b_scale + b_interp) * n2 / t_si / 1e9 / HBM_PEAK_GBS, 4)}
+        sweep = {args.content: {"frames_per_s": round(value, 1), "motion_ms": round(stage_ms.get("motion", 0.0), 4)}}
+        def sweep_case(label, content, mode):
+            p_in, c_in = make_content(content, w_in, h_in, 0, 0)
+            tp, fp = dev_frame(p_in)
+            tc, fc = dev_frame(c_in)
+            ctx.set_motion_mode(mode)
+            ctx.scale(fp, f_prev4)
+            def one(k):
+                ctx.scale(fc, f_curr4)
+                ctx.motion(f_prev4, f_curr4, f_mv, 8, 16.0)
+                interpolate_all(f_prev4, f_curr4, f_mv)
+            timed(one, 2)
+            ctx.profile_reset(); ctx.profile_enable(True)
+            n = 5 if mode == capi.MOTION_EXACT_ONLY else (20 if content in ("uncorrelated", "fade") else 100)
+            t = timed(one, n)
+            ms, cnt = ctx.profile_get(capi.STAGE_MOTION)
+            ctx.profile_enable(False)
+            entry = {"frames_per_s": round(n * len(factors) / t, 1), "motion_ms": round(ms / max(cnt, 1), 4), "steps": n}
+            if mode == capi.MOTION_PREFILTERED:
+                st = ctx.motion_last_stats()
+                entry["fallback_tiles"] = st[1]
+            sweep[label] = entry
+        if not exact_only:
+            for c in CONTENTS:
+                if c != args.content:
+                    sweep_case(c, c, capi.MOTION_PREFILTERED)
+            sweep_case("literal kernel only (any content)", "translated", capi.MOTION_EXACT_ONLY)
+            ctx.set_motion_mode(capi.MOTION_PREFILTERED)
+            ctx.scale(f_prev_in, f_prev4)
+        worst = min((v["frames_per_s"] for k, v in sweep.items() if not k.startswith("literal")), default=None)
+        extras["content_sweep"] = {"frames_per_s_by_content": sweep, "worst_case_frames_per_s": worst,
+                                   "note": "same kernels, same results discipline (bit-exact vectors on every content); the motion "
+                                           "stage's run time depends on how much of the frame has an exact or near match inside the "
+                                           "search range: `value` is on the SURVEY-prescribed pure pan, its best case bar `static`"}
+
     if rank == 0:
         stages = {}
         for name, avg in stage_ms.items():
             b = algorithmic_bytes(name, w_in, h_in, w if name == "scale" else mw, h if name == "scale" else mh)
+            if name == "interpolate" and len(factors) > 1 and not in_res:
+                b += 4 * mw * mh * (len(factors) - 1)               # one pass: inputs once, one frame per factor
             gbs = b / (avg * 1e-3) / 1e9
             stages[name] = {"avg_ms": round(avg, 5), "algorithmic_bytes": b, "hbm_gbs": round(gbs, 1),
                             "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
         dominant = max(stage_ms, key=stage_ms.get)
-        if dominant == "motion":
-            fl = motion_flops(mw, mh)
-            tf = fl / (stage_ms["motion"] * 1e-3) / 1e12
-            exact_only = os.environ.get("LFG_MOTION_MODE", "0") == "1"
-            roofline = {"kernel": ("motion_tiled_8_16_kernel" if exact_only else
-                                   "motion_prefilter_kernel (+ motion_hint/order_kernel, motion_resolve_kernel, motion_tiled_8_16_kernel on flagged tiles)"),
-                        "bound": "valu", "achieved": round(tf, 2),
-                        "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_VALU_PEAK_TFLOPS, 4),
-                        "traffic": None,
-                        "algorithmic_flops": fl,
-                        "note": ("motion.comp is fp32-VALU bound, not HBM bound (SURVEY.md F7).  achieved = ALGORITHMIC flops of "
-                                 "the shader (W*H*1089*(64 adds + 12 per distance)) / duration of the whole lfg_motion call (HIP "
-                                 "events around its launches).  The default path does not execute all of them: an exact bracket "
-                                 "on the cost rules out all but ~1 candidate per pixel before the literal 64-add chain is "
-                                 "needed, and a partial-distortion test drops most candidates of a 16 x 56 pixel segment after "
-                                 "24 of their 1449 distances (DESIGN.md, motion) -- which is how frac can exceed 1: it is the "
-                                 "rate at which the shader's work is disposed of, not a utilisation (see `executed`).  "
-                                 "LFG_MOTION_MODE=1 runs the literal kernel alone.  The 157.3 TFLOP/s peak counts an FMA as 2; "
-                                 "an add-only stream tops out at 78.65.")}
-            if not exact_only and args.input == "1080p" and not in_res:
-                ex = pmc_executed("lfg::motion_prefilter")
-                if ex is not None:
-                    roofline["executed"] = ex
-            if motion_stats is not None:
-                roofline["motion_mode"] = "prefiltered"
-                roofline["fallback_tiles"] = {"of": motion_stats[0], "exact_kernel": motion_stats[1]}
-                roofline["candidates_recorded_per_pixel"] = round(motion_stats[2], 2)
-            else:
-                roofline["motion_mode"] = "exact kernel only"
-        else:
-            s = stages[dominant]
-            roofline = {"kernel": {"scale": "scale_2x_kernel", "interpolate": "interpolate_kernel"}[dominant],
-                        "bound": "hbm", "achieved": s["hbm_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": s["hbm_frac"], "traffic": None}
-        size_name = {"540p": "540p->1080p", "1080p": "1080p->4K", "4k": "4K->8K", "8k": "8K->16K"}[args.input]
-        if args.input == "1080p" and not in_res:
-            t, src = pmc_traffic(["lfg::motion_tiled", "lfg::motion_prefilter", "lfg::motion_resolve", "lfg::motion_hint", "lfg::motion_order"] if dominant == "motion"
-                                 else {"scale_2x_kernel": "lfg::scale_2x", "interpolate_kernel": "lfg::interpolate"}[roofline["kernel"]])
-            if t is not None:
-                roofline["traffic"] = t
-                roofline["traffic_source"] = (f"{src}: FETCH_SIZE + WRITE_SIZE from two separate rocprofv3 --pmc passes, bytes per "
-                                              "launch; FETCH_SIZE raw (uncalibrated for 4-byte-per-lane loads)")
+
         def launches(n):        # per step
             if n == "interpolate":
-                return len(factors)
+                return len(factors) if in_res else 1
             if n == "scale":            # curr (+ the generated frames of the input-resolution variant) (+ the shared previous frame)
                 return 1 + (len(factors) if in_res else 0) + (1 if share_input and args.workload == "pipeline" else 0)
             return 1
-        total_bytes = sum(algorithmic_bytes(n, w_in, h_in, w if n == "scale" else mw, h if n == "scale" else mh) * launches(n)
-                          for n in stage_ms)
+        total_bytes = sum(stages[n]["algorithmic_bytes"] * launches(n) for n in stage_ms)
+        path_gbs = total_bytes * steps / elapsed / 1e9
+
+        # `roofline`: the PATH against the HBM roofline -- algorithmic bytes of every stage of a step / ms_per_step.
+        # It follows from this line alone and is a fraction.  The dominant kernel's own figures sit beside it.
+        roofline = {"kernel": ("scale_2x_kernel" if args.workload == "scale" else
+                               f"whole step: scale_2x_kernel -> lfg_motion's kernels -> interpolate kernel (dominant stage: {dominant})"),
+                    "bound": "hbm", "achieved": round(path_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(path_gbs / HBM_PEAK_GBS, 5), "traffic": None,
+                    "algorithmic_bytes_per_step": total_bytes,
+                    "how": "algorithmic bytes of a step (SURVEY.md 8(d): every stage reads each input once and writes each output once) "
+                           "/ ms_per_step, against the 8 TB/s spec peak"}
+        if args.workload != "scale" and "motion" in stage_ms:
+            fl = motion_flops(mw, mh)
+            md = {"kernel": ("motion_tiled_8_16_kernel" if exact_only else "the kernels of one lfg_motion call"),
+                  "avg_ms": stages["motion"]["avg_ms"], "hbm_frac": stages["motion"]["hbm_frac"],
+                  "work_disposed_tflops": round(fl / (stage_ms["motion"] * 1e-3) / 1e12, 2), "algorithmic_flops": fl,
+                  "note": ("motion.comp is fp32-VALU bound, not HBM bound (SURVEY.md F7): 1089 candidates x 64 block positions per "
+                           "pixel.  work_disposed_tflops = the shader's algorithmic flops (W*H*1089*(64 adds + 12 per distance)) / "
+                           "the duration of the lfg_motion call: the rate at which that work is DISPOSED OF, not executed -- an exact "
+                           "bracket on the cost rules out all but ~1 candidate per pixel and a partial-distortion test drops most "
+                           "candidates of a segment after 24 of their 1449 distances (DESIGN.md, motion) -- so it may exceed the "
+                           "157.3 TFLOP/s fp32 peak and is NOT a utilisation; `executed` (when a counter profile of this very "
+                           "library is committed) is.  LFG_MOTION_MODE=1 runs the literal kernel alone.")}
+            if not exact_only and args.input == "1080p" and not in_res:
+                ex = pmc_executed("lfg::motion_")
+                if ex is not None:
+                    md["executed"] = ex
+            if motion_stats is not None:
+                md["motion_mode"] = "prefiltered"
+                md["fallback_tiles"] = {"of": motion_stats[0], "exact_kernel": motion_stats[1]}
+                md["candidates_recorded_per_pixel"] = round(motion_stats[2], 2)
+            else:
+                md["motion_mode"] = "exact kernel only"
+            roofline["dominant_stage"] = md
+        size_name = {"540p": "540p->1080p", "1080p": "1080p->4K", "4k": "4K->8K", "8k": "8K->16K"}[args.input]
+        if args.input == "1080p" and not in_res and len(factors) == 1:
+            t, src = pmc_traffic("lfg::scale_2x" if args.workload == "scale" else "lfg::")
+            if t is not None:
+                roofline["traffic"] = t
+                roofline["traffic_source"] = (f"{src}: FETCH_SIZE + WRITE_SIZE of every kernel of a step, two separate rocprofv3 "
+                                              "--pmc passes with this very library; FETCH_SIZE raw (uncalibrated for 4-byte-per-lane loads)")
+            else:
+                roofline["traffic_note"] = src
         line = {
             "metric": (f"interpolated frames/s, {size_name} RGBA8" if args.workload == "pipeline"
                        else f"interpolated frames/s, {size_name} RGBA8 (variant: motion + interpolate at input resolution)" if in_res
@@ -436,13 +540,13 @@ def main():
                                                                     else "motion(8,16)+interpolate at input resolution, then scale real and generated frame" if in_res
                                                                     else "scale only")),
                        "input": [w_in, h_in], "output": [w, h], "factors": factors if args.workload != "scale" else [],
-                       "content": args.content, "parallelism": f"one frame pair per GPU x{world}" + (", RCCL broadcast of the shared previous input frame per step, upscaled on every rank" if world > 1 else "")},
+                       "content": args.content + (" (the motion stage's best case but `static`; see content_sweep)" if args.content == "translated" and args.workload != "scale" else ""),
+                       "parallelism": f"one frame pair per GPU x{world}" + (", lfg_broadcast_frame (RCCL) of the shared previous input frame per step, upscaled on every rank" if world > 1 else "")},
             "roofline": roofline,
             "stages": stages,
-            "path_hbm": {"algorithmic_bytes_per_step": total_bytes,
-                         "achieved_gbs": round(total_bytes * steps / elapsed / 1e9 * 1.0, 1),
-                         "frac_of_8TBs": round(total_bytes * steps / elapsed / 1e9 / HBM_PEAK_GBS, 5)},
+            "library_sha16": library_sha16(),
         }
+        line.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w_in, h_in, w, h, factors, args.workload)
         print(json.dumps(line), flush=True)

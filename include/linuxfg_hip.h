@@ -221,6 +221,33 @@ int  lfg_interpolate_frames_multi(lfg_context *ctx, const lfg_frame *prev, const
  * (shaders/motion.comp:56) into `device_rgba32f` (width*height*16 bytes, device memory). */
 int  lfg_mv_export_rgba32f(lfg_context *ctx, const lfg_frame *mv, void *device_rgba32f);
 
+/* ---------------------------------------------------------------- multi-GPU: the one exchange of the path */
+
+/* Frame pairs are independent, so a batch shards one pair per GPU with no communication -- except that the batch can
+ * share its previous frame, which then travels from the rank that owns it to every other rank as ONE broadcast per
+ * frame (RCCL ncclBroadcast of width*height*bpp bytes as ncclUint8, over xGMI).  The
+ * reference has a single queue and no communication (src/vulkan_context.cpp:130-151): no counterpart.
+ *
+ * One process (or thread) per GPU, one context each.  Rank 0 makes the id and hands its bytes to the other ranks by
+ * any means it likes (a file, a socket, MPI, a torch.distributed store); then EVERY rank calls lfg_comm_init with the
+ * same id -- a collective call that returns once all ranks have arrived.  librccl.so is opened the first time one of
+ * these calls is made; without it they return LFG_ERR_UNSUPPORTED. */
+#define LFG_COMM_ID_BYTES 128
+typedef struct lfg_comm_id { char bytes[LFG_COMM_ID_BYTES]; } lfg_comm_id;
+int  lfg_comm_unique_id(lfg_comm_id *out_id);
+int  lfg_comm_init(lfg_context *ctx, int nranks, int rank, const lfg_comm_id *id);
+int  lfg_comm_rank(const lfg_context *ctx);       /* -1 without a communicator */
+int  lfg_comm_ranks(const lfg_context *ctx);      /*  0 without a communicator */
+/* Broadcast a tightly packed frame (every rank passes its own frame of the same size and format) from `root`,
+ * asynchronously on the context's communication stream: it starts once everything enqueued so far on the compute
+ * stream has finished (the kernels still reading the frame on a receiver, the kernels producing it on the root) and
+ * runs next to whatever is enqueued afterwards.  Nothing enqueued later may touch the frame before lfg_comm_wait(). */
+int  lfg_broadcast_frame(lfg_context *ctx, lfg_frame *frame, int root);
+/* Make everything enqueued on the compute stream from now on wait (on the device) for the broadcasts issued so far. */
+int  lfg_comm_wait(lfg_context *ctx);
+/* Collective teardown (also done by lfg_context_destroy).  Idempotent. */
+int  lfg_comm_destroy(lfg_context *ctx);
+
 /* ---------------------------------------------------------------- diagnostics */
 
 /* The motion kernel uses a hand-written correctly rounded sqrt (csrc/motion.hip: exact_sqrt).  This

@@ -21,6 +21,7 @@ STAGE_SCALE, STAGE_MOTION, STAGE_INTERPOLATE = 0, 1, 2
 MOTION_PREFILTERED, MOTION_EXACT_ONLY = 0, 1
 SEMANTICS_REFERENCE, SEMANTICS_INTENDED = 0, 1
 _BPP = {FORMAT_RGBA8: 4, FORMAT_MV_S8X2: 2}
+COMM_ID_BYTES = 128
 
 
 class LfgError(RuntimeError):
@@ -74,6 +75,13 @@ SIGNATURES = {
     "lfg_interpolate_frames_multi": (_i, [_vp, _FP, _FP, ctypes.POINTER(_FP), ctypes.POINTER(ctypes.c_float), _u32]),
     "lfg_mv_export_rgba32f": (_i, [_vp, _FP, _vp]),
     "lfg_selftest_sqrt": (_i, [_vp, _u32, _u32, ctypes.POINTER(ctypes.c_uint64)]),
+    "lfg_comm_unique_id": (_i, [_vp]),
+    "lfg_comm_init": (_i, [_vp, _i, _i, _vp]),
+    "lfg_comm_rank": (_i, [_vp]),
+    "lfg_comm_ranks": (_i, [_vp]),
+    "lfg_broadcast_frame": (_i, [_vp, _FP, _i]),
+    "lfg_comm_wait": (_i, [_vp]),
+    "lfg_comm_destroy": (_i, [_vp]),
     "lfg_diag_scale_2x_strip": (_i, [_u32, _u32, _u32, ctypes.POINTER(_u32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "lfg_profile_enable": (_i, [_vp, _i]),
     "lfg_profile_reset": (_i, [_vp]),
@@ -265,6 +273,31 @@ class Context:
         n = ctypes.c_uint64()
         self._check(self.lib.lfg_selftest_sqrt(self.h, lo_bits, hi_bits, ctypes.byref(n)), "lfg_selftest_sqrt")
         return n.value
+
+    # -- multi-GPU: the shared previous frame (RCCL behind the C-ABI)
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """128 bytes made by ONE rank; hand them to the others (torch.distributed store, file, ...)."""
+        buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+        rc = load().lfg_comm_unique_id(buf)
+        if rc != 0:
+            raise LfgError(f"lfg_comm_unique_id failed ({rc}): is librccl.so available?")
+        return buf.raw
+
+    def comm_init(self, nranks: int, rank: int, comm_id: bytes):
+        if len(comm_id) != COMM_ID_BYTES:
+            raise ValueError(f"communicator id must be {COMM_ID_BYTES} bytes")
+        buf = ctypes.create_string_buffer(comm_id, COMM_ID_BYTES)
+        self._check(self.lib.lfg_comm_init(self.h, nranks, rank, buf), "lfg_comm_init")
+
+    def broadcast_frame(self, f: Frame, root: int = 0):
+        self._check(self.lib.lfg_broadcast_frame(self.h, ctypes.byref(f), root), "lfg_broadcast_frame")
+
+    def comm_wait(self):
+        self._check(self.lib.lfg_comm_wait(self.h), "lfg_comm_wait")
+
+    def comm_destroy(self):
+        self._check(self.lib.lfg_comm_destroy(self.h), "lfg_comm_destroy")
 
     # -- measurement
     def profile_enable(self, on: bool = True):

@@ -272,6 +272,7 @@ LFG_EXPORT int lfg_context_create(int device_ordinal, lfg_context **out_ctx) {
 LFG_EXPORT void lfg_context_destroy(lfg_context *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    (void)lfg_comm_destroy(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream != ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     for (auto &s : ctx->prof_pending) { (void)hipEventDestroy(s.begin); (void)hipEventDestroy(s.end); }

@@ -88,6 +88,12 @@ struct lfg_context {
     int semantics = 0;                         // 0: the shaders as written, 1: "intended" (lfg_set_semantics)
     uint32_t *motion_tables = nullptr;         // device: [semantics][rank2scan | order32 | entryOfScan], then baseScan
     bool motion_hints = true;                  // per-call visiting order from sample-block hints (LFG_MOTION_HINTS=0: off)
+    // the one exchange of the path (lfg_comm.cpp): an RCCL communicator, its stream and two events
+    void *comm = nullptr;                      // ncclComm_t
+    int comm_ranks = 0, comm_rank = 0;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t comm_ready = nullptr, comm_done = nullptr;
+    bool comm_pending = false;                 // a broadcast has been issued that the compute stream has not been told to wait for
     // profiling
     bool profile = false;
     std::vector<lfg::ProfileSlot> prof_pending;

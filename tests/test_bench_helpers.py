@@ -27,12 +27,50 @@ def test_every_rank_moves_inside_the_search_range():
     assert len(seen) == 8                                    # eight GPUs, eight different motions
 
 
-def test_counter_summaries_are_readable():
-    """The committed profiles feed two fields of the bench line; a format drift must not turn them into None unnoticed."""
+SAMPLE_TRAFFIC = """# lib_sha16 0123456789abcdef
+# steps 10
+kernel lfg::interpolate_kernel launches_per_step 1 mean_us 20.27 FETCH_SIZE 8185 WRITE_SIZE 32400
+kernel lfg::motion_prefilter_kernel launches_per_step 2 mean_us 319.6 FETCH_SIZE 116200 WRITE_SIZE 162200
+kernel lfg::motion_resolve_kernel launches_per_step 1 mean_us 48.4 FETCH_SIZE 11000 WRITE_SIZE 388
+kernel lfg::scale_2x_kernel launches_per_step 1 mean_us 12.9 FETCH_SIZE 6616 WRITE_SIZE 32630
+per_step FETCH_SIZE 258201 WRITE_SIZE 389818
+"""
+SAMPLE_SQ = """# lib_sha16 0123456789abcdef
+# steps 10
+kernel lfg::motion_prefilter_kernel launches_per_step 2 mean_us 320.0 SQ_INSTS_LDS 4450000 SQ_INSTS_SALU 9000000 SQ_INSTS_VALU 90250000 SQ_WAVES 40000
+kernel lfg::scale_2x_kernel launches_per_step 1 mean_us 12.9 SQ_INSTS_LDS 280000 SQ_INSTS_SALU 500000 SQ_INSTS_VALU 3270000 SQ_WAVES 4352
+per_step SQ_INSTS_VALU 183770000
+"""
+
+
+def test_counter_tables_are_read_back_only_for_the_library_that_made_them(tmp_path, monkeypatch):
+    """`roofline.traffic` and `dominant_stage.executed` come from committed counter tables (tools/pmc_per_step.py); a
+    format drift must not turn them into None unnoticed, and a table taken with another build must not be quoted."""
     b = _bench()
-    traffic, src = b.pmc_traffic(["lfg::motion_tiled", "lfg::motion_prefilter", "lfg::motion_resolve", "lfg::motion_hint", "lfg::motion_order"])
-    assert src and src.startswith("profiles/") and traffic and 5e7 < traffic < 5e9
-    ex = b.pmc_executed("lfg::motion_prefilter")
-    assert ex is not None and ex["launches_per_call"] == b.PREFILTER_LAUNCHES_PER_CALL
-    assert 0.05 < ex["valu_issue_utilisation"] < 1.0 and ex["valu_wave_instructions"] > 1e7
-    assert b.pmc_traffic("lfg::scale_2x")[0] > 1e6
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "profiles" / "r02_hbm_traffic_pmc.txt").write_text(SAMPLE_TRAFFIC)
+    (tmp_path / "profiles" / "r02_sq_counters.txt").write_text(SAMPLE_SQ)
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    monkeypatch.setattr(b, "library_sha16", lambda: "0123456789abcdef")
+    traffic, src = b.pmc_traffic("lfg::")
+    assert src == "profiles/r02_hbm_traffic_pmc.txt"
+    want = (8185 + 32400 + 2 * (116200 + 162200) + 11000 + 388 + 6616 + 32630) * 1024
+    assert traffic == want
+    assert b.pmc_traffic("lfg::scale_2x")[0] == (6616 + 32630) * 1024
+    ex = b.pmc_executed("lfg::motion_")
+    assert ex["valu_wave_instructions"] == 2 * 90250000 and ex["kernel_us_per_step_in_that_pass"] == 640.0
+    assert abs(ex["valu_issue_utilisation"] - 2 * 90250000 * 4 / (640e-6 * 2.4e9 * 1024)) < 1e-3
+    monkeypatch.setattr(b, "library_sha16", lambda: "ffffffffffffffff")       # another build: nothing is quoted
+    t, why = b.pmc_traffic("lfg::")
+    assert t is None and "not quoted" in why
+    assert b.pmc_executed("lfg::motion_") is None
+
+
+def test_contents_are_deterministic_and_distinct():
+    b = _bench()
+    frames = {c: b.make_content(c, 192, 108, 0, 0) for c in b.CONTENTS}
+    again = b.make_content("occluded", 192, 108, 0, 0)
+    assert (frames["occluded"][1] == again[1]).all()
+    assert (frames["static"][0] == frames["static"][1]).all()
+    cur = [frames[c][1].tobytes() for c in b.CONTENTS]
+    assert len(set(cur)) == len(cur)

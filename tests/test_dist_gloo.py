@@ -1,7 +1,9 @@
 """The N > 1 path on CPU: two processes over gloo run the same double-buffered shared-frame
-broadcast and per-rank sharding that bench.py uses on the GPU node (there the backend is nccl = RCCL).
-Checks that every rank sees the source rank's frame for every step, that slots are never clobbered
-before use, and the max-over-ranks / whole-job aggregation bench.py reports."""
+broadcast and per-rank sharding that bench.py uses on the GPU node (there the transport is the C-ABI's
+lfg_broadcast_frame = RCCL; here torch.distributed over gloo carries the bytes).  Checks that every rank sees the
+source rank's frame for every step, that slots are never clobbered before use, the communicator-id exchange
+bench.py does before lfg_comm_init, the C-ABI's argument validation without a GPU, and the max-over-ranks /
+whole-job aggregation bench.py reports."""
 import os
 import socket
 
@@ -34,12 +36,32 @@ def _worker(rank, world, port, q):
         def refill(step, slot):                      # only ever called on the source rank
             slots[slot].copy_(frames[step])
 
-        b = sharding.SharedFrameBroadcaster(slots, src=0, dist=dist, world_size=world, refill=refill)
+        # the id exchange of bench.py: rank 0 makes 128 bytes, everyone ends up with the same ones.  (A real id needs a
+        # GPU -- RCCL initialises HIP -- so here rank 0 makes recognisable bytes instead.)
+        comm_id = sharding.exchange_comm_id(dist, lambda: bytes((7 * i + 3) & 0xFF for i in range(128)), src=0)
+        assert comm_id == bytes((7 * i + 3) & 0xFF for i in range(128))
+        with pytest.raises(ValueError):
+            if rank == 0:
+                sharding.exchange_comm_id(dist, lambda: b"short", src=0)
+            else:
+                raise ValueError("(only the source rank validates the id it made)")
+        # the C-ABI's communicator calls refuse bad arguments before they touch RCCL or a GPU
+        from linux_fg_amd import capi
+        lib = capi.load()
+        import ctypes
+        idbuf = ctypes.create_string_buffer(comm_id, 128)
+        assert lib.lfg_comm_init(None, world, rank, idbuf) == -1          # no context
+        assert lib.lfg_comm_unique_id(None) == -1
+        assert lib.lfg_comm_ranks(None) == 0 and lib.lfg_comm_rank(None) == -1
+        assert lib.lfg_comm_wait(None) == -1 and lib.lfg_broadcast_frame(None, None, 0) == -1
+
+        transport = sharding.TorchTransport(dist, slots, src=0)
+        b = sharding.SharedFrameBroadcaster(2, transport, world_size=world, is_source=rank == 0, refill=refill)
         b.start(0)
         sums = []
         mine = sharding.stream_of_rank(rank, world)
         for k in range(STEPS):
-            shared = b.acquire(k)
+            shared = slots[b.acquire(k)]
             assert torch.equal(shared, frames[k]), f"rank {rank} step {k}: wrong shared frame"
             # stand-in for the per-rank kernels: combine the shared frame with this rank's own stream
             own = torch.from_numpy(synth.make_prev(w, h, synth.BASE_SEED + mine[0]))

@@ -1,0 +1,55 @@
+"""The C-ABI's communicator calls on the GPU (include/linuxfg_hip.h: lfg_comm_*, lfg_broadcast_frame), one rank: RCCL is
+opened at run time, a one-rank communicator is created, a frame is broadcast on the communication stream next to kernels
+on the compute stream, and every refusal the header promises is checked.  More ranks need more GPUs (RCCL wants one device
+per rank): the driver's multi-GPU bench runs that; the scheduling around these calls is tested over gloo in
+tests/test_dist_gloo.py."""
+import numpy as np
+import pytest
+
+from linux_fg_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_one_rank_communicator_broadcast_and_refusals():
+    from linux_fg_amd import capi
+    cid = capi.Context.comm_unique_id()
+    assert len(cid) == capi.COMM_ID_BYTES and any(cid)
+    with capi.Context(0) as ctx:
+        assert ctx.lib.lfg_comm_ranks(ctx.h) == 0 and ctx.lib.lfg_comm_rank(ctx.h) == -1
+        f = ctx.frame_from(synth.make_prev(320, 180, seed=5))
+        with pytest.raises(capi.LfgError, match="no communicator"):
+            ctx.broadcast_frame(f, 0)
+        with pytest.raises(capi.LfgError, match="rank < nranks"):
+            ctx.comm_init(2, 2, cid)
+        ctx.comm_init(1, 0, cid)
+        assert ctx.lib.lfg_comm_ranks(ctx.h) == 1 and ctx.lib.lfg_comm_rank(ctx.h) == 0
+        with pytest.raises(capi.LfgError, match="already has a communicator"):
+            ctx.comm_init(1, 0, cid)
+        # a broadcast between kernels: scale reads f before and after; the pixels are those of the root (this rank)
+        up1, up2 = ctx.create_frame(640, 360), ctx.create_frame(640, 360)
+        ctx.scale(f, up1)
+        ctx.broadcast_frame(f, 0)
+        ctx.comm_wait()
+        ctx.scale(f, up2)
+        ctx.comm_wait()                                       # nothing pending: a no-op
+        assert (ctx.download(f) == synth.make_prev(320, 180, seed=5)).all()
+        assert (ctx.download(up1) == ctx.download(up2)).all()
+        with pytest.raises(capi.LfgError, match="root out of range"):
+            ctx.broadcast_frame(f, 1)
+        wide = ctx.create_frame(330, 180)
+        view = capi.Context.wrap(wide.data, 320, 180, capi.FORMAT_RGBA8, pitch=330 * 4)
+        with pytest.raises(capi.LfgError, match="tightly packed"):
+            ctx.broadcast_frame(view, 0)
+        mv = ctx.frame_from(np.zeros((180, 320, 2), np.int8), capi.FORMAT_MV_S8X2)
+        ctx.broadcast_frame(mv, 0)                            # motion-vector frames travel the same way
+        ctx.comm_wait()
+        ctx.comm_destroy()
+        ctx.comm_destroy()                                    # idempotent
+        with pytest.raises(capi.LfgError, match="no communicator"):
+            ctx.comm_wait()
+        ctx.comm_init(1, 0, capi.Context.comm_unique_id())    # a context can get a new communicator after destroying one
+        ctx.broadcast_frame(f, 0)
+        ctx.comm_wait()
+        ctx.sync()
+        # lfg_context_destroy tears the communicator down

@@ -2,7 +2,7 @@
 # Runs on the MI355X box (gpurun): regenerates every file profiles/README.md lists into gpurun_out/profiles_new/.
 # usage: tools/collect_profiles.sh rNN
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/profiles_new
 rm -rf $OUT && mkdir -p $OUT
@@ -10,26 +10,25 @@ cd /tmp && export TMPDIR=/tmp
 stats() {   # $1 = name, rest = bench args [env prefix via LFG_MOTION_MODE]
   local name=$1; shift
   rm -rf /tmp/prof_$name
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python3 $R/bench.py "$@" --no-cpu-baseline \
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python3 $R/bench.py "$@" --no-cpu-baseline --no-extras \
       > $OUT/${TAG}_${name}_bench_under_rocprof.json 2> /tmp/prof_$name.err
   cp $(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${name}_kernel_stats.csv
 }
-stats pipeline --steps 10 --warmup 2
-stats scale --workload scale
+stats pipeline --steps 200 --warmup 5
+stats scale --workload scale --steps 2000 --warmup 50
 LFG_MOTION_MODE=1 stats pipeline_exact_only --steps 5 --warmup 1
 echo "kernel stats done"
-python3 $R/bench.py --steps 10 --warmup 2 > $OUT/${TAG}_pipeline_bench.json 2> /tmp/bench.err
+python3 $R/bench.py > $OUT/${TAG}_pipeline_bench.json 2> /tmp/bench.err
 python3 $R/bench.py --workload scale > $OUT/${TAG}_scale_bench.json 2>> /tmp/bench.err
 echo "bench done"
+N=10
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 $R/tools/run_stage.py pipeline $N > /dev/null 2>&1
 done
-python3 $R/tools/pmc_summary.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE | sed "s#/tmp/##" > $OUT/${TAG}_hbm_traffic_pmc.txt
-for c in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT"; do
-  rm -rf /tmp/pmc_sq
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_sq -- python3 $R/tools/run_stage.py motion 2 > /dev/null 2>&1
-done
-python3 $R/tools/pmc_summary.py /tmp/pmc_sq | sed "s#/tmp/##" > $OUT/${TAG}_motion_sq_counters.txt
-bash $R/tools/bench_contents.sh > $OUT/${TAG}_content_table.txt 2>&1
+python3 $R/tools/pmc_per_step.py $N /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE > $OUT/${TAG}_hbm_traffic_pmc.txt
+rm -rf /tmp/pmc_sq
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT \
+    --output-format csv -d /tmp/pmc_sq -- python3 $R/tools/run_stage.py pipeline $N > /dev/null 2>&1
+python3 $R/tools/pmc_per_step.py $N /tmp/pmc_sq > $OUT/${TAG}_sq_counters.txt
 echo "pmc done"; ls -la $OUT
