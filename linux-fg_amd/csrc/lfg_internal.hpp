@@ -34,8 +34,8 @@ struct AxisTable {
     int strips_per_xcd = 0;
 };
 
-struct MotionWorkspaceLayout { size_t list, umin, count, tileFlags, segDone, segMap, queueCount, order, plan, auxList, auxUmin, auxCount,
-                               queue, dynList, dynUmin, dynCount, total; int queueCap; };
+struct MotionWorkspaceLayout { size_t list, umin, count, tileFlags, segDone, segMap, queueCount, ctrl, order, plan, auxList, auxUmin, auxCount,
+                               queue, dynList, dynUmin, dynCount, total; int queueCap, slots; };
 // Work units of the motion prefilter (motion.hip: prefilter_plan).  A unit is a 56 x 64 tile, or one of nChunks
 // contiguous parts of a tile's candidate order, or one 16-row segment of a tile with its four waves on four parts of
 // the order; parts have private lists in the aux arrays (merged by the resolve kernel).
@@ -51,9 +51,8 @@ struct PrefilterPlan {               // passed by value to the kernels
     // of unitMap-style entries and their private lists in 16-row blocks; see motion_prefilter_kernel.
     uint32_t *segMap;                // per (tile, segment): 0, or first block | parts << 24 | 1 << 31
     uint32_t *queueCount;            // [0] entries pushed this call (may exceed queueCap: the excess was not handed over), [1] tiles flagged
-    uint32_t *queue;                 // [queueCap] unit entries, [queueCap] first blocks
+    uint32_t *queue;                 // [queueCap] unit entries (0: not pushed yet); slot h's lists are blocks 4h .. 4h+3
     int queueCap;
-    int fromQueue;                   // this launch takes its units from the queue
     uint2 *dynList;
     float *dynUmin;
     uint32_t *dynCount;

@@ -389,16 +389,21 @@ __device__ unsigned long long gResolveStats[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, ~0
 #ifndef LFG_PREF_OCC
 #define LFG_PREF_OCC 3
 #endif
-__global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
+#ifndef LFG_DYN_PARTS
+#define LFG_DYN_PARTS 8                 // parts of the candidate order a handed-over segment is searched in (4 or 8)
+#endif
+static_assert(LFG_DYN_PARTS == 4 || LFG_DYN_PARTS == 8, "four parts per queue entry, at most eight lists per pixel in the resolve kernel");
+
+// One work unit of the prefilter (see motion_prefilter_kernel below, which hands units to its workgroups).
+// `unit` indexes the plan's unit table, or -- fromQueue -- the queue of segments handed over at run time.
+__device__ __forceinline__ void prefilter_unit(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int W, int H, uint2 *__restrict__ list, float *__restrict__ uminOut,
     uint32_t *__restrict__ countOut, uint32_t *__restrict__ tileFlags, int flagTilesX,
-    const uint32_t *__restrict__ order32, PrefilterPlan sp,
-    int8_t *__restrict__ mv, int mvPitch, const uint32_t *__restrict__ rank2scan, uint32_t *__restrict__ segDone) {
-    __shared__ uint32_t sWin[kWinH * kWinW];                           // 38.2 KB packed RGBA8 search window
-    __shared__ __attribute__((aligned(8))) float sSlab[kPNT / 64][4 * kSlabP];      // 4 x 2.1 KB
-    __shared__ uint32_t sOrder[kCand + 7];                             // the visiting order
-    __shared__ uint32_t sGiveUp;
+    const uint32_t *__restrict__ order32, const PrefilterPlan &sp,
+    int8_t *__restrict__ mv, int mvPitch, const uint32_t *__restrict__ rank2scan, uint32_t *__restrict__ segDone,
+    const int unit, const bool fromQueue, const uint32_t um,
+    uint32_t *sWin, float (*sSlab)[4 * kSlabP], uint32_t *sOrder, uint32_t &sGiveUp) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -416,11 +421,8 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
     // `seg` is the segment this wave works on, `wave` its place in the workgroup (its slab).
     //   A whole tile's wave that still has a threshold of 510 or more after the first eight candidates -- its segment
     //   holds pixels without a match, the partial-distortion test cannot fire, all 1089 candidates await a full
-    //   evaluation -- hands the segment over instead: it pushes a segment unit onto a queue and returns, and a second
-    //   launch of this kernel (sp.fromQueue) runs the queued segments with four waves each.
-    const int unit = blockIdx.x;
-    if (sp.fromQueue && unit >= (int)min(*sp.queueCount, (uint32_t)sp.queueCap)) return;
-    const uint32_t um = sp.fromQueue ? sp.queue[unit] : sp.unitMap[unit];
+    //   evaluation -- hands the segment over instead: it pushes a segment unit onto a queue and returns, and the
+    //   workgroups that have run out of plan units take the queued segments, four waves each (motion_prefilter_kernel).
     const bool segUnit = ((um >> 28) & 1u) != 0u;
     const int tile = (int)(um & 0xFFFFFu), nChunks = (int)((um >> 24) & 0xFu);
     const int seg = segUnit ? (int)((um >> 29) & 3u) : wave;
@@ -440,7 +442,6 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
 #endif
     constexpr int kHead = LFG_HEAD;
     const int nHead = chunk > 0 ? kHead : 0;
-    for (int i = tid; i < kCand; i += kPNT) sOrder[i] = order32[i];
 
     // ---- search window: prev(bx0 - R + wx, by0 - R + wy), zero outside the image (texelFetch semantics); a segment
     // unit stages its own 55 rows only.  Staging is a latency chain (load -> LDS store), so everything a thread loads is
@@ -594,11 +595,11 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
     // Whole tiles write into the image-shaped arrays (row stride W), shared tiles into their unit's private
     // 56 x 64 block of the auxiliary arrays (row stride 56).
     // (auxiliary blocks: a tile's 64 rows for the units of the plan, a segment's 16 rows for queued units)
-    const int auxUnit = whole ? 0 : (int)(sp.fromQueue ? sp.queue[sp.queueCap + unit] : sp.unitAux[unit]) + chunk;
-    const int auxRows = sp.fromQueue ? kSeg : kPTH, auxRow0 = sp.fromQueue ? kSeg * seg : 0;
-    uint2 *const auxListBase = sp.fromQueue ? sp.dynList : sp.auxList;
-    float *const auxUminBase = sp.fromQueue ? sp.dynUmin : sp.auxUmin;
-    uint32_t *const auxCountBase = sp.fromQueue ? sp.dynCount : sp.auxCount;
+    const int auxUnit = whole ? 0 : (fromQueue ? 4 * unit + wave : (int)sp.unitAux[unit] + chunk);
+    const int auxRows = fromQueue ? kSeg : kPTH, auxRow0 = fromQueue ? kSeg * seg : 0;
+    uint2 *const auxListBase = fromQueue ? sp.dynList : sp.auxList;
+    float *const auxUminBase = fromQueue ? sp.dynUmin : sp.auxUmin;
+    uint32_t *const auxCountBase = fromQueue ? sp.dynCount : sp.auxCount;
     const uint32_t rowStride = whole ? (uint32_t)W : (uint32_t)kPTW;
     uint2 *const waveList = whole
         ? list + ((size_t)(ty0 + kSeg * seg) * (size_t)kListK * (size_t)W + (size_t)tx0)
@@ -938,16 +939,20 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
         for (int i0 = 0, count = 2; i0 < nEntries; i0 += count, count = i0 == 2 ? hintsEnd - 2 : 64) {
             // Hand the segment over?  Either no threshold to test against once every hint has been tried, or the test
             // let a quarter of the first full batch through.
-            if (whole && !sp.fromQueue && order32[kCand] != 0u &&
+            if (whole && !fromQueue && order32[kCand] != 0u &&
                 ((i0 == hintsEnd && !(waveThr < 4.0f * 510.0f)) || (i0 == hintsEnd + 64 && firstBatchSurvivors >= 16))) {
+                // LFG_DYN_PARTS parts of the candidate order, four per queue entry (one workgroup each); the entries of a
+                // segment are consecutive slots, so its private lists are the blocks 4 slot .. 4 slot + parts - 1
+                constexpr uint32_t kEntries = LFG_DYN_PARTS / 4;
                 uint32_t slot = 0u;
-                if (lane == 0) slot = atomicAdd(sp.queueCount, 1u);
+                if (lane == 0) slot = atomicAdd(sp.queueCount, kEntries);
                 slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
-                if (slot < (uint32_t)sp.queueCap) {
+                if (slot + kEntries <= (uint32_t)sp.queueCap) {
                     if (lane == 0) {
-                        sp.queue[slot] = (uint32_t)tile | (4u << 24) | (1u << 28) | ((uint32_t)seg << 29);
-                        sp.queue[sp.queueCap + slot] = 4u * slot;
-                        sp.segMap[tile * (kPTH / kSeg) + seg] = (4u * slot) | (4u << 24) | (1u << 31);
+                        sp.segMap[tile * (kPTH / kSeg) + seg] = (4u * slot) | ((uint32_t)LFG_DYN_PARTS << 24) | (1u << 31);    // (read by the resolve kernel)
+                        // the entry itself is the "slot filled" signal (never 0): an atomic, like the read that waits for it
+                        for (uint32_t k = 0; k < kEntries; ++k)
+                            atomicExch(&sp.queue[slot + k], (uint32_t)tile | ((4u * k) << 20) | ((uint32_t)LFG_DYN_PARTS << 24) | (1u << 28) | ((uint32_t)seg << 29));
                     }
                     return 2;
                 }
@@ -994,8 +999,8 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
     const int outcome = run();
     const bool gaveUp = outcome == 1;
 #ifdef LFG_MOTION_STAMPS
-    if (lane == 0 && blockIdx.x < 8192) {
-        unsigned long long *o = gMotionStamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+    if (lane == 0 && !fromQueue && unit < 8192) {
+        unsigned long long *o = gMotionStamps + ((size_t)unit * 4 + wave) * 8;
         o[0] = stampStart; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = stampEvals; o[3] = ((unsigned long long)borderTile << 32) | stampBatches;
         o[4] = stampStaged; o[5] = stampFirst;
     }
@@ -1177,6 +1182,107 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
         if (__builtin_amdgcn_readfirstlane(__ballot(open) != 0ull) && lane == 0) *sOpen = 1u;
         __syncthreads();
         if (tid == 0 && *sOpen == 0u) segDone[tile * (kPTH / kSeg) + seg] = 1u;
+    }
+}
+
+// The prefilter's launch: as many workgroups as the device holds at once (prefilter_slots), each taking work units
+// until none are left -- first the units of the plan (ctrl[0]: next index; rim segment units come first in the
+// table, so the long ones start at once), then the segments that whole tiles hand over AT RUN TIME (ctrl[2]: next
+// queue slot; sp.queueCount[0]: slots pushed so far).  A segment is handed over by a wave that finds no match for it
+// once every hint has been tried: one such segment used to hold its whole tile's workgroup for milliseconds, and a
+// second launch for the queue could only start when the first had drained.  Now the workgroups that run out of
+// plan units pick the queued segments up while the long units are still running.
+//   ctrl[1] counts finished plan units: only a running plan unit can push, so "all plan units finished and my slot
+//   is still empty" ends a workgroup.  A workgroup that waits polls with read-modify-write atomics (the counters
+//   and the queue entries are written by atomics on other XCDs; the per-XCD L2s are not coherent for plain
+//   accesses) and sleeps ~14 us between polls.  Every wait is bounded by the running units, every workgroup of
+//   the grid is resident or finds nothing to wait for: no workgroup ever waits for one that has not started.
+constexpr uint32_t kNoUnit = 0xFFFFFFFFu;
+#ifndef LFG_QUEUE_FIRST
+#define LFG_QUEUE_FIRST 0
+#endif
+#ifndef LFG_PREF_POLL_SLEEPS
+#define LFG_PREF_POLL_SLEEPS 2         // x 8128 clocks between two looks of a waiting workgroup
+#endif
+// A word that workgroups on other XCDs update with atomics, as they left it: an agent-scope load (served by L2, which
+// those atomics write through), and every 32nd look a read-modify-write that changes nothing -- a compare-and-swap
+// against a value the word never holds -- so that progress never depends on a cache line being refreshed.
+__device__ __forceinline__ uint32_t peek(uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t peek_hard(uint32_t *p) { return atomicCAS(p, 0xFFFFFFFFu, 0xFFFFFFFFu); }
+
+__global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
+    const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
+    int W, int H, uint2 *__restrict__ list, float *__restrict__ uminOut,
+    uint32_t *__restrict__ countOut, uint32_t *__restrict__ tileFlags, int flagTilesX,
+    const uint32_t *__restrict__ order32, PrefilterPlan sp,
+    int8_t *__restrict__ mv, int mvPitch, const uint32_t *__restrict__ rank2scan, uint32_t *__restrict__ segDone,
+    uint32_t *__restrict__ ctrl) {
+    __shared__ uint32_t sWin[kWinH * kWinW];                           // 38.2 KB packed RGBA8 search window
+    __shared__ __attribute__((aligned(8))) float sSlab[kPNT / 64][4 * kSlabP];      // 4 x 2.1 KB
+    __shared__ uint32_t sOrder[kCand + 7];                             // the visiting order
+    __shared__ uint32_t sGiveUp;
+    __shared__ uint32_t sNext[2];                                      // {unit | fromQueue << 31, its table entry}
+    for (int i = threadIdx.x; i < kCand; i += kPNT) sOrder[i] = order32[i];      // once: the same for every unit
+    // Thread 0 hands out the work.  Plan units: ctrl[0] is the next index (fetch-and-add).  Queue slots: ctrl[2] is the
+    // next slot, also fetch-and-add -- a compare-and-swap loop collapses when hundreds of workgroups run out of plan
+    // units together -- so a workgroup can come to OWN a slot that no segment has been pushed into yet.  It keeps the
+    // slot (`owned`) through whatever else it does and does not leave while somebody could still fill it.
+    uint32_t owned = kNoUnit;
+    for (;;) {
+        __syncthreads();                   // the previous unit is over for all four waves: its LDS may be reused
+        if (threadIdx.x == 0) {
+            uint32_t next = kNoUnit, entry = 0u;
+            const uint32_t cap = (uint32_t)sp.queueCap;
+            auto wait_entry = [&](uint32_t h) {           // slot h has been pushed (h < tail): its entry is on its way
+                uint32_t e, n = 0u;
+                while ((e = (++n & 31u) ? peek(&sp.queue[h]) : peek_hard(&sp.queue[h])) == 0u) __builtin_amdgcn_s_sleep(8);
+                return e;
+            };
+            if (owned != kNoUnit && (entry = peek(&sp.queue[owned])) != 0u) { next = 0x80000000u | owned; owned = kNoUnit; }
+            // Queued segments before plan units: they are the long units (a segment that searches in full), and the
+            // earlier they start the more of them run next to the plan's units instead of after them.
+            if (LFG_QUEUE_FIRST && next == kNoUnit && owned == kNoUnit && peek(&ctrl[2]) < min(peek(sp.queueCount), cap)) {
+                const uint32_t h = atomicAdd(&ctrl[2], 1u);
+                if (h < min(peek_hard(sp.queueCount), cap)) { entry = wait_entry(h); next = 0x80000000u | h; }
+                else if (h < cap) owned = h;              // lost the race for the last filled slot: h is mine when it fills
+            }
+            if (next == kNoUnit) {        // (drawn when needed, not ahead: a workgroup holding two of the long units in a row
+                                          //  would run them one after the other while others idle)
+                const uint32_t u = atomicAdd(&ctrl[0], 1u);
+                if (u < (uint32_t)sp.units) { next = u; entry = sp.unitMap[u]; }
+            }
+            if (next == kNoUnit) {
+                // Out of plan units: wait for my slot to be filled, or for the last plan unit to finish (only a running
+                // plan unit can push; its pushes precede its count in ctrl[1]).
+                // (A frame in which no segment has been handed over by now -- a clean pan -- is unlikely to start: the
+                //  workgroup leaves at once, because even a waiting workgroup costs the long units that still run beside
+                //  it a few percent.  Should a late unit push after all, the workgroups still running, in the end the
+                //  pusher itself, take the segment.)
+                if (owned == kNoUnit && peek_hard(sp.queueCount) != 0u) { const uint32_t h = atomicAdd(&ctrl[2], 1u); if (h < cap) owned = h; }
+                uint32_t n = 0u;
+                while (owned != kNoUnit) {
+                    const bool hard = (++n & 31u) == 0u;
+                    if ((entry = hard ? peek_hard(&sp.queue[owned]) : peek(&sp.queue[owned])) != 0u) { next = 0x80000000u | owned; owned = kNoUnit; break; }
+                    if ((hard ? peek_hard(&ctrl[1]) : peek(&ctrl[1])) >= (uint32_t)sp.units) {
+                        if (owned < min(peek_hard(sp.queueCount), cap)) { entry = wait_entry(owned); next = 0x80000000u | owned; }
+                        owned = kNoUnit;
+                        break;
+                    }
+                    for (int k = 0; k < LFG_PREF_POLL_SLEEPS; ++k) __builtin_amdgcn_s_sleep(127);
+                }
+            }
+            sNext[0] = next; sNext[1] = entry;
+        }
+        __syncthreads();
+        const uint32_t next = sNext[0], entry = sNext[1];
+        if (next == kNoUnit) return;
+        const bool fromQueue = (next >> 31) != 0u;
+        prefilter_unit(prev, prevPitch, curr, currPitch, W, H, list, uminOut, countOut, tileFlags, flagTilesX, order32, sp,
+                       mv, mvPitch, rank2scan, segDone, (int)(next & 0x7FFFFFFFu), fromQueue, entry, sWin, sSlab, sOrder, sGiveUp);
+        if (!fromQueue) {
+            __syncthreads();               // every wave of the unit is past its pushes
+            if (threadIdx.x == 0) atomicAdd(&ctrl[1], 1u);
+        }
     }
 }
 
@@ -1511,8 +1617,15 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, Motion
     l.segDone = l.tileFlags + tiles * sizeof(uint32_t);
     l.segMap = l.segDone + ptiles * (kPTH / kSeg) * sizeof(uint32_t);
     l.queueCount = l.segMap + ptiles * (kPTH / kSeg) * sizeof(uint32_t);
-    // (+ the number of flagged tiles and the list of the first kShareBelow of them)
-    l.order = align(l.queueCount + (2 + kShareBelow) * sizeof(uint32_t));      // this call's hints and visiting order
+    // (+ the number of flagged tiles and the list of the first kShareBelow of them, + the prefilter's three unit counters)
+    l.ctrl = l.queueCount + (2 + kShareBelow) * sizeof(uint32_t);
+    // ... and the queue of segments handed over at run time (entries double as "slot filled" signals): up to a quarter
+    // of the frame's segments, 2048 at most (a multiple of the entries one segment takes, so that a push either fits as
+    // a whole or is refused as a whole; beyond that a segment is searched by the wave that owns it, as before).  One
+    // memset clears everything from the tile flags to here.
+    l.queueCap = (int)std::min<size_t>(2048, std::max<size_t>(LFG_DYN_PARTS / 4, ptiles * (kPTH / kSeg) / 4 / (LFG_DYN_PARTS / 4) * (LFG_DYN_PARTS / 4)));
+    l.queue = l.ctrl + 4 * sizeof(uint32_t);
+    l.order = align(l.queue + (size_t)l.queueCap * sizeof(uint32_t));           // this call's hints and visiting order
     // work-unit tables and the auxiliary arrays of the shared tiles (see prefilter_plan): one 56 x 64 block per unit
     const PrefilterPlanHost plan = prefilter_plan(width, height, slots);
     const size_t auxUnits = (size_t)plan.auxUnits;
@@ -1520,12 +1633,10 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, Motion
     l.auxList = align(l.plan + (size_t)(2 * plan.units + plan.tiles) * sizeof(uint32_t));
     l.auxUmin = align(l.auxList + auxUnits * kPTH * kPTW * kListK * sizeof(uint2));
     l.auxCount = align(l.auxUmin + auxUnits * kPTH * kPTW * sizeof(float));
-    // Up to a quarter of the frame's segments (2048 at most) can be handed over at run time; each gets four 16-row
-    // blocks of private lists (0.92 MB).  Beyond that a segment is searched by the wave that owns it, as before.
-    l.queueCap = (int)std::min<size_t>(2048, std::max<size_t>(1, ptiles * (kPTH / kSeg) / 4));
+    // each queue entry owns four 16-row blocks of private lists (0.92 MB)
     const size_t dynBlocks = (size_t)l.queueCap * 4;
-    l.queue = align(l.auxCount + auxUnits * kPTH * kPTW * sizeof(uint32_t));
-    l.dynList = align(l.queue + 2 * (size_t)l.queueCap * sizeof(uint32_t));
+    l.dynList = align(l.auxCount + auxUnits * kPTH * kPTW * sizeof(uint32_t));
+    l.slots = slots;
     l.dynUmin = align(l.dynList + dynBlocks * kSeg * kPTW * kListK * sizeof(uint2));
     l.dynCount = align(l.dynUmin + dynBlocks * kSeg * kPTW * sizeof(float));
     l.total = align(l.dynCount + dynBlocks * kSeg * kPTW * sizeof(uint32_t));
@@ -1798,12 +1909,11 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
     sp.queueCount = reinterpret_cast<uint32_t *>(workspace + l.queueCount);
     sp.queue = reinterpret_cast<uint32_t *>(workspace + l.queue);
     sp.queueCap = l.queueCap;
-    sp.fromQueue = 0;
     sp.dynList = reinterpret_cast<uint2 *>(workspace + l.dynList);
     sp.dynUmin = reinterpret_cast<float *>(workspace + l.dynUmin);
     sp.dynCount = reinterpret_cast<uint32_t *>(workspace + l.dynCount);
     uint32_t *segDone = reinterpret_cast<uint32_t *>(workspace + l.segDone);
-    hipError_t e = hipMemsetAsync(flags, 0, l.order - l.tileFlags, s);             // tile flags, segment marks and map, queue length
+    hipError_t e = hipMemsetAsync(flags, 0, l.order - l.tileFlags, s);             // tile flags, segment marks and map, counters, queue
     if (e != hipSuccess) return e;
     if (useHints && curr.width >= 64u && curr.height >= 64u) {         // this call's visiting order
         uint32_t *hints = reinterpret_cast<uint32_t *>(workspace + l.order);
@@ -1816,22 +1926,13 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
         if (e != hipSuccess) return e;
         order = callOrder;
     }
-    hipLaunchKernelGGL(motion_prefilter_kernel, dim3(sp.units), dim3(kPNT), 0, s,
+    const int groups = std::max(1, std::min(sp.units, l.slots > 0 ? l.slots : sp.units));
+    hipLaunchKernelGGL(motion_prefilter_kernel, dim3(groups), dim3(kPNT), 0, s,
                        (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
                        (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, order, sp,
-                       (int8_t *)mv.data, (int)mv.pitch, rank2scan, segDone);
+                       (int8_t *)mv.data, (int)mv.pitch, rank2scan, segDone, reinterpret_cast<uint32_t *>(workspace + l.ctrl));
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    {   // the segments handed over: one workgroup per queue slot, the unused ones return at once
-        PrefilterPlan sq = sp;
-        sq.fromQueue = 1;
-        hipLaunchKernelGGL(motion_prefilter_kernel, dim3(sq.queueCap), dim3(kPNT), 0, s,
-                           (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
-                           (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, order, sq,
-                           (int8_t *)mv.data, (int)mv.pitch, rank2scan, segDone);
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
-    }
 #ifdef LFG_MOTION_STAMPS
     {
         static int calls = 0;

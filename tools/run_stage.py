@@ -16,8 +16,11 @@ content = sys.argv[3] if len(sys.argv) > 3 else "translated"
 w, h = (int(v) for v in os.environ.get("LFG_STAGE_INPUT", "1920x1080").split("x"))
 W, H = 2 * w, 2 * h
 ctx = capi.Context(0)
-prev_in = synth.make_prev(w, h, synth.BASE_SEED)
-curr_in = synth.translate(prev_in, (3, -2), synth.BASE_SEED) if content == "translated" else synth.noise_bytes(w, h, 12345)
+import importlib.util  # noqa: E402
+_spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+_bench = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_bench)
+prev_in, curr_in = _bench.make_content(content, w, h, 0, 0)          # the benchmark's own frames
 p_in, c_in = ctx.frame_from(prev_in), ctx.frame_from(curr_in)
 P, C, O = ctx.create_frame(W, H), ctx.create_frame(W, H), ctx.create_frame(W, H)
 M = ctx.create_frame(W, H, capi.FORMAT_MV_S8X2)
