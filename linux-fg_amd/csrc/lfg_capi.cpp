@@ -577,12 +577,18 @@ LFG_EXPORT int lfg_motion_last_stats(lfg_context *ctx, uint32_t *out_tiles, uint
         LFG_HIP(ctx, hipMemcpy(cnt.data(), ctx->motion_ws + ctx->motion_ws_layout.count, px * 4, hipMemcpyDeviceToHost));
         // (tiles whose candidates were shared between several workgroups keep their counts elsewhere: left out)
         const lfg::PrefilterPlanHost plan = lfg::prefilter_plan(ctx->motion_ws_w, ctx->motion_ws_h, ctx->motion_slots);
+        // (a segment that settled all of its pixels in the prefilter wrote no counts: its pixels hold at most two records,
+        //  counted as none here)
+        std::vector<uint32_t> segDone((size_t)plan.tiles * 4u);
+        LFG_HIP(ctx, hipMemcpy(segDone.data(), ctx->motion_ws + ctx->motion_ws_layout.segDone, segDone.size() * 4, hipMemcpyDeviceToHost));
         double sum = 0; size_t n = 0;
         for (uint32_t y = 0; y < ctx->motion_ws_h; ++y)
-            for (uint32_t x = 0; x < ctx->motion_ws_w; ++x)
-                if (!flags[(size_t)(y / 64u) * tx + x / 64u] && plan.tileMap[(size_t)(y / 64u) * (size_t)plan.tilesX + x / 56u] == 0xFFFFFFFFu) {
-                    sum += cnt[(size_t)y * ctx->motion_ws_w + x]; ++n;
+            for (uint32_t x = 0; x < ctx->motion_ws_w; ++x) {
+                const size_t ptile = (size_t)(y / 64u) * (size_t)plan.tilesX + x / 56u;
+                if (!flags[(size_t)(y / 64u) * tx + x / 64u] && plan.tileMap[ptile] == 0xFFFFFFFFu) {
+                    sum += segDone[ptile * 4u + (y % 64u) / 16u] ? 0.0 : (double)cnt[(size_t)y * ctx->motion_ws_w + x]; ++n;
                 }
+            }
         *out_mean_recorded = n ? sum / (double)n : 0.0;
     }
     return LFG_OK;

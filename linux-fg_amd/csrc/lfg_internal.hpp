@@ -44,7 +44,7 @@ struct PrefilterPlan {               // passed by value to the kernels
     const uint32_t *unitMap;         // per unit: tile | (first) chunk << 20 | nChunks << 24 | segment unit << 28 | segment << 29
     const uint32_t *unitAux;         // per unit: index of its tile's first 56 x 64 block in the aux arrays (whole tiles: 0xFFFFFFFF)
     const uint32_t *tileMap;         // per tile: 0xFFFFFFFF (whole) or first aux index | nChunks << 24
-    uint2 *auxList;
+    uint32_t *auxList;               // records: csrc/motion.hip, Rec
     float *auxUmin;
     uint32_t *auxCount;
     // Segments handed over at run time (a whole tile's segment that finds no match after the first batches): a queue
@@ -53,7 +53,7 @@ struct PrefilterPlan {               // passed by value to the kernels
     uint32_t *queueCount;            // [0] entries pushed this call (may exceed queueCap: the excess was not handed over), [1] tiles flagged
     uint32_t *queue;                 // [queueCap] unit entries (0: not pushed yet); slot h's lists are blocks 4h .. 4h+3
     int queueCap;
-    uint2 *dynList;
+    uint32_t *dynList;
     float *dynUmin;
     uint32_t *dynCount;
 };

@@ -376,6 +376,17 @@ __device__ __forceinline__ bool block_leaves_prev(int px, int py, int dx, int dy
     return (px + kB / 2 - 1 + dx < 0) | (px - kB / 2 + dx >= W) | (py + kB / 2 - 1 + dy < 0) | (py - kB / 2 + dy >= H);
 }
 
+// A recorded candidate: 21 bits of its S~ (the float's exponent and 13 mantissa bits, i.e. S~ rounded DOWN by at most
+// 2^-13 of its value) above its 11-bit rank in the tie order.  The resolve kernel keeps a record while that lower
+// bound passes the pixel's final threshold: no survivor is lost, and a record within 0.012 % above the threshold is
+// kept needlessly and goes through the literal chain with the others.  Four bytes instead of eight: half the scratch
+// and half the bytes a record moves.
+typedef uint32_t Rec;
+__device__ __forceinline__ Rec rec_make(float s, uint32_t cand) { return ((__builtin_bit_cast(uint32_t, s) >> 10) << 11) | cand; }
+__device__ __forceinline__ float rec_cost_low(Rec r) { return __builtin_bit_cast(float, (r >> 11) << 10); }
+__device__ __forceinline__ uint32_t rec_cand(Rec r) { return r & 0x7FFu; }
+static_assert(kCand < 2048, "a rank fits eleven bits");
+
 typedef const __attribute__((address_space(3))) uint32_t *lds_ro_u32_ptr;
 typedef const __attribute__((address_space(3))) float *lds_ro_f32_ptr;
 
@@ -398,7 +409,7 @@ static_assert(LFG_DYN_PARTS == 4 || LFG_DYN_PARTS == 8, "four parts per queue en
 // `unit` indexes the plan's unit table, or -- fromQueue -- the queue of segments handed over at run time.
 __device__ __forceinline__ void prefilter_unit(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
-    int W, int H, uint2 *__restrict__ list, float *__restrict__ uminOut,
+    int W, int H, Rec *__restrict__ list, float *__restrict__ uminOut,
     uint32_t *__restrict__ countOut, uint32_t *__restrict__ tileFlags, int flagTilesX,
     const uint32_t *__restrict__ order32, const PrefilterPlan &sp,
     int8_t *__restrict__ mv, int mvPitch, const uint32_t *__restrict__ rank2scan, uint32_t *__restrict__ segDone,
@@ -597,11 +608,11 @@ __device__ __forceinline__ void prefilter_unit(
     // (auxiliary blocks: a tile's 64 rows for the units of the plan, a segment's 16 rows for queued units)
     const int auxUnit = whole ? 0 : (fromQueue ? 4 * unit + wave : (int)sp.unitAux[unit] + chunk);
     const int auxRows = fromQueue ? kSeg : kPTH, auxRow0 = fromQueue ? kSeg * seg : 0;
-    uint2 *const auxListBase = fromQueue ? sp.dynList : sp.auxList;
+    Rec *const auxListBase = fromQueue ? sp.dynList : sp.auxList;
     float *const auxUminBase = fromQueue ? sp.dynUmin : sp.auxUmin;
     uint32_t *const auxCountBase = fromQueue ? sp.dynCount : sp.auxCount;
     const uint32_t rowStride = whole ? (uint32_t)W : (uint32_t)kPTW;
-    uint2 *const waveList = whole
+    Rec *const waveList = whole
         ? list + ((size_t)(ty0 + kSeg * seg) * (size_t)kListK * (size_t)W + (size_t)tx0)
         : auxListBase + ((size_t)auxUnit * auxRows + (size_t)(kSeg * seg - auxRow0)) * (size_t)kListK * (size_t)kPTW;
     uint32_t laneOff[2];
@@ -690,7 +701,7 @@ __device__ __forceinline__ void prefilter_unit(
                         // past the end of the list the last slot is overwritten; the count keeps growing and
                         // flags the tile
                         const uint32_t at = __umul24(min(n, (uint32_t)kListK - 1u), rowStride) + laneOff[hb] + (uint32_t)i;
-                        waveList[at] = uint2{__builtin_bit_cast(uint32_t, s), cand};
+                        waveList[at] = rec_make(s, cand);
                         uint32_t inc = (s != 0.0f && countIt != 0u) ? (1u << (16 * (i & 1))) : 0u;
                         if (windowLeavesPrev) {                        // wave-uniform: tiles away from the rim skip this
                             // one member per plateau (block_leaves_prev): a second one is written but not counted
@@ -1024,31 +1035,37 @@ __device__ __forceinline__ void prefilter_unit(
         if (!segUnit) return;              // (the waves of a segment unit meet at a barrier below)
     }
     if (outcome == 2) return;              // handed over (whole tiles only: no barrier below for them)
+    // Threshold and count of every pixel, for the resolve kernel -- which never looks at a segment that settles all of
+    // its pixels below, so such a segment (most of a frame under a pan) does not write them at all.
+    auto writeThresholds = [&]() {
 #pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-        const int py = ty0 + kSeg * seg + 8 * hb + r8;
+        for (int hb = 0; hb < 2; ++hb) {
+            const int py = ty0 + kSeg * seg + 8 * hb + r8;
 #pragma unroll
-        for (int i = 0; i < kRun; ++i) {
-            if (!gaveUp && py < H && px0 + i < W) {
-                const uint32_t cnt = (cnt2[hb][i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
-                if (whole) {
-                    const size_t gp = (size_t)py * (size_t)W + (size_t)(px0 + i);
-                    uminOut[gp] = hb ? thr2[i].y : thr2[i].x;
-                    countOut[gp] = cnt;
-                } else {
-                    const size_t ap = ((size_t)auxUnit * auxRows + (size_t)(py - ty0 - auxRow0)) * kPTW + (size_t)(px0 + i - tx0);
-                    auxUminBase[ap] = hb ? thr2[i].y : thr2[i].x;
-                    auxCountBase[ap] = cnt;
+            for (int i = 0; i < kRun; ++i) {
+                if (!gaveUp && py < H && px0 + i < W) {
+                    const uint32_t cnt = (cnt2[hb][i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+                    if (whole) {
+                        const size_t gp = (size_t)py * (size_t)W + (size_t)(px0 + i);
+                        uminOut[gp] = hb ? thr2[i].y : thr2[i].x;
+                        countOut[gp] = cnt;
+                    } else {
+                        const size_t ap = ((size_t)auxUnit * auxRows + (size_t)(py - ty0 - auxRow0)) * kPTW + (size_t)(px0 + i - tx0);
+                        auxUminBase[ap] = hb ? thr2[i].y : thr2[i].x;
+                        auxCountBase[ap] = cnt;
+                    }
                 }
             }
         }
-    }
+    };
+    const bool settlesHere = whole && !windowLeavesPrev;
+    if (!settlesHere) writeThresholds();
     // Whole tiles away from the rim settle their easy pixels here and now, while threshold and count are still in
     // registers: a zero-cost candidate (encoded in the threshold), a single record, or two records of which one
     // survives ARE the answer (motion_resolve_kernel's rules; no plateaus where the window stays inside prev).
     // A segment whose pixels were all settled says so, and the resolve kernel skips the blocks it covers.
     if (whole && !windowLeavesPrev) {
-        uint2 ra[2][kRun], rb[2][kRun];
+        Rec ra[2][kRun], rb[2][kRun];
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
 #pragma unroll
@@ -1068,11 +1085,11 @@ __device__ __forceinline__ void prefilter_unit(
                 const float bound = hb ? fy : fx;
                 const uint32_t cnt = (cnt2[hb][i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
                 const bool inImage = py < H && px0 + i < W;
-                const bool sa = __builtin_bit_cast(float, ra[hb][i].x) <= bound, sb = __builtin_bit_cast(float, rb[hb][i].x) <= bound;
+                const bool sa = rec_cost_low(ra[hb][i]) <= bound, sb = rec_cost_low(rb[hb][i]) <= bound;
                 uint32_t b = 0xFFFFFFFFu;
                 if (bound < 0.5f) b = __builtin_bit_cast(uint32_t, bound) - 0x00800000u;
-                else if (cnt == 1u) b = ra[hb][i].y;
-                else if (cnt == 2u && sa != sb) b = sa ? ra[hb][i].y : rb[hb][i].y;
+                else if (cnt == 1u) b = rec_cand(ra[hb][i]);
+                else if (cnt == 2u && sa != sb) b = sa ? rec_cand(ra[hb][i]) : rec_cand(rb[hb][i]);
                 best[hb][i] = inImage ? b : 0xFFFFFFFFu;
                 allSettled = allSettled && (!inImage || b != 0xFFFFFFFFu);
             }
@@ -1091,7 +1108,11 @@ __device__ __forceinline__ void prefilter_unit(
                 }
             }
         }
-        if (__builtin_amdgcn_readfirstlane(__ballot(!allSettled) == 0ull) && lane == 0) segDone[tile * (kPTH / kSeg) + seg] = 1u;
+        if (__builtin_amdgcn_readfirstlane(__ballot(!allSettled) == 0ull)) {
+            if (lane == 0) segDone[tile * (kPTH / kSeg) + seg] = 1u;
+        } else {
+            writeThresholds();
+        }
     }
     // A segment unit does the same for its segment, its four waves pooling what each learnt about its part of the
     // candidate order: the tightest threshold of the four is the pixel's bound, every wave holds its own records
@@ -1106,7 +1127,7 @@ __device__ __forceinline__ void prefilter_unit(
         static_assert(8 * kPix + 1 <= kWinH * kWinW, "exchange area fits the window");
         __syncthreads();
         if (*(volatile uint32_t *)&sGiveUp != 0u) return;              // the tile goes through the exact kernel
-        uint2 ra[2][kRun], rb[2][kRun];
+        Rec ra[2][kRun], rb[2][kRun];
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
 #pragma unroll
@@ -1127,12 +1148,12 @@ __device__ __forceinline__ void prefilter_unit(
                 const float bound = __builtin_fminf(__builtin_fminf(sBound[at], sBound[kPix + at]),
                                                     __builtin_fminf(sBound[2 * kPix + at], sBound[3 * kPix + at]));
                 const uint32_t cnt = (cnt2[hb][i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
-                const bool sa = cnt >= 1u && __builtin_bit_cast(float, ra[hb][i].x) <= bound;
-                const bool sb = cnt >= 2u && __builtin_bit_cast(float, rb[hb][i].x) <= bound;
+                const bool sa = cnt >= 1u && rec_cost_low(ra[hb][i]) <= bound;
+                const bool sb = cnt >= 2u && rec_cost_low(rb[hb][i]) <= bound;
                 uint32_t word = 0u;
                 if (cnt > 2u || (sa && sb)) word = 0xFFFFFFFFu;
-                else if (sa) word = 0x80000000u | ra[hb][i].y;
-                else if (sb) word = 0x80000000u | rb[hb][i].y;
+                else if (sa) word = 0x80000000u | rec_cand(ra[hb][i]);
+                else if (sb) word = 0x80000000u | rec_cand(rb[hb][i]);
                 sMine[wave * kPix + at] = word;
             }
         }
@@ -1212,7 +1233,7 @@ __device__ __forceinline__ uint32_t peek_hard(uint32_t *p) { return atomicCAS(p,
 
 __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
-    int W, int H, uint2 *__restrict__ list, float *__restrict__ uminOut,
+    int W, int H, Rec *__restrict__ list, float *__restrict__ uminOut,
     uint32_t *__restrict__ countOut, uint32_t *__restrict__ tileFlags, int flagTilesX,
     const uint32_t *__restrict__ order32, PrefilterPlan sp,
     int8_t *__restrict__ mv, int mvPitch, const uint32_t *__restrict__ rank2scan, uint32_t *__restrict__ segDone,
@@ -1317,7 +1338,7 @@ __device__ float exact_cost(const uint8_t *__restrict__ prev, int prevPitch, con
 #endif
 __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
-    int8_t *__restrict__ mv, int mvPitch, int W, int H, const uint2 *__restrict__ list,
+    int8_t *__restrict__ mv, int mvPitch, int W, int H, const Rec *__restrict__ list,
     const float *__restrict__ uminIn, const uint32_t *__restrict__ countIn, const uint32_t *__restrict__ tileFlags,
     int tilesX, PrefilterPlan sp, const uint32_t *__restrict__ rank2scan, const uint32_t *__restrict__ segDone,
     unsigned long long *__restrict__ mergeWords) {
@@ -1347,21 +1368,24 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
     const size_t pix = (size_t)cpy * (size_t)W + (size_t)cpx;
     const float thr0 = uminIn[pix];
     const uint32_t cnt0 = countIn[pix];
-    const uint2 rec0 = list[(size_t)cpy * (size_t)kListK * (size_t)W + (size_t)cpx];
+    const Rec rec0 = list[(size_t)cpy * (size_t)kListK * (size_t)W + (size_t)cpx];
     const uint32_t flagged = tileFlags[(cpy / kTH) * tilesX + cpx / kTW];
     const int ptile = (cpy / kPTH) * sp.tilesX + cpx / kPTW;
     const uint32_t tm = sp.tileMap[ptile];
     const uint32_t sm = sp.segMap[ptile * (kPTH / kSeg) + (cpy % kPTH) / kSeg];      // segment handed over at run time?
-    const bool live = inside && flagged == 0u;
+    // A pixel of a segment the prefilter settled is final (and has no threshold or count: settled segments do not
+    // write them); this block got here because the other tile it touches has work left.
+    const bool settledSeg = segDone[ptile * (kPTH / kSeg) + (cpy % kPTH) / kSeg] != 0u;
+    const bool live = inside && flagged == 0u && !settledSeg;
     // A flagged tile goes through the exact kernel in parts that meet in record 0 of the pixel's list (atomicMin).
-    if (inside && flagged != 0u) mergeWords[(size_t)cpy * (size_t)kListK * (size_t)W + (size_t)cpx] = ~0ull;
+    if (inside && flagged != 0u) mergeWords[(size_t)cpy * ((size_t)kListK * (size_t)W / 2u) + (size_t)cpx] = ~0ull;   // (8 bytes per pixel: planes 0 and 1 of the row)
     // Where this pixel's records live: one list in the image-shaped arrays, or several lists (one per unit that
     // shared the tile's candidates) in the auxiliary arrays -- blocks of a tile's 64 rows for the units of the plan,
     // of a segment's 16 rows for a segment handed over at run time.  Record k of list c: recs[c * listStride + k * recStride].
     const bool handedOver = tm == 0xFFFFFFFFu && sm != 0u;
     const bool whole = tm == 0xFFFFFFFFu && sm == 0u;
     const int nLists = whole ? 1 : (int)(((handedOver ? sm : tm) >> 24) & 0xFu);
-    const uint2 *recs;
+    const Rec *recs;
     const float *thrs;
     const uint32_t *cnts;
     uint32_t listStride, recStride, thrStride;
@@ -1410,7 +1434,7 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
         constexpr int kMaxLists = 8;
         float thrL[kMaxLists];
         uint32_t cntL[kMaxLists];
-        uint2 recL[kMaxLists];
+        Rec recL[kMaxLists];
         // (branch-free: a list that does not exist reads list 0 and is masked afterwards -- per-list branches made
         //  every list a memory latency of its own)
 #pragma unroll
@@ -1433,9 +1457,9 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
             bestC = __builtin_bit_cast(uint32_t, bound) - 0x00800000u;
         } else {
             // A single survivor IS the shader's answer (the exact minimiser always survives): no evaluation.
-            auto count = [&](const uint2 rec, bool valid) {
-                if (valid && __builtin_bit_cast(float, rec.x) <= bound) {
-                    if (survivors == 0u) bestC = rec.y;
+            auto count = [&](const Rec rec, bool valid) {
+                if (valid && rec_cost_low(rec) <= bound) {
+                    if (survivors == 0u) bestC = rec_cand(rec);
                     ++survivors;
                 }
             };
@@ -1453,7 +1477,7 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
             for (int c0 = 0; c0 < kMaxLists; c0 += 4) {
                 const uint32_t nMax = max(max(nL[c0], nL[c0 + 1]), max(nL[c0 + 2], nL[c0 + 3]));
                 for (uint32_t k0 = 1; k0 < nMax; k0 += 4u) {
-                    uint2 r[4][4];
+                    Rec r[4][4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
 #pragma unroll
@@ -1489,7 +1513,7 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
         const float qBound = __shfl(bound, L);
         const int qLists = __shfl(nLists, L);
         const uint32_t qListStride = __shfl(listStride, L), qRecStride = __shfl(recStride, L), qThrStride = __shfl(thrStride, L);
-        const uint2 *qRecs = reinterpret_cast<const uint2 *>(
+        const Rec *qRecs = reinterpret_cast<const Rec *>(
             ((unsigned long long)__shfl((uint32_t)((unsigned long long)recs >> 32), L) << 32) |
             (unsigned long long)__shfl((uint32_t)(unsigned long long)recs, L));
         const uint32_t *qCnts = reinterpret_cast<const uint32_t *>(
@@ -1506,9 +1530,9 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
         for (int c = 0; c < qLists; ++c) {
             const uint32_t n = min(qCnts[(size_t)c * qThrStride], (uint32_t)kListK);
             for (uint32_t k = 0; k < n; ++k) {
-                const uint2 rec = qRecs[(size_t)c * qListStride + (size_t)k * qRecStride];    // same address in every lane
-                if (!(__builtin_bit_cast(float, rec.x) <= qBound)) continue;
-                const int cscan = (int)rank2scan[rec.y];
+                const Rec rec = qRecs[(size_t)c * qListStride + (size_t)k * qRecStride];    // same address in every lane
+                if (!(rec_cost_low(rec) <= qBound)) continue;
+                const int cscan = (int)rank2scan[rec_cand(rec)];
                 const int dy = cscan / kSide - kR, dx = cscan % kSide - kR;
                 const int sx = cx + dx, sy = cy + dy;
                 uint32_t ptex = 0u;
@@ -1523,7 +1547,7 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
 #pragma unroll
                 for (int i = 0; i < kB * kB; ++i) v += sDist[wv][i];
                 wave_lds_sync();
-                const uint32_t r = firstOfPlateau(qx, qy, rec.y);
+                const uint32_t r = firstOfPlateau(qx, qy, rec_cand(rec));
                 if (v < bestV || (v == bestV && r < bestR)) { bestV = v; bestR = r; }
             }
         }
@@ -1608,7 +1632,7 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, Motion
     auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
     MotionWorkspaceLayout l;
     l.list = 0;
-    l.umin = align(l.list + px * kListK * sizeof(uint2));
+    l.umin = align(l.list + px * kListK * sizeof(Rec));
     l.count = align(l.umin + px * sizeof(float));
     l.tileFlags = align(l.count + px * sizeof(uint32_t));
     // one word per 16-row segment of a prefilter tile, right behind the flags: one memset clears both
@@ -1620,10 +1644,10 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, Motion
     // (+ the number of flagged tiles and the list of the first kShareBelow of them, + the prefilter's three unit counters)
     l.ctrl = l.queueCount + (2 + kShareBelow) * sizeof(uint32_t);
     // ... and the queue of segments handed over at run time (entries double as "slot filled" signals): up to a quarter
-    // of the frame's segments, 2048 at most (a multiple of the entries one segment takes, so that a push either fits as
+    // of the frame's segments, 1024 entries at most (a multiple of the entries one segment takes, so that a push either fits as
     // a whole or is refused as a whole; beyond that a segment is searched by the wave that owns it, as before).  One
     // memset clears everything from the tile flags to here.
-    l.queueCap = (int)std::min<size_t>(2048, std::max<size_t>(LFG_DYN_PARTS / 4, ptiles * (kPTH / kSeg) / 4 / (LFG_DYN_PARTS / 4) * (LFG_DYN_PARTS / 4)));
+    l.queueCap = (int)std::min<size_t>(1024, std::max<size_t>(LFG_DYN_PARTS / 4, ptiles * (kPTH / kSeg) / 4 / (LFG_DYN_PARTS / 4) * (LFG_DYN_PARTS / 4)));
     l.queue = l.ctrl + 4 * sizeof(uint32_t);
     l.order = align(l.queue + (size_t)l.queueCap * sizeof(uint32_t));           // this call's hints and visiting order
     // work-unit tables and the auxiliary arrays of the shared tiles (see prefilter_plan): one 56 x 64 block per unit
@@ -1631,13 +1655,13 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, Motion
     const size_t auxUnits = (size_t)plan.auxUnits;
     l.plan = align(l.order + (kHints + kCand + 3) * sizeof(uint32_t));
     l.auxList = align(l.plan + (size_t)(2 * plan.units + plan.tiles) * sizeof(uint32_t));
-    l.auxUmin = align(l.auxList + auxUnits * kPTH * kPTW * kListK * sizeof(uint2));
+    l.auxUmin = align(l.auxList + auxUnits * kPTH * kPTW * kListK * sizeof(Rec));
     l.auxCount = align(l.auxUmin + auxUnits * kPTH * kPTW * sizeof(float));
     // each queue entry owns four 16-row blocks of private lists (0.92 MB)
     const size_t dynBlocks = (size_t)l.queueCap * 4;
     l.dynList = align(l.auxCount + auxUnits * kPTH * kPTW * sizeof(uint32_t));
     l.slots = slots;
-    l.dynUmin = align(l.dynList + dynBlocks * kSeg * kPTW * kListK * sizeof(uint2));
+    l.dynUmin = align(l.dynList + dynBlocks * kSeg * kPTW * kListK * sizeof(Rec));
     l.dynCount = align(l.dynUmin + dynBlocks * kSeg * kPTW * sizeof(float));
     l.total = align(l.dynCount + dynBlocks * kSeg * kPTW * sizeof(uint32_t));
     if (layout) *layout = l;
@@ -1891,7 +1915,7 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
                                           const uint32_t *rank2scan, const uint32_t *order,
                                           const uint32_t *entryOfScan, const uint32_t *baseScan, bool useHints) {
     const int tilesX = ((int)curr.width + kTW - 1) / kTW;
-    uint2 *list = reinterpret_cast<uint2 *>(workspace + l.list);
+    Rec *list = reinterpret_cast<Rec *>(workspace + l.list);
     float *umin = reinterpret_cast<float *>(workspace + l.umin);
     uint32_t *count = reinterpret_cast<uint32_t *>(workspace + l.count);
     uint32_t *flags = reinterpret_cast<uint32_t *>(workspace + l.tileFlags);
@@ -1902,14 +1926,14 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
     sp.unitMap = reinterpret_cast<const uint32_t *>(workspace + l.plan);
     sp.unitAux = sp.unitMap + units;
     sp.tileMap = sp.unitAux + units;
-    sp.auxList = reinterpret_cast<uint2 *>(workspace + l.auxList);
+    sp.auxList = reinterpret_cast<uint32_t *>(workspace + l.auxList);
     sp.auxUmin = reinterpret_cast<float *>(workspace + l.auxUmin);
     sp.auxCount = reinterpret_cast<uint32_t *>(workspace + l.auxCount);
     sp.segMap = reinterpret_cast<uint32_t *>(workspace + l.segMap);
     sp.queueCount = reinterpret_cast<uint32_t *>(workspace + l.queueCount);
     sp.queue = reinterpret_cast<uint32_t *>(workspace + l.queue);
     sp.queueCap = l.queueCap;
-    sp.dynList = reinterpret_cast<uint2 *>(workspace + l.dynList);
+    sp.dynList = reinterpret_cast<uint32_t *>(workspace + l.dynList);
     sp.dynUmin = reinterpret_cast<float *>(workspace + l.dynUmin);
     sp.dynCount = reinterpret_cast<uint32_t *>(workspace + l.dynCount);
     uint32_t *segDone = reinterpret_cast<uint32_t *>(workspace + l.segDone);
@@ -1974,7 +1998,7 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
     if (e != hipSuccess) return e;
     // (the flagged tiles' parts merge in record 0 of their pixels' lists, which nothing reads any more)
     return launch_motion_tiled_8_16(s, prev, curr, mv, flags, rank2scan, reinterpret_cast<unsigned long long *>(list),
-                                    (size_t)kListK * (size_t)curr.width, sp.queueCount + 1);
+                                    (size_t)kListK * (size_t)curr.width / 2u, sp.queueCount + 1);
 }
 
 // Diagnostic: compares exact_sqrt with __builtin_sqrtf for every float whose bit pattern lies in
