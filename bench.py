@@ -312,7 +312,6 @@ def main():
     t_mv, f_mv = empty_frame(w, h, capi.FORMAT_MV_S8X2)
     if args.workload == "pipeline_input_res":
         t_mv_in, f_mv_in = empty_frame(w_in, h_in, capi.FORMAT_MV_S8X2)
-        t_mid_in, f_mid_in = empty_frame(w_in, h_in)
     # The previous frame.  One GPU: upscaled once, before the timed region (in a stream it is the last step's current
     # frame).  Several GPUs: the batch shares its previous frame, which travels as the 8.3 MB INPUT frame -- one
     # broadcast per step, double-buffered -- and every rank upscales it (13 us) rather than 33 MB of upscaled frame
@@ -344,9 +343,8 @@ def main():
         if args.workload == "pipeline_input_res":
             ctx.motion(f_prev_step, f_curr_in, f_mv_in, 8, 16.0)
             ctx.scale(f_curr_in, f_curr4)
-            for t, fo in zip(factors, f_outs):
-                ctx.interpolate(f_prev_step, f_curr_in, f_mv_in, f_mid_in, t)
-                ctx.scale(f_mid_in, fo)
+            for t, fo in zip(factors, f_outs):      # one kernel: interpolated row by row inside the 2x scale kernel
+                ctx.interpolate_scale(f_prev_step, f_curr_in, f_mv_in, fo, t)
             return
         ctx.scale(f_curr_in, f_curr4)
         if args.workload == "pipeline":

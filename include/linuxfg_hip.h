@@ -217,6 +217,22 @@ int  lfg_interpolate_multi(lfg_context *ctx, const lfg_frame *prev, const lfg_fr
 int  lfg_interpolate_frames_multi(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *curr,
                                   lfg_frame *const *outs, const float *factors, uint32_t count);
 
+/* The reference's own data flow keeps prev / curr at INPUT resolution (src/scaler.cpp:443,451): there the generated
+ * frame is interpolated at input resolution and then upscaled like a captured one.  This does both in one call --
+ * identical, byte for byte, to lfg_interpolate into a temporary followed by lfg_scale of that temporary -- and where
+ * `out` is exactly twice the size of the inputs optionally in ONE kernel (lfg_set_fused_interpolate_scale): each input
+ * row of the 2x scale kernel is then interpolated on the fly (shaders/interpolate.comp:15-40 arithmetic, rounded to
+ * bytes as the stage would store it), so the generated frame never exists at input resolution in memory (SURVEY.md
+ * 8(f) rank 1).  prev, curr, mv: same size; out: any size. */
+int  lfg_interpolate_scale(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *curr, const lfg_frame *mv,
+                           lfg_frame *out, float factor);
+/* Which of the two lfg_interpolate_scale uses at exactly 2x.  Default 0: the two stages through a context-owned frame
+ * -- measured FASTER on MI355X at 1080p -> 4K (interpolate 5 us + scale 13 us against 33 us for the fused kernel: the
+ * 16 MB the intermediate frame moves cost less than re-interpolating the five warm-up rows of every strip inside a
+ * kernel that is bound by instruction issue, not by memory).  1: the fused kernel.  Results
+ * are identical.  Also set by LFG_FUSED_INTERPOLATE_SCALE=1 in the environment at context creation. */
+int  lfg_set_fused_interpolate_scale(lfg_context *ctx, int enabled);
+
 /* Write the motion vectors as the reference's rgba32f image: vec4(mv.x, mv.y, 0, 1) per pixel
  * (shaders/motion.comp:56) into `device_rgba32f` (width*height*16 bytes, device memory). */
 int  lfg_mv_export_rgba32f(lfg_context *ctx, const lfg_frame *mv, void *device_rgba32f);

@@ -73,6 +73,8 @@ SIGNATURES = {
     "lfg_interpolate_frames": (_i, [_vp, _FP, _FP, _FP, ctypes.c_float]),
     "lfg_interpolate_multi": (_i, [_vp, _FP, _FP, _FP, ctypes.POINTER(_FP), ctypes.POINTER(ctypes.c_float), _u32]),
     "lfg_interpolate_frames_multi": (_i, [_vp, _FP, _FP, ctypes.POINTER(_FP), ctypes.POINTER(ctypes.c_float), _u32]),
+    "lfg_interpolate_scale": (_i, [_vp, _FP, _FP, _FP, _FP, ctypes.c_float]),
+    "lfg_set_fused_interpolate_scale": (_i, [_vp, _i]),
     "lfg_mv_export_rgba32f": (_i, [_vp, _FP, _vp]),
     "lfg_selftest_sqrt": (_i, [_vp, _u32, _u32, ctypes.POINTER(ctypes.c_uint64)]),
     "lfg_comm_unique_id": (_i, [_vp]),
@@ -268,6 +270,14 @@ class Context:
         po, pf, n = self._multi_args(outs, factors)
         self._check(self.lib.lfg_interpolate_frames_multi(self.h, ctypes.byref(prev), ctypes.byref(curr), po, pf, n),
                     "lfg_interpolate_frames_multi")
+
+    def set_fused_interpolate_scale(self, on: bool):
+        self._check(self.lib.lfg_set_fused_interpolate_scale(self.h, int(on)), "lfg_set_fused_interpolate_scale")
+
+    def interpolate_scale(self, prev: Frame, curr: Frame, mv: Frame, out: Frame, factor: float = 0.5):
+        """interpolate at input resolution and upscale, one call (one kernel when out is exactly 2x the inputs)."""
+        self._check(self.lib.lfg_interpolate_scale(self.h, ctypes.byref(prev), ctypes.byref(curr), ctypes.byref(mv),
+                                                   ctypes.byref(out), factor), "lfg_interpolate_scale")
 
     def selftest_sqrt(self, lo_bits: int, hi_bits: int) -> int:
         n = ctypes.c_uint64()

@@ -54,7 +54,9 @@ def check(disasm_lines, name):
             continue
         window = BUFFER_WINDOW if ins.startswith("buffer") else OTHER_WINDOW
         for later in insts[i + 1:i + 1 + window]:
-            if later.startswith(("v_", "ds_read", "buffer_load", "global_load")) and not later.startswith("v_cmp"):
+            # (VALU writers only: data an LDS or memory read returns arrives long after any store has read its operands,
+            #  and the compiler waits for the counters where registers are reused)
+            if later.startswith("v_") and not later.startswith("v_cmp"):
                 dst = later.split(None, 1)[1].split(",")[0].strip()
                 if reg_range(dst) & data:
                     bad.append((name, ins, later))

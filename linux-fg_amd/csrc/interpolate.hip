@@ -15,53 +15,9 @@
 // One thread produces four horizontally adjacent pixels: one 8-byte MV load, one 16-byte store.
 #include "lfg_device.hpp"
 #include "lfg_internal.hpp"
+#include "lfg_interp.hpp"
 
 namespace lfg {
-
-struct V4 { float x, y, z, w; };
-
-__device__ __forceinline__ V4 texel_unorm(const uint8_t *__restrict__ img, int pitch, int x, int y) {
-    const uint32_t p = *reinterpret_cast<const uint32_t *>(img + (size_t)y * (size_t)pitch + (size_t)x * 4u);
-    return V4{unorm8_to_float(byte0(p)), unorm8_to_float(byte1(p)),
-              unorm8_to_float(byte2(p)), unorm8_to_float(byte3(p))};
-}
-
-// texture() on a LINEAR / CLAMP_TO_EDGE sampler with normalised coordinates
-// (src/frame_manager.cpp:555-561), oracle choice (3).
-__device__ __forceinline__ V4 texture_bilinear(const uint8_t *__restrict__ img, int W, int H, int pitch,
-                                               float s, float t) {
-    const float u = s * (float)W - 0.5f;
-    const float v = t * (float)H - 0.5f;
-    const float fu = __builtin_floorf(u), fv = __builtin_floorf(v);
-    const float a = u - fu, b = v - fv;
-    int i0 = (int)fu, j0 = (int)fv;
-    int i1 = i0 + 1, j1 = j0 + 1;
-    i0 = clampi(i0, 0, W - 1); i1 = clampi(i1, 0, W - 1);
-    j0 = clampi(j0, 0, H - 1); j1 = clampi(j1, 0, H - 1);
-    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b);
-    const float w01 = (1.0f - a) * b, w11 = a * b;
-    const V4 t00 = texel_unorm(img, pitch, i0, j0);
-    if (a == 0.0f && b == 0.0f) return t00;     // w00 == 1, the other three products are exactly 0
-    const V4 t10 = texel_unorm(img, pitch, i1, j0);
-    const V4 t01 = texel_unorm(img, pitch, i0, j1);
-    const V4 t11 = texel_unorm(img, pitch, i1, j1);
-    V4 r;
-    r.x = ((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x;
-    r.y = ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y;
-    r.z = ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z;
-    r.w = ((w00 * t00.w + w10 * t10.w) + w01 * t01.w) + w11 * t11.w;
-    return r;
-}
-
-// interpolate.comp:15-22
-__device__ __forceinline__ V4 sample_with_motion(const uint8_t *__restrict__ img, int W, int H, int pitch,
-                                                 float uvx, float uvy, float mx, float my, float scale) {
-    const float sx = uvx + mx * scale, sy = uvy + my * scale;
-    if (sx < 0.0f || sy < 0.0f || sx > 1.0f || sy > 1.0f) return V4{0.f, 0.f, 0.f, 0.f};
-    return texture_bilinear(img, W, H, pitch, sx, sy);
-}
-
-__device__ __forceinline__ float mixf(float x, float y, float a) { return x * (1.0f - a) + y * a; }
 
 // INTENDED = false: interpolate.comp as written.  INTENDED = true (opt-in, lfg_set_semantics):
 // the motion vector is divided by the image size before it is added to uv, so it displaces by pixels.

@@ -264,6 +264,7 @@ LFG_EXPORT int lfg_context_create(int device_ordinal, lfg_context **out_ctx) {
     ctx->stream = ctx->own_stream;
     ctx->tables.reserve(17);                 // AxisTable pointers handed out stay valid
     if (const char *m = getenv("LFG_MOTION_HINTS")) ctx->motion_hints = atoi(m) != 0;
+    if (const char *m = getenv("LFG_FUSED_INTERPOLATE_SCALE")) ctx->fuse_interpolate_scale = atoi(m) != 0;
     if (const char *m = getenv("LFG_MOTION_MODE")) ctx->motion_mode = atoi(m) == 1 ? LFG_MOTION_EXACT_ONLY : LFG_MOTION_PREFILTERED;
     *out_ctx = ctx;
     return LFG_OK;
@@ -279,6 +280,7 @@ LFG_EXPORT void lfg_context_destroy(lfg_context *ctx) {
     for (auto &p : ctx->prof_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto &t : ctx->tables) { (void)hipFree(t.d_start); (void)hipFree(t.d_weight); (void)hipFree(t.d_class); (void)hipFree(t.d_palette); }
     if (ctx->mv_tmp.data && ctx->mv_tmp.owned) (void)hipFree(ctx->mv_tmp.data);
+    if (ctx->mid_tmp.data && ctx->mid_tmp.owned) (void)hipFree(ctx->mid_tmp.data);
     if (ctx->motion_tables) (void)hipFree(ctx->motion_tables);
     if (ctx->motion_ws) (void)hipFree(ctx->motion_ws);
     (void)hipStreamDestroy(ctx->own_stream);
@@ -666,6 +668,53 @@ LFG_EXPORT int lfg_interpolate_frames_multi(lfg_context *ctx, const lfg_frame *p
     int rc = lfg_motion(ctx, prev, curr, &mv, 8, 16.0f);                      // frame_manager.cpp:332-333
     if (rc != LFG_OK) return rc;
     return lfg_interpolate_multi(ctx, prev, curr, &mv, outs, factors, count);
+}
+
+LFG_EXPORT int lfg_set_fused_interpolate_scale(lfg_context *ctx, int enabled) {
+    if (!ctx) return LFG_ERR_INVALID;
+    ctx->fuse_interpolate_scale = enabled != 0;
+    return LFG_OK;
+}
+
+LFG_EXPORT int lfg_interpolate_scale(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *curr, const lfg_frame *mv,
+                                     lfg_frame *out, float factor) {
+    if (!ctx) return LFG_ERR_INVALID;
+    LFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (!frame_ok(prev, LFG_FORMAT_RGBA8_UNORM) || !frame_ok(curr, LFG_FORMAT_RGBA8_UNORM) ||
+        !frame_ok(mv, LFG_FORMAT_MV_S8X2) || !frame_ok(out, LFG_FORMAT_RGBA8_UNORM))
+        return fail(ctx, LFG_ERR_INVALID, "lfg_interpolate_scale: bad frame (NULL, empty or wrong format)");
+    if (!same_size(prev, curr) || !same_size(curr, mv))
+        return fail(ctx, LFG_ERR_INVALID, "lfg_interpolate_scale: prev, curr and mv differ in size");
+    if ((prev->pitch | curr->pitch) % 4u || mv->pitch % 2u)
+        return fail(ctx, LFG_ERR_INVALID, "lfg_interpolate_scale: row pitch not a multiple of the pixel size");
+    if (out->data == prev->data || out->data == curr->data)
+        return fail(ctx, LFG_ERR_INVALID, "lfg_interpolate_scale: output aliases an input");
+    trim_axis_tables(ctx);
+    lfg::AxisTable *tx = nullptr, *ty = nullptr;
+    int rc = build_axis_table(ctx, (int)curr->width, (int)out->width, &tx);
+    if (rc != LFG_OK) return rc;
+    rc = build_axis_table(ctx, (int)curr->height, (int)out->height, &ty);
+    if (rc != LFG_OK) return rc;
+    const bool fused = ctx->fuse_interpolate_scale && tx->pattern_2x && ty->pattern_2x && tx->palette_rows > 0 && ty->strips_per_xcd > 0 && lfg::scale_2x_supported(*curr, *out) &&
+                       (uint64_t)prev->height * prev->pitch < 0x7fffffffull;
+    if (fused) {
+        // one kernel: the generated frame is interpolated row by row inside the 2x scale kernel and never stored at
+        // input resolution; accounted to the scale stage
+        StageTimer timer(ctx, LFG_STAGE_SCALE);
+        hipError_t e = lfg::launch_interpolate_scale_2x(ctx->stream, *prev, *curr, *mv, *out, *tx, *ty, factor, ctx->semantics != 0);
+        if (e != hipSuccess) return fail_hip(ctx, e, "fused interpolate + scale kernel launch");
+        return LFG_OK;
+    }
+    // any other size ratio: the two stages, through a context-owned frame at input resolution
+    lfg_frame &mid = ctx->mid_tmp;
+    if (!mid.data || mid.width != curr->width || mid.height != curr->height) {
+        lfg_frame_destroy(ctx, &mid);
+        rc = lfg_frame_create(ctx, curr->width, curr->height, LFG_FORMAT_RGBA8_UNORM, &mid);
+        if (rc != LFG_OK) return rc;
+    }
+    rc = lfg_interpolate(ctx, prev, curr, mv, &mid, factor);
+    if (rc != LFG_OK) return rc;
+    return lfg_scale(ctx, &mid, out);
 }
 
 LFG_EXPORT int lfg_mv_export_rgba32f(lfg_context *ctx, const lfg_frame *mv, void *device_rgba32f) {

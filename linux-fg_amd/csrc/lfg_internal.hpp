@@ -76,6 +76,7 @@ struct lfg_context {
     std::string error;
     std::vector<lfg::AxisTable> tables;       // small cache, linear search
     lfg_frame mv_tmp{};                        // temporary of lfg_interpolate_frames
+    lfg_frame mid_tmp{};                       // temporary of lfg_interpolate_scale where the fused kernel does not apply
     // prefiltered motion path: scratch for one frame size, grown on demand
     uint8_t *motion_ws = nullptr;
     size_t motion_ws_bytes = 0;
@@ -86,6 +87,7 @@ struct lfg_context {
     int motion_mode = 0;                       // 0: prefilter + exact fallback, 1: exact kernel only
     int semantics = 0;                         // 0: the shaders as written, 1: "intended" (lfg_set_semantics)
     uint32_t *motion_tables = nullptr;         // device: [semantics][rank2scan | order32 | entryOfScan], then baseScan
+    bool fuse_interpolate_scale = false;       // lfg_interpolate_scale: one fused kernel instead of the two stages (measured slower)
     bool motion_hints = true;                  // per-call visiting order from sample-block hints (LFG_MOTION_HINTS=0: off)
     // the one exchange of the path (lfg_comm.cpp): an RCCL communicator, its stream and two events
     void *comm = nullptr;                      // ncclComm_t
@@ -110,6 +112,8 @@ hipError_t launch_scale_generic(hipStream_t s, const lfg_frame &in, const lfg_fr
 hipError_t launch_scale_2x(hipStream_t s, const lfg_frame &in, const lfg_frame &out,
                            const AxisTable &tx, const AxisTable &ty);
 bool scale_2x_supported(const lfg_frame &in, const lfg_frame &out);
+hipError_t launch_interpolate_scale_2x(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv,
+                                       const lfg_frame &out, const AxisTable &tx, const AxisTable &ty, float factor, bool intended);
 int scale_2x_strips_per_xcd(int inH);
 void scale_2x_strip_host(int inH, int xcd, int index, int &first, int &steps);
 hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,

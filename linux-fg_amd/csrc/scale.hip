@@ -25,6 +25,7 @@
 
 #include "lfg_device.hpp"
 #include "lfg_internal.hpp"
+#include "lfg_interp.hpp"
 
 namespace lfg {
 
@@ -129,9 +130,6 @@ constexpr int kStoreAux = LFG_STORE_AUX;              // gfx940+ cache policy bi
 #ifndef LFG_SCALE_AHEAD
 #define LFG_SCALE_AHEAD 1                             // input rows requested beyond the six of the current step
 #endif
-#ifndef LFG_SCALE_PACKED_LOADS
-#define LFG_SCALE_PACKED_LOADS 0                      // 1: 8-byte row loads + v_cvt unpacking instead of format loads
-#endif
 #ifndef LFG_SCALE_WAVES
 #define LFG_SCALE_WAVES 3                             // waves per SIMD the register allocation aims at
 #endif
@@ -174,10 +172,21 @@ __host__ __device__ inline void scale_2x_strip_of(int inH, int x, int i, int str
 
 typedef f32x4 (*SlabPtr)[2][2][68];                    // [step parity][row A | row B][even | odd column][lane + 2]
 
+// Where a strip's input rows come from.  Plain: the input frame `in`.  Fused (the
+// input-resolution data flow): there is no input frame -- a row is interpolated on the fly from prev, curr and the
+// motion vectors (all at input resolution) with interpolate.comp's own arithmetic, rounded to bytes exactly as the
+// interpolate stage stores it, and upscaled at once: the generated frame never exists at input resolution in memory.
+struct FusedSource {
+    const uint8_t *prev; int prevPitch;
+    const uint8_t *curr; int currPitch;
+    const int8_t *mv; int mvPitch;
+    float t; int intended;
+};
+
 // One strip: STEPS unrolled steps of which the first n emit (n <= STEPS; the others' stores are switched off).
-template <int STEPS>
+template <int STEPS, bool FUSED>
 __device__ __forceinline__ void scale_2x_strip(
-    const uint8_t *__restrict__ in, int inW, int inH, int inPitch,
+    const FusedSource &fs, const uint8_t *__restrict__ in, int inW, int inH, int inPitch,
     uint8_t *__restrict__ out, int outW, int outH, int outPitch,
     const uint8_t *__restrict__ classX, const float *__restrict__ paletteX, const float *__restrict__ weightY,
     int rBegin, int n, int cg, int lane, SlabPtr slabW
@@ -205,49 +214,24 @@ __device__ __forceinline__ void scale_2x_strip(
     const int voff0 = (c0 >= 0 && c0 < inW) ? c0 * 4 : kOobOffset;
     const int voff1 = (c0 + 1 >= 0 && c0 + 1 < inW) ? (c0 + 1) * 4 : kOobOffset;
     const uint32_t cls = *reinterpret_cast<const uint32_t *>(classX + 2 * clampi(c0, 0, inW - 2));   // lanes outside the image never store
-#if LFG_SCALE_PACKED_LOADS
-    // One 8-byte load per lane and row (both columns, 512 contiguous bytes per wave) into a two-register staging
-    // slot; the row is unpacked (8 x v_cvt_f32_ubyte) when it enters the window.
-    const __amdgpu_buffer_rsrc_t rInRaw = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint8_t *>(in), 0, inH * inPitch, kRsrcRaw32);
-    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-    constexpr int W = 6;                                   // float rows of the window
-    constexpr int kStage = 1 + LFG_SCALE_AHEAD;            // packed rows in flight
-    u32x2 stage[kStage];
-    auto request_row = [&](int t) {                       // strip row t -> staging slot t % kStage
-        const int rowOff = clampi(rFirst + t, 0, inH - 1) * inPitch;
-        stage[t % kStage] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rInRaw, voff0, rowOff, 0));
-    };
-    F4 win[W][2];
-    auto admit_row = [&](int t) {                         // staging -> window slot t % W, as floats in 0..255
-        const u32x2 p = stage[t % kStage];
-        win[t % W][0] = F4{f32x2{byte0(p.x), byte1(p.x)}, f32x2{byte2(p.x), byte3(p.x)}};
-        win[t % W][1] = F4{f32x2{byte0(p.y), byte1(p.y)}, f32x2{byte2(p.y), byte3(p.y)}};
-    };
-    // the first six rows go straight into the window
-    {
-        u32x2 first[6];
-#pragma unroll
-        for (int t = 0; t < 6; ++t) {
-            const int rowOff = clampi(rFirst + t, 0, inH - 1) * inPitch;
-            first[t] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rInRaw, voff0, rowOff, 0));
-        }
-#pragma unroll
-        for (int t = 6; t < 6 + kStage && t < T; ++t) request_row(t);
-#pragma unroll
-        for (int t = 0; t < 6; ++t) {
-            win[t][0] = F4{f32x2{byte0(first[t].x), byte1(first[t].x)}, f32x2{byte2(first[t].x), byte3(first[t].x)}};
-            win[t][1] = F4{f32x2{byte0(first[t].y), byte1(first[t].y)}, f32x2{byte2(first[t].y), byte3(first[t].y)}};
-        }
-    }
-    // called once the vertical pass of step s has consumed row s: rows up to s+5 are in the window; admit row s+6 into
-    // the freed slot (it was requested kStage steps ago) and request row s+6+kStage.
-    auto advance = [&](int s) {
-        if (s + 6 < T) admit_row(s + 6);
-        if (s + 6 + kStage < T) request_row(s + 6 + kStage);
-    };
-#else
     auto load_row = [&](int r, F4 &a, F4 &b) {
+        if (FUSED) {
+            // the lane's two pixels of the interpolated row (rows clamped like the loads of the plain kernel; columns
+            // outside the image carry weight 0 everywhere: any finite value will do)
+            const int y = clampi(r, 0, inH - 1);
+            uint32_t px[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int x = clampi(c0 + c, 0, inW - 1);
+                const int8_t *m = fs.mv + (size_t)y * (size_t)fs.mvPitch + (size_t)x * 2u;
+                float mx = (float)m[0], my = (float)m[1];
+                if (fs.intended) { mx = mx / (float)inW; my = my / (float)inH; }
+                px[c] = interpolate_pixel(fs.prev, fs.prevPitch, fs.curr, fs.currPitch, inW, inH, x, y, mx, my, fs.t);
+            }
+            a = F4{f32x2{byte0(px[0]), byte1(px[0])}, f32x2{byte2(px[0]), byte3(px[0])}};
+            b = F4{f32x2{byte0(px[1]), byte1(px[1])}, f32x2{byte2(px[1]), byte3(px[1])}};
+            return;
+        }
         const int rowOff = clampi(r, 0, inH - 1) * inPitch;                 // wave-uniform
         a = to_f4(buffer_load_rgba8_format(rIn, voff0, rowOff));
         b = to_f4(buffer_load_rgba8_format(rIn, voff1, rowOff));
@@ -263,7 +247,6 @@ __device__ __forceinline__ void scale_2x_strip(
     auto advance = [&](int s) {
         if (s + W < T) load_row(rFirst + s + W, win[s % W][0], win[s % W][1]);
     };
-#endif
 
     // Horizontal weights of the lane's four output columns 2c0 .. 2c0+3: one class byte per column (a 4-byte load,
     // requested before anything else: its answer is the address of the next loads), then the class's row of the
@@ -403,8 +386,10 @@ __device__ __forceinline__ void scale_2x_strip(
 #endif
 }
 
-__global__ __launch_bounds__(256, LFG_SCALE_WAVES) void scale_2x_kernel(
-    const uint8_t *__restrict__ in, int inW, int inH, int inPitch,
+// (the fused variant carries interpolate.comp's sampling code next to the filter: two waves per SIMD instead of three)
+template <bool FUSED>
+__global__ __launch_bounds__(256, FUSED ? 2 : LFG_SCALE_WAVES) void scale_2x_kernel(
+    FusedSource fs, const uint8_t *__restrict__ in, int inW, int inH, int inPitch,
     uint8_t *__restrict__ out, int outW, int outH, int outPitch,
     const uint8_t *__restrict__ classX, const float *__restrict__ paletteX, const float *__restrict__ weightY,
     int colGroups, int stripsPerXcd
@@ -440,11 +425,11 @@ __global__ __launch_bounds__(256, LFG_SCALE_WAVES) void scale_2x_kernel(
     // Three straight-line bodies, one per strip length of the plan; a strip cut short at the end of its band runs the
     // next longer body with the surplus steps' stores switched off.
     if (n > LFG_SCALE_L1)
-        scale_2x_strip<LFG_SCALE_L0>(in, inW, inH, inPitch, out, outW, outH, outPitch, classX, paletteX, weightY, rBegin, n, cg, lane, slab[wv] LFG_STAMP_ARGS);
+        scale_2x_strip<LFG_SCALE_L0, FUSED>(fs, in, inW, inH, inPitch, out, outW, outH, outPitch, classX, paletteX, weightY, rBegin, n, cg, lane, slab[wv] LFG_STAMP_ARGS);
     else if (n > LFG_SCALE_L2)
-        scale_2x_strip<LFG_SCALE_L1>(in, inW, inH, inPitch, out, outW, outH, outPitch, classX, paletteX, weightY, rBegin, n, cg, lane, slab[wv] LFG_STAMP_ARGS);
+        scale_2x_strip<LFG_SCALE_L1, FUSED>(fs, in, inW, inH, inPitch, out, outW, outH, outPitch, classX, paletteX, weightY, rBegin, n, cg, lane, slab[wv] LFG_STAMP_ARGS);
     else
-        scale_2x_strip<LFG_SCALE_L2>(in, inW, inH, inPitch, out, outW, outH, outPitch, classX, paletteX, weightY, rBegin, n, cg, lane, slab[wv] LFG_STAMP_ARGS);
+        scale_2x_strip<LFG_SCALE_L2, FUSED>(fs, in, inW, inH, inPitch, out, outW, outH, outPitch, classX, paletteX, weightY, rBegin, n, cg, lane, slab[wv] LFG_STAMP_ARGS);
 #undef LFG_STAMP_ARGS
 }
 
@@ -502,12 +487,13 @@ void scale_2x_strip_host(int inH, int xcd, int index, int &first, int &steps) {
     scale_2x_strip_of(inH, xcd, index, scale_2x_strips_per_xcd(inH), first, steps);
 }
 
-hipError_t launch_scale_2x(hipStream_t s, const lfg_frame &in, const lfg_frame &out,
-                           const AxisTable &tx, const AxisTable &ty) {
+template <bool FUSED>
+static hipError_t launch_2x(hipStream_t s, const FusedSource &fs, const lfg_frame &in, const lfg_frame &out,
+                            const AxisTable &tx, const AxisTable &ty) {
     const int colGroups = ((int)in.width + kOwnedCols - 1) / kOwnedCols;
     const int groupsPerRow = (colGroups + 3) / 4;         // workgroups of four waves (four adjacent column groups)
     dim3 grid(8 * ty.strips_per_xcd * groupsPerRow);
-    hipLaunchKernelGGL(scale_2x_kernel, grid, dim3(256), 0, s,
+    hipLaunchKernelGGL(scale_2x_kernel<FUSED>, grid, dim3(256), 0, s, fs,
                        (const uint8_t *)in.data, (int)in.width, (int)in.height, (int)in.pitch,
                        (uint8_t *)out.data, (int)out.width, (int)out.height, (int)out.pitch,
                        tx.d_class, tx.d_palette, ty.d_weight, colGroups, ty.strips_per_xcd
@@ -516,6 +502,20 @@ hipError_t launch_scale_2x(hipStream_t s, const lfg_frame &in, const lfg_frame &
 #endif
                        );
     return hipGetLastError();
+}
+
+hipError_t launch_scale_2x(hipStream_t s, const lfg_frame &in, const lfg_frame &out,
+                           const AxisTable &tx, const AxisTable &ty) {
+    return launch_2x<false>(s, FusedSource{}, in, out, tx, ty);
+}
+
+// interpolate(prev, curr, mv, t) upscaled 2x straight into `out` (all three inputs at input resolution).
+hipError_t launch_interpolate_scale_2x(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv,
+                                       const lfg_frame &out, const AxisTable &tx, const AxisTable &ty, float factor, bool intended) {
+    FusedSource fs{(const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
+                   (const int8_t *)mv.data, (int)mv.pitch, factor, intended ? 1 : 0};
+    lfg_frame shape = curr;               // sizes only: the kernel reads no input frame
+    return launch_2x<true>(s, fs, shape, out, tx, ty);
 }
 
 }  // namespace lfg

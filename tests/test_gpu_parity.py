@@ -735,6 +735,70 @@ def test_interpolate_frames_multi_entry_point(ctx, oracle):
         ctx.destroy_frame(f)
 
 
+@pytest.mark.parametrize("wh,out_wh", [((96, 54), (192, 108)), ((250, 70), (500, 140)), ((64, 36), (100, 50)), ((40, 30), (40, 30))])
+def test_interpolate_scale_equals_the_two_stages(ctx, oracle, wh, out_wh):
+    """lfg_interpolate_scale (the input-resolution data flow): where out is exactly 2x the
+    inputs ONE kernel interpolates every input row on the fly inside the 2x scale kernel -- and must give, byte for
+    byte, what lfg_interpolate into a frame followed by lfg_scale of that frame gives (and within +-1 LSB what the
+    oracle's two functions give); other size ratios take the two stages through a context-owned frame."""
+    from linux_fg_amd import capi
+    w, h = wh
+    ow, oh = out_wh
+    prev, curr = rand_frame(w, h), rand_frame(w, h)
+    mv = RNG.integers(-16, 17, size=(h, w, 2)).astype(np.int8)
+    mv[: h // 2] = 0                                              # both sources sampled in range: the bilinear path at texel centres
+    mv[h // 2:, : w // 2] = RNG.integers(-1, 2, size=(h - h // 2, w // 2, 2)).astype(np.int8)
+    p, c = ctx.frame_from(prev), ctx.frame_from(curr)
+    m = ctx.frame_from(mv, capi.FORMAT_MV_S8X2)
+    mid, staged, fused = ctx.create_frame(w, h), ctx.create_frame(ow, oh), ctx.create_frame(ow, oh)
+    for sem in (capi.SEMANTICS_REFERENCE, capi.SEMANTICS_INTENDED):
+        ctx.set_semantics(sem)
+        try:
+            for t in (0.5, 0.25):
+                ctx.interpolate(p, c, m, mid, t)
+                ctx.scale(mid, staged)
+                a = ctx.download(staged)
+                for fuse in (True, False):                      # the fused kernel, and the default (two stages inside)
+                    ctx.set_fused_interpolate_scale(fuse)
+                    ctx.interpolate_scale(p, c, m, fused, t)
+                    b = ctx.download(fused)
+                    assert (a == b).all(), f"{(a != b).any(-1).sum()} pixels differ (semantics {sem}, t {t}, fused {fuse})"
+                if sem == capi.SEMANTICS_REFERENCE:
+                    want = oracle.scale(oracle.interpolate(prev, curr, mv.astype(np.float32), t), ow, oh)
+                    assert_within_1lsb(b, want)
+        finally:
+            ctx.set_semantics(capi.SEMANTICS_REFERENCE)
+            ctx.set_fused_interpolate_scale(False)
+    other = ctx.create_frame(w + 2, h)
+    with pytest.raises(capi.LfgError, match="differ in size"):
+        ctx.interpolate_scale(p, other, m, fused, 0.5)
+    ctx.destroy_frame(other)
+    with pytest.raises(capi.LfgError, match="aliases an input"):
+        ctx.interpolate_scale(p, c, m, c, 0.5)
+    for f in (p, c, m, mid, staged, fused):
+        ctx.destroy_frame(f)
+
+
+def test_interpolate_scale_1080p_to_4k(ctx):
+    """The benchmark's input-resolution variant at full size: fused kernel == the two stages, on the device's own motion vectors."""
+    from linux_fg_amd import capi
+    prev, curr = synth.make_pair(1920, 1080, stream=0, shift=(3, -2))
+    p, c = ctx.frame_from(prev), ctx.frame_from(curr)
+    m = ctx.create_frame(1920, 1080, capi.FORMAT_MV_S8X2)
+    ctx.motion(p, c, m)
+    mid, staged, fused = ctx.create_frame(1920, 1080), ctx.create_frame(3840, 2160), ctx.create_frame(3840, 2160)
+    ctx.interpolate(p, c, m, mid, 0.5)
+    ctx.scale(mid, staged)
+    ctx.set_fused_interpolate_scale(True)
+    try:
+        ctx.interpolate_scale(p, c, m, fused, 0.5)
+    finally:
+        ctx.set_fused_interpolate_scale(False)
+    assert (ctx.download(staged) == ctx.download(fused)).all()
+    for f in (p, c, m, mid, staged, fused):
+        ctx.destroy_frame(f)
+
+
 def test_interpolate_frames_entry_point(ctx, oracle):
     """FrameManager::InterpolateFrames equivalent: motion(8,16) then interpolate, MV temp inside."""
     W, H = 128, 64

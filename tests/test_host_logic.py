@@ -73,15 +73,15 @@ def test_stream_assignment_covers_every_stream_once():
 
 
 def test_single_rank_broadcaster_is_a_pass_through():
-    import torch
     calls = []
-    slot = torch.zeros(4, dtype=torch.uint8)
-    b = sharding.SharedFrameBroadcaster([slot], world_size=1, refill=lambda step, s: calls.append((step, s)))
+    b = sharding.SharedFrameBroadcaster(1, None, world_size=1, refill=lambda step, s: calls.append((step, s)))
     b.start(0)
     for k in range(3):
-        assert b.acquire(k) is slot
+        assert b.acquire(k) == 0                     # one slot, no transport, nothing to wait for
     b.drain()
     assert calls == [(0, 0), (1, 0), (2, 0)]
+    with pytest.raises(ValueError):
+        sharding.SharedFrameBroadcaster(2, None, world_size=2)      # several ranks need a transport
 
 
 @pytest.mark.parametrize("in_h", [1, 2, 5, 16, 17, 36, 135, 540, 1080, 1081, 2160, 4320, 32768])
