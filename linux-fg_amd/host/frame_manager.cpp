@@ -93,6 +93,23 @@ bool FrameManager::InterpolateFramesMulti(const Frame& previous, const Frame& cu
     return HipContext::Get().WaitIdle();
 }
 
+bool FrameManager::BroadcastFrame(Frame& frame, int root) {
+    lfg_frame f = frame.AsAbi();
+    if (lfg_broadcast_frame(Ctx(), &f, root) != LFG_OK) {
+        LOG_ERROR("Failed to broadcast frame: ", lfg_last_error(Ctx()));
+        return false;
+    }
+    return true;
+}
+
+bool FrameManager::WaitBroadcasts() {
+    if (lfg_comm_wait(Ctx()) != LFG_OK) {
+        LOG_ERROR("Failed to wait for broadcasts: ", lfg_last_error(Ctx()));
+        return false;
+    }
+    return true;
+}
+
 bool FrameManager::CreateStagingBuffer(void*& buffer, size_t size) {
     if (lfg_staging_create(Ctx(), size, &buffer) != LFG_OK) {
         LOG_ERROR("Failed to create staging buffer: ", lfg_last_error(Ctx()));

@@ -66,6 +66,11 @@ public:
     bool InterpolateFramesMultiAsync(const Frame& previous, const Frame& current, const std::vector<Frame*>& outputs,
                                      const std::vector<float>& factors);
 
+    // The one exchange of the multi-GPU path: broadcast a frame from rank `root` to every rank (asynchronous, on the
+    // device context's communication stream) and make later work on the compute queue wait for it.
+    bool BroadcastFrame(Frame& frame, int root);
+    bool WaitBroadcasts();
+
     // Buffer management (src/frame_manager.cpp:199-214): pinned host memory instead of a
     // host-visible VkBuffer.
     bool CreateStagingBuffer(void*& buffer, size_t size);

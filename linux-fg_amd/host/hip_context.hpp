@@ -4,6 +4,7 @@
 // ordinal and one stream (the "compute queue").  It calls only the C-ABI in include/linuxfg_hip.h.
 #pragma once
 #include <cstdint>
+#include <string>
 
 #include "linuxfg_hip.h"
 #include "logger.hpp"
@@ -24,6 +25,13 @@ public:
     void* GetComputeQueue() const;                            // the HIP stream (VulkanContext::GetComputeQueue)
     int GetDeviceOrdinal() const;
     bool WaitIdle();                                          // vkQueueWaitIdle
+
+    // Several GPUs, one process each (no reference counterpart: one queue, no communication,
+    // src/vulkan_context.cpp:130-151).  Rank 0 makes the communicator id and leaves it in `idFile` (written under a
+    // temporary name, then renamed); the other ranks wait for the file.  Collective: returns when all ranks have joined.
+    bool InitComm(int ranks, int rank, const std::string& idFile);
+    int GetRank() const { return m_ctx ? lfg_comm_rank(m_ctx) : -1; }
+    int GetRanks() const { return m_ctx ? lfg_comm_ranks(m_ctx) : 0; }
 
 private:
     HipContext() = default;

@@ -23,6 +23,10 @@ static void PrintUsage() {
               << "  --interpolation-factor F Interpolation blend factor (0.0-1.0, default: 0.5)\n"
               << "  --factors A,B,...        Several generated frames per pair, in presentation order (e.g. 0.25,0.5,0.75\n"
               << "                           for 60 -> 240 fps); motion runs once per pair\n"
+              << "  --ranks N --rank R --comm-file FILE\n"
+              << "                           One process per GPU (BASELINE config 4): the batch shares its previous frame\n"
+              << "                           (synthetic stream 0, captured on rank 0, broadcast over RCCL per frame); each\n"
+              << "                           rank's current frames are its own stream.  FILE carries the communicator id.\n"
               << "  --frames N               Number of input frames to process (default: 10)\n"
               << "  --device N               HIP device ordinal (default: 0)\n"
               << "  --dump-dir DIR           Write every presented frame to DIR as raw RGBA8\n"
@@ -39,7 +43,8 @@ int main(int argc, char* argv[]) {
     config.targetFps = 60;
     uint32_t stream = 0;
     int frames = 10, device = 0;
-    std::string dumpDir, inputRaw, outputRaw;
+    std::string dumpDir, inputRaw, outputRaw, commFile;
+    int ranks = 0, rank = 0;
     std::vector<float> factors;
     bool syncPresent = false;
 
@@ -61,6 +66,9 @@ int main(int argc, char* argv[]) {
                 p = *end == ',' ? end + 1 : end;
             }
         }
+        else if (strcmp(argv[i], "--ranks") == 0 && i + 1 < argc) ranks = std::atoi(argv[++i]);
+        else if (strcmp(argv[i], "--rank") == 0 && i + 1 < argc) rank = std::atoi(argv[++i]);
+        else if (strcmp(argv[i], "--comm-file") == 0 && i + 1 < argc) commFile = argv[++i];
         else if (strcmp(argv[i], "--frames") == 0 && i + 1 < argc) frames = std::atoi(argv[++i]);
         else if (strcmp(argv[i], "--device") == 0 && i + 1 < argc) device = std::atoi(argv[++i]);
         else if (strcmp(argv[i], "--dump-dir") == 0 && i + 1 < argc) dumpDir = argv[++i];
@@ -95,6 +103,12 @@ int main(int argc, char* argv[]) {
         LOG_ERROR("Failed to initialize frame manager");
         HipContext::Get().Cleanup();
         return 1;
+    }
+    if (ranks > 0) {
+        if (commFile.empty() || rank < 0 || rank >= ranks) { LOG_ERROR("--ranks needs --rank in range and --comm-file"); return 1; }
+        if (!HipContext::Get().InitComm(ranks, rank, commFile)) { HipContext::Get().Cleanup(); return 1; }
+        Scaler::Get().SetSharedPreviousSource(std::make_unique<SyntheticCapture>(0));   // the batch's previous frames: stream 0
+        if (stream == 0) stream = (uint32_t)rank + 1;                                   // a rank's own current frames
     }
     if (!inputRaw.empty()) Scaler::Get().SetFrameSource(std::make_unique<RawFileCapture>(inputRaw));
     else Scaler::Get().SetFrameSource(std::make_unique<SyntheticCapture>(stream));

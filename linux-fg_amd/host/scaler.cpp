@@ -20,6 +20,16 @@ bool Scaler::Initialize(const ScalerConfig& config) {
         LOG_ERROR("Failed to initialize frame source");
         return false;
     }
+    if (m_sharedSource) {
+        if (HipContext::Get().GetRanks() < 1) {
+            LOG_ERROR("Scaler::Initialize: a shared previous frame needs HipContext::InitComm first");
+            return false;
+        }
+        if (HipContext::Get().GetRank() == 0 && !m_sharedSource->Initialize(config.inputWidth, config.inputHeight)) {
+            LOG_ERROR("Failed to initialize the shared frame source");
+            return false;
+        }
+    }
     if (m_factors.empty()) m_factors.push_back(config.interpolationFactor);
     if (m_factors.size() > LFG_MAX_FACTORS) {
         LOG_ERROR("Scaler::Initialize: at most ", LFG_MAX_FACTORS, " interpolation factors per pair");
@@ -60,6 +70,13 @@ bool Scaler::CreateFrameResources() {
             return false;
         }
     }
+    if (m_sharedSource && !m_sharedIn[0].data) {
+        if (!fm.CreateFrame(m_sharedIn[0], m_config.inputWidth, m_config.inputHeight) ||
+            !fm.CreateFrame(m_sharedIn[1], m_config.inputWidth, m_config.inputHeight)) {
+            LOG_ERROR("Failed to create the shared previous frames");
+            return false;
+        }
+    }
     if (m_config.enableInterpolation && !m_previousOutput.data) {
         bool ok = fm.CreateFrame(m_previousOutput, m_config.outputWidth, m_config.outputHeight);
         m_interpolatedFrames.resize(m_factors.size());
@@ -72,14 +89,23 @@ bool Scaler::CreateFrameResources() {
     return true;
 }
 
-bool Scaler::CaptureFrame(Frame& frame) {
+bool Scaler::CaptureFrame(Frame& frame) { return CaptureFrom(*m_source, frame); }
+
+// Root: the next shared previous frame goes into m_sharedIn[slot]; every rank: its broadcast starts (asynchronously,
+// ordered after everything enqueued so far -- the kernels that read the slot two calls ago).
+bool Scaler::IssueSharedPrevious(int slot) {
+    if (HipContext::Get().GetRank() == 0 && !CaptureFrom(*m_sharedSource, m_sharedIn[slot])) return false;
+    return FrameManager::Get().BroadcastFrame(m_sharedIn[slot], 0);
+}
+
+bool Scaler::CaptureFrom(FrameSource& source, Frame& frame) {
     void* host = nullptr;
     uint32_t slot = 0;
     if (lfg_ring_acquire(m_uploadRing, &host, &slot) != LFG_OK) {
         LOG_ERROR("Failed to acquire an upload slot");
         return false;
     }
-    if (!m_source->NextFrame(static_cast<uint8_t*>(host))) {
+    if (!source.NextFrame(static_cast<uint8_t*>(host))) {
         LOG_ERROR("Failed to capture frame");
         return false;
     }
@@ -149,6 +175,24 @@ bool Scaler::ProcessFrame() {
 
     if (!CreateFrameResources()) return false;
 
+    if (m_sharedSource) {
+        // this call's shared previous frame: its broadcast was issued during the last call (now, for the first);
+        // the next call's starts right away and runs next to this call's kernels
+        const int slot = (int)(m_calls & 1u);
+        if (m_calls == 0 && !IssueSharedPrevious(0)) return false;
+        if (!FrameManager::Get().WaitBroadcasts()) return false;
+        if (m_config.enableInterpolation) {
+            auto fence = [&](const Frame& f) {
+                const auto it = m_lastReadback.find(f.data);
+                if (it != m_lastReadback.end()) lfg_ring_fence_slot(m_readbackRing, it->second);
+            };
+            fence(m_previousOutput);
+            if (!ScaleFrame(m_sharedIn[slot], m_previousOutput)) return false;
+            m_havePrevious = true;
+        }
+        if (!IssueSharedPrevious(slot ^ 1)) return false;
+    }
+    ++m_calls;
     if (!CaptureFrame(m_currentFrame)) {
         LOG_ERROR("Failed to capture frame");
         return false;
@@ -190,7 +234,7 @@ bool Scaler::ProcessFrame() {
     // Pipelined: present what the previous call queued while this call's work runs; otherwise everything now.
     if (!PresentPending(m_pipelined ? m_pending.size() - inFlightBefore : 0)) return false;
 
-    if (m_config.enableInterpolation) {
+    if (m_config.enableInterpolation && !m_sharedSource) {
         // previous <- current: swap the handles instead of copying the image (src/scaler.cpp:616-621).
         std::swap(m_previousFrame, m_currentFrame);
         std::swap(m_previousOutput, m_outputFrame);
@@ -211,6 +255,10 @@ void Scaler::Cleanup() {
     fm.DestroyFrame(m_previousFrame);
     fm.DestroyFrame(m_outputFrame);
     fm.DestroyFrame(m_previousOutput);
+    if (Ctx() && m_sharedSource && HipContext::Get().GetRanks() > 0) (void)fm.WaitBroadcasts();   // the look-ahead broadcast of the last call
+    fm.DestroyFrame(m_sharedIn[0]);
+    fm.DestroyFrame(m_sharedIn[1]);
+    m_calls = 0;
     for (Frame& f : m_interpolatedFrames) fm.DestroyFrame(f);
     m_interpolatedFrames.clear();
     m_factors.clear();

@@ -78,6 +78,41 @@ def test_cadence_60_to_240_sequence_matches_oracle(host_binary, oracle, tmp_path
                 assert (frames[4 * i + 1 + j] == oracle.interpolate(reals[i], reals[i + 1], mv, t)).all(), (i, t)
 
 
+def test_shared_previous_batch_mode_one_rank(host_binary, oracle, tmp_path):
+    """lfg_host --ranks 1 --rank 0 --comm-file F (BASELINE config 4's data flow in the C++ host, on the one GPU of this
+    box): the communicator id travels through the file, call k's previous frame is frame k of stream 0 -- captured on
+    rank 0, broadcast through lfg_broadcast_frame one call ahead, upscaled on the rank -- and its current frame is
+    frame k of the rank's own stream.  Every call presents [generated, real]; each generated frame equals the
+    oracle's for that pair.  (More ranks need more GPUs: RCCL wants one device per rank.)"""
+    w, h, n = 64, 36, 3
+    d = tmp_path / "shared"
+    d.mkdir()
+    stats = run_host(["--input-width", str(w), "--input-height", str(h), "--output-width", str(2 * w), "--output-height", str(2 * h),
+                      "--frames", str(n), "--dump-dir", str(d), "--quiet", "--ranks", "1", "--rank", "0",
+                      "--comm-file", str(tmp_path / "comm.id")])
+    assert stats["presented"] == 2 * n and stats["interpolated"] == n
+    assert os.path.getsize(tmp_path / "comm.id") == 128
+    files = sorted(os.listdir(d))
+    assert [f.split("_")[2] for f in files] == ["interp", "real"] * n
+    frames = [np.fromfile(d / f, np.uint8).reshape(2 * h, 2 * w, 4) for f in files]
+
+    def stream(idx):
+        seed = synth.BASE_SEED + idx
+        out = [synth.make_prev(w, h, seed)]
+        for k in range(1, n):
+            out.append(synth.translate(out[-1], (3, -2), seed + k))
+        return out
+    shared, own = stream(0), stream(1)
+    for k in range(n):
+        real = frames[2 * k + 1]
+        assert np.abs(real.astype(np.int16) - oracle.scale(own[k], 2 * w, 2 * h).astype(np.int16)).max() <= 1
+        prev_up = oracle.scale(shared[k], 2 * w, 2 * h)              # the device's own upscale may differ by an LSB: take
+        mv = oracle.motion(prev_up, real, 8, 16.0)                  # the vectors and the blend from what it presented
+        gen = oracle.interpolate(prev_up, real, mv, 0.5)
+        diff = np.abs(frames[2 * k].astype(np.int16) - gen.astype(np.int16))
+        assert diff.max() <= 1 or (diff > 1).mean() < 0.02, k        # (an LSB in prev_up can move a blend by one, rarely a vector)
+
+
 def test_no_interpolation_and_aspect_ratio(host_binary):
     out = subprocess.run([host_binary, "--input-width", "80", "--input-height", "40", "--output-height", "100",
                           "--no-interpolation", "--frames", "4", "--quiet"], capture_output=True, text=True, check=True)
