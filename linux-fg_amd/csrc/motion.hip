@@ -1644,10 +1644,10 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, Motion
     // (+ the number of flagged tiles and the list of the first kShareBelow of them, + the prefilter's three unit counters)
     l.ctrl = l.queueCount + (2 + kShareBelow) * sizeof(uint32_t);
     // ... and the queue of segments handed over at run time (entries double as "slot filled" signals): up to a quarter
-    // of the frame's segments, 1024 entries at most (a multiple of the entries one segment takes, so that a push either fits as
+    // of the frame's segments, 2048 entries at most (a multiple of the entries one segment takes, so that a push either fits as
     // a whole or is refused as a whole; beyond that a segment is searched by the wave that owns it, as before).  One
     // memset clears everything from the tile flags to here.
-    l.queueCap = (int)std::min<size_t>(1024, std::max<size_t>(LFG_DYN_PARTS / 4, ptiles * (kPTH / kSeg) / 4 / (LFG_DYN_PARTS / 4) * (LFG_DYN_PARTS / 4)));
+    l.queueCap = (int)std::min<size_t>(2048, std::max<size_t>(LFG_DYN_PARTS / 4, ptiles * (kPTH / kSeg) / 4 / (LFG_DYN_PARTS / 4) * (LFG_DYN_PARTS / 4)));
     l.queue = l.ctrl + 4 * sizeof(uint32_t);
     l.order = align(l.queue + (size_t)l.queueCap * sizeof(uint32_t));           // this call's hints and visiting order
     // work-unit tables and the auxiliary arrays of the shared tiles (see prefilter_plan): one 56 x 64 block per unit
