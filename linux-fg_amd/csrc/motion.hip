@@ -398,7 +398,8 @@ __device__ unsigned long long gResolveStats[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, ~0
 // order32[e] = the candidate's rank in the tie order (motion_tables) in the low half, its window offset
 // (dx+R)*kWinH + (dy+R) in the high half; 32-bit entries so the wave-uniform reads are scalar loads.
 #ifndef LFG_PREF_OCC
-#define LFG_PREF_OCC 3
+#define LFG_PREF_OCC 2                 // waves per SIMD: 2 = 256 VGPRs, no spills (168 VGPRs at 3 spill 89 registers to scratch:
+                                       // +24 % on matched content, 6 % faster only where every segment searches in full)
 #endif
 #ifndef LFG_DYN_PARTS
 #define LFG_DYN_PARTS 8                 // parts of the candidate order a handed-over segment is searched in (4 or 8)
@@ -691,8 +692,7 @@ __device__ __forceinline__ void prefilter_unit(
                         // answer is the first such candidate in scan order.  Its index goes into the threshold
                         // itself (zeroCap = 0x00800000 + cand as a float: tiny, yet above 0 and below every
                         // non-zero S~ >= 1) and the list does not grow -- static or flat areas, where many
-                        // candidates cost 0, never fill the lists.  Branch-free: max() picks zeroCap only for
-                        // S~ == 0, and the record written for a zero is overwritten by the next real one.
+                        // candidates cost 0, never fill the lists.  max() picks zeroCap only for S~ == 0.
                         float cap, t;
                         asm("v_max_f32 %0, %2, %1" : "=v"(cap) : "v"(s * kRatio), "s"(zeroCap));   // no NaNs here
                         asm("v_min_f32 %0, %1, %2" : "=v"(t) : "v"(thr[hb][i]), "v"(cap));
@@ -701,7 +701,7 @@ __device__ __forceinline__ void prefilter_unit(
                         // past the end of the list the last slot is overwritten; the count keeps growing and
                         // flags the tile
                         const uint32_t at = __umul24(min(n, (uint32_t)kListK - 1u), rowStride) + laneOff[hb] + (uint32_t)i;
-                        waveList[at] = rec_make(s, cand);
+                        if (s != 0.0f) waveList[at] = rec_make(s, cand);       // (a zero-cost candidate lives in the threshold word: no record, no write)
                         uint32_t inc = (s != 0.0f && countIt != 0u) ? (1u << (16 * (i & 1))) : 0u;
                         if (windowLeavesPrev) {                        // wave-uniform: tiles away from the rim skip this
                             // one member per plateau (block_leaves_prev): a second one is written but not counted
@@ -1065,13 +1065,16 @@ __device__ __forceinline__ void prefilter_unit(
     // survives ARE the answer (motion_resolve_kernel's rules; no plateaus where the window stays inside prev).
     // A segment whose pixels were all settled says so, and the resolve kernel skips the blocks it covers.
     if (whole && !windowLeavesPrev) {
+        // the first two records of the pixels that have any (a zero-cost pixel has none: most of a frame under a pan)
         Rec ra[2][kRun], rb[2][kRun];
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
 #pragma unroll
-            for (int i = 0; i < kRun; ++i) {           // (beyond the count: stale records, read but not used)
-                ra[hb][i] = waveList[laneOff[hb] + (uint32_t)i];
-                rb[hb][i] = waveList[rowStride + laneOff[hb] + (uint32_t)i];
+            for (int i = 0; i < kRun; ++i) {
+                const uint32_t cnt = (cnt2[hb][i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+                ra[hb][i] = 0u; rb[hb][i] = 0u;
+                if (cnt >= 1u) ra[hb][i] = waveList[laneOff[hb] + (uint32_t)i];
+                if (cnt >= 2u) rb[hb][i] = waveList[rowStride + laneOff[hb] + (uint32_t)i];
             }
         }
         uint32_t best[2][kRun];
@@ -1094,21 +1097,39 @@ __device__ __forceinline__ void prefilter_unit(
                 allSettled = allSettled && (!inImage || b != 0xFFFFFFFFu);
             }
         }
+        // Only a segment that settles ALL of its pixels writes vectors (the resolve kernel redoes every pixel of any
+        // other segment anyway), and it writes them as rows: the 16 x 56 vectors go through the wave's slab and leave
+        // as 112 contiguous bytes per image row, two rows per store instruction -- a lane's own 2 x 7 pixels, stored
+        // from where they were computed, touched sixteen cache lines per instruction with two bytes each (133 MB of
+        // write requests per 4K frame for 16.6 MB of vectors).
+        if (__builtin_amdgcn_readfirstlane(__ballot(!allSettled) == 0ull)) {
+            uint16_t *const rows = reinterpret_cast<uint16_t *>(sSlab[wave]);          // [16][56] vectors (1,792 of 2,176 bytes)
+            wave_lds_sync();
 #pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {
-            const int py = ty0 + kSeg * seg + 8 * hb + r8;
+            for (int hb = 0; hb < 2; ++hb) {
 #pragma unroll
-            for (int i = 0; i < kRun; ++i) {
-                if (best[hb][i] != 0xFFFFFFFFu) {
-                    const int scan = (int)rank2scan[best[hb][i]];
+                for (int i = 0; i < kRun; ++i) {
+                    const int scan = (int)rank2scan[best[hb][i] != 0xFFFFFFFFu ? best[hb][i] : 0u];     // (outside the image: never stored)
                     const int dyi = scan / kSide, dxi = scan - dyi * kSide;
-                    int8_t *dst = mv + (size_t)py * (size_t)mvPitch + (size_t)(px0 + i) * 2u;
-                    dst[0] = (int8_t)(dxi - kR);
-                    dst[1] = (int8_t)(dyi - kR);
+                    rows[(8 * hb + r8) * kPTW + kRun * q + i] = (uint16_t)(uint8_t)(int8_t)(dxi - kR) | (uint16_t)((uint16_t)(uint8_t)(int8_t)(dyi - kR) << 8);
                 }
             }
-        }
-        if (__builtin_amdgcn_readfirstlane(__ballot(!allSettled) == 0ull)) {
+            wave_lds_sync();
+            const bool wide = ((mvPitch & 3) == 0) && (((uintptr_t)mv & 3u) == 0u);       // 4-byte stores need 4-byte rows
+            const int half = lane / 28, d = lane - half * 28;                            // 28 dwords = one row of the tile
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int row = 2 * rr + half, py = ty0 + kSeg * seg + row, px = tx0 + 2 * d;
+                if (lane < 56 && py < H && px < W) {
+                    const uint32_t two = *reinterpret_cast<const uint32_t *>(rows + row * kPTW + 2 * d);
+                    int8_t *dst = mv + (size_t)py * (size_t)mvPitch + (size_t)px * 2u;
+                    if (wide && px + 1 < W) *reinterpret_cast<uint32_t *>(dst) = two;
+                    else {
+                        *reinterpret_cast<uint16_t *>(dst) = (uint16_t)two;
+                        if (px + 1 < W) *reinterpret_cast<uint16_t *>(dst + 2) = (uint16_t)(two >> 16);
+                    }
+                }
+            }
             if (lane == 0) segDone[tile * (kPTH / kSeg) + seg] = 1u;
         } else {
             writeThresholds();
@@ -1132,8 +1153,10 @@ __device__ __forceinline__ void prefilter_unit(
         for (int hb = 0; hb < 2; ++hb) {
 #pragma unroll
             for (int i = 0; i < kRun; ++i) {
-                ra[hb][i] = waveList[laneOff[hb] + (uint32_t)i];
-                rb[hb][i] = waveList[rowStride + laneOff[hb] + (uint32_t)i];
+                const uint32_t cnt = (cnt2[hb][i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+                ra[hb][i] = 0u; rb[hb][i] = 0u;
+                if (cnt >= 1u) ra[hb][i] = waveList[laneOff[hb] + (uint32_t)i];
+                if (cnt >= 2u) rb[hb][i] = waveList[rowStride + laneOff[hb] + (uint32_t)i];
                 const float fx = thr2[i].x, fy = thr2[i].y;            // (named floats: see refreshZeroBound)
                 sBound[wave * kPix + (kRun * hb + i) * 64 + lane] = hb ? fy : fx;
             }
@@ -1193,8 +1216,7 @@ __device__ __forceinline__ void prefilter_unit(
                     if (single && block_leaves_prev(px0 + i, py, dxi - kR, dyi - kR, W, H)) settled = false;
                     if (settled) {
                         int8_t *dst = mv + (size_t)py * (size_t)mvPitch + (size_t)(px0 + i) * 2u;
-                        dst[0] = (int8_t)(dxi - kR);
-                        dst[1] = (int8_t)(dyi - kR);
+                        *reinterpret_cast<uint16_t *>(dst) = (uint16_t)(uint8_t)(int8_t)(dxi - kR) | (uint16_t)((uint16_t)(uint8_t)(int8_t)(dyi - kR) << 8);   // both components, one store
                     }
                 }
                 open = open || !settled;
@@ -1565,8 +1587,7 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
         const int bscan = (int)rank2scan[bestC];
         const int dyi = bscan / kSide, dxi = bscan - dyi * kSide;
         int8_t *dst = mv + (size_t)py * (size_t)mvPitch + (size_t)px * 2u;
-        dst[0] = (int8_t)(dxi - kR);
-        dst[1] = (int8_t)(dyi - kR);
+        *reinterpret_cast<uint16_t *>(dst) = (uint16_t)(uint8_t)(int8_t)(dxi - kR) | (uint16_t)((uint16_t)(uint8_t)(int8_t)(dyi - kR) << 8);   // both components, one store
     }
 #ifdef LFG_MOTION_STAMPS
     if ((threadIdx.x & 63) == 0) {
@@ -1596,8 +1617,7 @@ __global__ __launch_bounds__(256) void motion_merge_kernel(
         const int scan = (int)rank2scan[(uint32_t)merge[(size_t)py * mergeRowStride + (size_t)px]];
         const int dyi = scan / kSide, dxi = scan - dyi * kSide;
         int8_t *dst = mv + (size_t)py * (size_t)mvPitch + (size_t)px * 2u;
-        dst[0] = (int8_t)(dxi - kR);
-        dst[1] = (int8_t)(dyi - kR);
+        *reinterpret_cast<uint16_t *>(dst) = (uint16_t)(uint8_t)(int8_t)(dxi - kR) | (uint16_t)((uint16_t)(uint8_t)(int8_t)(dyi - kR) << 8);   // both components, one store
     }
 }
 
