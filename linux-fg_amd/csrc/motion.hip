@@ -34,6 +34,9 @@
 #include "lfg_internal.hpp"
 
 #include <algorithm>
+#include <cstring>
+#include <utility>
+#include <vector>
 
 namespace lfg {
 
@@ -355,6 +358,9 @@ constexpr int kSlabP = 136;                       // slab pitch of a ROW PAIR (f
                                                   // transposed reads on 32 distinct banks
 constexpr int kRun = 7;                           // pixels per row-sum run: 8 runs x 7 = 56
 constexpr int kRunIn = kRun + kB - 1;             // 13
+#ifndef LFG_SIXTEEN
+#define LFG_SIXTEEN 1
+#endif
 #ifndef LFG_HINT_GRID
 #define LFG_HINT_GRID 16
 #endif
@@ -372,6 +378,10 @@ static_assert(kPTW + kB - 1 <= 64 && kWinW >= kPTW + kB - 1 + 2 * kR, "one lane 
 // a given pixel they all cost exactly the same (the same sequence of |curr texel| distances): a plateau of up to a few
 // hundred tied candidates next to the left/right/top/bottom edge.  Only the first of them in tie order can win, so the
 // prefilter records ONE member of the plateau per pixel and the resolve kernel replaces it by the first in tie order.
+// ... for some pixel of the rectangle [x0, x1] x [y0, y1]
+__device__ __forceinline__ bool block_leaves_prev_any(int x0, int x1, int y0, int y1, int dx, int dy, int W, int H) {
+    return (x0 + kB / 2 - 1 + dx < 0) | (x1 - kB / 2 + dx >= W) | (y0 + kB / 2 - 1 + dy < 0) | (y1 - kB / 2 + dy >= H);
+}
 __device__ __forceinline__ bool block_leaves_prev(int px, int py, int dx, int dy, int W, int H) {
     return (px + kB / 2 - 1 + dx < 0) | (px - kB / 2 + dx >= W) | (py + kB / 2 - 1 + dy < 0) | (py - kB / 2 + dy >= H);
 }
@@ -415,14 +425,14 @@ __device__ __forceinline__ void prefilter_unit(
     const uint32_t *__restrict__ order32, const PrefilterPlan &sp,
     int8_t *__restrict__ mv, int mvPitch, const uint32_t *__restrict__ rank2scan, uint32_t *__restrict__ segDone,
     const int unit, const bool fromQueue, const uint32_t um,
-    uint32_t *sWin, float (*sSlab)[4 * kSlabP], uint32_t *sOrder, uint32_t &sGiveUp) {
+    uint32_t *sWin, float (*sSlab)[4 * kSlabP], uint32_t *sOrder, const uint16_t *sInv, uint32_t &sGiveUp) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         // wave index 0..3
 #ifdef LFG_MOTION_STAMPS
     const unsigned long long stampStart = __builtin_amdgcn_s_memrealtime();
-    unsigned stampEvals = 0u, stampBatches = 0u;
+    unsigned stampEvals = 0u, stampBatches = 0u, stampThr = 0u, stampThrEnd = 0u, stampFour = 0u;
     unsigned long long stampStaged = 0ull, stampFirst = 0ull;
 #endif
     // Work units (PrefilterPlan).  A tile is 4 segments of 16 rows, and a workgroup is either
@@ -549,7 +559,8 @@ __device__ __forceinline__ void prefilter_unit(
     // tree is "pair j + pair j+k" with a few scalar adds where the two halves meet.
     constexpr int kHalf = 12;
     static_assert(kSegD == 2 * kHalf - 1, "pairing (j, j+12) covers 23 positions with position 11 alone");
-    auto columnSums = [&](const uint32_t (&p)[kSegD], float (&v8)[kSeg]) {
+    auto columnSums = [&](const uint32_t (&p)[kSegD], const uint32_t (&c)[kSegD], const uint32_t (&cc)[kSegD], const uint32_t valid,
+                          float (&v8)[kSeg]) {
         // n = |c|^2 + |p|^2 - 2 c.p without integer->float conversions or shifts (half-rate ops on gfx950):
         // the dot products accumulate onto float bit patterns, 0x4B000000 + k = 2^23 + k and
         // 0x4B800000 + k = 2^24 + 2k (k < 2^23), so two exact fp32 operations give n as a float.
@@ -659,6 +670,11 @@ __device__ __forceinline__ void prefilter_unit(
         const uint32_t cand = ord & 0xFFFFu;
         const int candDx = (int)((ord >> 16) / (uint32_t)kWinH) - kR, candDy = (int)((ord >> 16) % (uint32_t)kWinH) - kR;
         const uint32_t zeroCap = 0x00800000u + cand;                   // float bits, wave-uniform
+        // can this candidate's block leave prev for ANY pixel of the segment?  (wave-uniform; next to the rim a third of
+        // the candidates can, and the per-pixel plateau bookkeeping below is most of what a recorded candidate costs)
+        const int segY0 = ty0 + kSeg * seg;
+        const bool candMayLeave = windowLeavesPrev &&
+            block_leaves_prev_any(tx0, min(tx0 + kPTW - 1, W - 1), segY0, min(segY0 + kSeg - 1, H - 1), candDx, candDy, W, H);
         f32x2 s2[kRun];
         runSums(X, s2);
         // Level 0: does ANY of the lane's 14 pixels pass (thr - S~ >= 0 for some of them)?  Seven packed
@@ -673,6 +689,14 @@ __device__ __forceinline__ void prefilter_unit(
             top = __builtin_fmaxf(top, __builtin_fmaxf(dm.x, dm.y));                     // v_max3_f32
         }
         if (__builtin_amdgcn_readfirstlane(__ballot(top >= 0.0f) == 0ull)) return;
+#ifdef LFG_DIAG_NO_SLOW   // timing experiment (wrong results): thresholds follow the minima, nothing is recorded
+#pragma unroll
+        for (int i = 0; i < kRun; ++i) {
+            const f32x2 capped = s2[i] * f32x2{kRatio, kRatio};
+            thr2[i].x = __builtin_fminf(thr2[i].x, capped.x); thr2[i].y = __builtin_fminf(thr2[i].y, capped.y);
+        }
+        return;
+#endif
         float sv[2][kRun], thr[2][kRun];
 #pragma unroll
         for (int i = 0; i < kRun; ++i) { sv[0][i] = s2[i].x; sv[1][i] = s2[i].y; thr[0][i] = thr2[i].x; thr[1][i] = thr2[i].y; }
@@ -703,7 +727,7 @@ __device__ __forceinline__ void prefilter_unit(
                         const uint32_t at = __umul24(min(n, (uint32_t)kListK - 1u), rowStride) + laneOff[hb] + (uint32_t)i;
                         if (s != 0.0f) waveList[at] = rec_make(s, cand);       // (a zero-cost candidate lives in the threshold word: no record, no write)
                         uint32_t inc = (s != 0.0f && countIt != 0u) ? (1u << (16 * (i & 1))) : 0u;
-                        if (windowLeavesPrev) {                        // wave-uniform: tiles away from the rim skip this
+                        if (candMayLeave) {                            // wave-uniform: tiles away from the rim skip this
                             // one member per plateau (block_leaves_prev): a second one is written but not counted
                             // (the pixel's coordinates are recomputed from the lane number here: kept in registers
                             //  across the evaluation they end up spilled, and a scratch reload costs a memory latency)
@@ -725,7 +749,7 @@ __device__ __forceinline__ void prefilter_unit(
     // (The wave-scope fences are for the compiler only: writes go through an f32x2 pointer, reads through a float
     //  LDS pointer, and nothing else tells it that the reads of a pass must stay between that pass's writes and
     //  the next pass's.  The hardware executes one wave's DS operations in order.)
-    auto transpose = [&](const float (&v8)[kSeg], f32x2 (&X)[kRunIn]) {
+    auto transpose = [&](const float (&v8)[kSeg], f32x2 (&X)[kRunIn], const lds_ro_f32_ptr slabR) {
         wave_lds_sync();
 #pragma unroll
         for (int a = 0; a < 4; ++a) slabW[a * (kSlabP / 2)] = f32x2{v8[2 * a], v8[2 * a + 1]};
@@ -800,14 +824,10 @@ __device__ __forceinline__ void prefilter_unit(
 #define LFG_ONEPOINT_MAX 32.0f
 #endif
         constexpr float kOnePointMax = LFG_ONEPOINT_MAX;   // below: the one-point test alone (cheap, and strong while thresholds are small)
-        bool useFourPoint = true;
+        bool useFourPoint = true, useSixteen = LFG_SIXTEEN != 0;
         // bit k of the result: candidate i0 + k of the staged order has to be evaluated in full
-        auto latticeBatch = [&](int i0, int count, uint32_t &ordL) -> unsigned long long {
-            uint32_t l;                    // lane number; volatile, so that it is not hoisted out of the loop and spilled
-            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(l));
-            const int idx = i0 + (int)l;
-            ordL = ((lds_ro_u32_ptr)sOrder)[min(idx < nHead ? idx : eBegin + (idx - nHead), kCand - 1)];
-            bool need = (int)l < count && idx < nEntries && (ordL & 0xFFFFu) < zeroBound;
+        // (ordL: this lane's candidate, an entry of the order; need: it has to be looked at; fullBatch: 64 candidates)
+        auto latticeBatch = [&](const uint32_t ordL, bool need, const bool fullBatch) -> unsigned long long {
 #ifndef LFG_ONEPOINT_OFF
 #define LFG_ONEPOINT_OFF 96.0f
 #endif
@@ -908,7 +928,72 @@ __device__ __forceinline__ void prefilter_unit(
                     if (a & 1) asm volatile("" : "+v"(w), "+v"(pMin));
                 }
                 need = need & !(pMin > bitsOf(waveThr * 1.000002f));
-                if (count == 64 && __builtin_popcountll(__ballot(need)) >= 48) useFourPoint = false;
+                if (fullBatch && __builtin_popcountll(__ballot(need)) >= 48) useFourPoint = false;
+            }
+#ifndef LFG_SIXTEEN_MAX
+#define LFG_SIXTEEN_MAX 2048.0f
+#endif
+            if (useSixteen && !(waveThr < kOnePointMax) && waveThr < LFG_SIXTEEN_MAX && __builtin_popcountll(__ballot(need)) > 8) {
+                // SIXTEEN-point test, where four distances do not reach the threshold either: a match that is only nearly
+                // exact -- the rows and columns the upscaler filters differently next to the border, compression noise --
+                // costs several hundred, a wrong candidate ten thousand, and four of its 64 distances sum to 830 +- 140, of
+                // which the smallest of a segment's 75 groups is often below 500.  The block positions with both
+                // coordinates even form a lattice of 12 x 32 points of which every pixel's 8 x 8 block holds exactly a
+                // 4 x 4 group (rows 2a .. 2a + 6 with a = ceil(r / 2) for pixel row r, columns likewise), and
+                // S~ >= (the sum of those sixteen distances) (1 - 10.1 u): S~ adds the same rounded distances in a depth-6
+                // tree, the group sum here in four levels.  Mean 3,300: every wrong candidate falls to it while the
+                // threshold stays below 2,048.  The lane walks the lattice column by column -- twelve distances, eleven
+                // pair sums, nine vertical sums of four, and the running sums over four columns -- 4,400 instructions per
+                // batch of 64 candidates: a sixth of evaluating them.  A rolled loop (the code of 32 columns would not
+                // fit the instruction cache); positions outside the image add nothing, groups that no pixel inside the
+                // image maps to are left out.
+                auto bitsOf = [](float d) { return __builtin_bit_cast(uint32_t, d); };
+                lds_ro_u32_ptr w = (lds_ro_u32_ptr)(sWin + kSeg * seg) + (ordL >> 16);
+                uint32_t gMin = 0x7F800000u;
+                float vOld[9], hOld[2][9];
+#pragma unroll
+                for (int a = 0; a < 9; ++a) { vOld[a] = 0.0f; hOld[0][a] = 0.0f; hOld[1][a] = 0.0f; }
+                int rowsL = ty0 + kSeg * seg;
+                asm volatile("" : "+s"(rowsL));
+                uint32_t rowRelevant = 0u;                              // bit a: some pixel row inside the image maps to vertical group a
+#pragma unroll
+                for (int a = 0; a < 9; ++a) rowRelevant |= (!border || rowsL + max(0, 2 * a - 1) < H) ? (1u << a) : 0u;
+#pragma unroll 2
+                for (int t = 0; t < 32; ++t) {
+                    int colL = 2 * t;
+                    asm volatile("" : "+s"(colL));
+                    uint32_t tex[12];
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) tex[k] = w[2 * k];
+                    const uint32_t inImage = border ? (uint32_t)__builtin_amdgcn_readlane((int)valid, colL) : 0xFFFFFFFFu;
+                    float d[12];
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) {
+                        const float dd = __builtin_amdgcn_sqrtf(distanceOf((uint32_t)__builtin_amdgcn_readlane((int)c[2 * k], colL), tex[k]));
+                        const uint32_t keep = 0u - ((inImage >> (2 * k)) & 1u);       // scalar: all ones or zero
+                        d[k] = border ? __builtin_bit_cast(float, bitsOf(dd) & keep) : dd;
+                    }
+                    float pr[11], v[9];
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) pr[k] = d[k] + d[k + 1];
+#pragma unroll
+                    for (int a = 0; a < 9; ++a) v[a] = pr[a] + pr[a + 2];
+                    // columns t-1, t; with the pair sum of columns t-3, t-2 the group b = t - 3, whose first pixel
+                    // column is max(0, 2 b - 1)
+                    const bool colRelevant = t >= 3 && (!border || tx0 + max(0, 2 * (t - 3) - 1) < W);
+                    const int sel = t & 1;                             // hOld[sel] holds the pair sum made two columns ago
+#pragma unroll
+                    for (int a = 0; a < 9; ++a) {
+                        const float h = vOld[a] + v[a];
+                        const uint32_t g = bitsOf((sel ? hOld[1][a] : hOld[0][a]) + h);
+                        gMin = min(gMin, (colRelevant && ((rowRelevant >> a) & 1u)) ? g : 0x7F800000u);
+                        if (sel) hOld[1][a] = h; else hOld[0][a] = h;
+                        vOld[a] = v[a];
+                    }
+                    w += 2 * kWinH;
+                }
+                need = need & !(gMin > bitsOf(waveThr * 1.000002f));
+                if (fullBatch && __builtin_popcountll(__ballot(need)) >= 48) useSixteen = false;
             }
             return __ballot(need);
         };
@@ -947,10 +1032,22 @@ __device__ __forceinline__ void prefilter_unit(
         // which run the first eight for their thresholds see the same boundary); then sixty-four at a time.
         const int hintsEnd = nHead ? kHead : max(kHead, min((int)order32[kCand + 1], 2 + 62));
         int firstBatchSurvivors = 0;
-        for (int i0 = 0, count = 2; i0 < nEntries; i0 += count, count = i0 == 2 ? hintsEnd - 2 : 64) {
+        // BY RANK.  Once every pixel of the wave owns a zero-cost candidate only candidates that come EARLIER in the tie
+        // order than the latest of those can still matter (zeroBound).  Walking on through the visiting order would
+        // look at every remaining batch for the few lanes whose rank qualifies; instead the wave turns to the ranks
+        // themselves -- 0 .. zeroBound - 1, sixty-four per batch, through the inverse of the order (sInv), leaving out
+        // what it has visited already or what belongs to another part of the order.  Under a pan or on a static frame
+        // that is zeroBound / 64 batches instead of seventeen; the candidates looked at are the same.
+        bool byRank = false;
+        int rank0 = 0, visited = 0;
+        for (int i0 = 0, count = 2;;) {
+            if (byRank ? rank0 >= (int)min(zeroBound, (uint32_t)kCand) : i0 >= nEntries) break;
+            if (!byRank && i0 >= max(nHead, 2) && zeroBound < (uint32_t)kCand && (int)zeroBound + 64 <= nEntries - i0) {
+                byRank = true; rank0 = 0; visited = i0;
+            }
             // Hand the segment over?  Either no threshold to test against once every hint has been tried, or the test
             // let a quarter of the first full batch through.
-            if (whole && !fromQueue && order32[kCand] != 0u &&
+            if (!byRank && whole && !fromQueue && order32[kCand] != 0u &&
                 ((i0 == hintsEnd && !(waveThr < 4.0f * 510.0f)) || (i0 == hintsEnd + 64 && firstBatchSurvivors >= 16))) {
                 // LFG_DYN_PARTS parts of the candidate order, four per queue entry (one workgroup each); the entries of a
                 // segment are consecutive slots, so its private lists are the blocks 4 slot .. 4 slot + parts - 1
@@ -968,13 +1065,33 @@ __device__ __forceinline__ void prefilter_unit(
                     return 2;
                 }
             }
+#ifdef LFG_MOTION_STAMPS
+            if (i0 == hintsEnd) stampThr = __builtin_bit_cast(uint32_t, waveThr);
+            stampThrEnd = __builtin_bit_cast(uint32_t, waveThr);
+            stampFour = useFourPoint ? 1u : 0u;
+#endif
             uint32_t ordL;
-            unsigned long long m = latticeBatch(i0, count, ordL);
-            if (i0 == hintsEnd) firstBatchSurvivors = __builtin_popcountll(m);
+            bool need;
+            {
+                uint32_t l;                // lane number; volatile, so that it is not hoisted out of the loop and spilled
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(l));
+                if (!byRank) {
+                    const int idx = i0 + (int)l;
+                    ordL = ((lds_ro_u32_ptr)sOrder)[min(idx < nHead ? idx : eBegin + (idx - nHead), kCand - 1)];
+                    need = (int)l < count && idx < nEntries && (ordL & 0xFFFFu) < zeroBound;
+                } else {
+                    const int r = rank0 + (int)l;
+                    const int e = (int)sInv[min(r, kCand - 1)];                       // where the order visits rank r
+                    ordL = ((lds_ro_u32_ptr)sOrder)[e];
+                    need = r < (int)zeroBound && e >= eBegin && e < eEnd && nHead + (e - eBegin) >= visited;
+                }
+            }
+            unsigned long long m = latticeBatch(ordL, need, byRank || count == 64);
+            if (!byRank && i0 == hintsEnd) firstBatchSurvivors = __builtin_popcountll(m);
 #ifdef LFG_MOTION_STAMPS
             stampBatches += 1u; stampEvals += (unsigned)__builtin_popcountll(m);
 #endif
-            if (m == 0ull) continue;
+            if (m != 0ull) {
             // The survivors, software-pipelined: the window reads of one are in flight while the previous one is
             // finished; a last pass drains the pipeline.
             bool pending = false;
@@ -986,14 +1103,14 @@ __device__ __forceinline__ void prefilter_unit(
                     const int b = __builtin_ctzll(m);
                     m &= m - 1ull;
                     ord = (uint32_t)__builtin_amdgcn_readlane((int)ordL, b);
-                    cntIt = (i0 + b) >= nHead ? 1u : 0u;
+                    cntIt = (byRank || (i0 + b) >= nHead) ? 1u : 0u;
                     fetchWindow(p, ord);
                 }
                 if (pending) rowSumsAndTest(x, ordP, cntP);
                 __builtin_amdgcn_sched_barrier(0);
                 if (have) {
-                    columnSums(p, v8);
-                    transpose(v8, x);
+                    columnSums(p, c, cc, valid, v8);
+                    transpose(v8, x, slabR);
                 }
                 ordP = ord; cntP = cntIt; pending = have;
             }
@@ -1001,19 +1118,23 @@ __device__ __forceinline__ void prefilter_unit(
             if (__builtin_amdgcn_readfirstlane(__ballot(listsOverflowed()) != 0ull)) sGiveUp = 1u;
             if (__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)&sGiveUp) != 0) return 1;
             refreshZeroBound();
+            }
 #ifdef LFG_MOTION_STAMPS
-            if (i0 == 0) stampFirst = __builtin_amdgcn_s_memrealtime();
+            if (!byRank && i0 == 0) stampFirst = __builtin_amdgcn_s_memrealtime();
 #endif
+            if (byRank) rank0 += 64;
+            else { i0 += count; count = i0 == 2 ? hintsEnd - 2 : 64; }
         }
         return __builtin_amdgcn_readfirstlane(__ballot(listsOverflowed()) != 0ull) ? 1 : 0;
     };
     const int outcome = run();
     const bool gaveUp = outcome == 1;
 #ifdef LFG_MOTION_STAMPS
-    if (lane == 0 && !fromQueue && unit < 8192) {
-        unsigned long long *o = gMotionStamps + ((size_t)unit * 4 + wave) * 8;
+    if (lane == 0 && (fromQueue ? sp.units + unit : unit) < 8192) {
+        unsigned long long *o = gMotionStamps + ((size_t)(fromQueue ? sp.units + unit : unit) * 4 + wave) * 8;
         o[0] = stampStart; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = stampEvals; o[3] = ((unsigned long long)borderTile << 32) | stampBatches;
-        o[4] = stampStaged; o[5] = stampFirst;
+        o[4] = stampStaged; o[5] = stampFirst; o[6] = (stampFour << 8) | ((unsigned long long)(fromQueue ? 1u : 0u) << 9) | ((unsigned long long)seg << 10) | ((unsigned long long)tileX << 12) | ((unsigned long long)tileY << 20);
+        o[7] = ((unsigned long long)stampThrEnd << 32) | stampThr;
     }
 #endif
     if (gaveUp) {
@@ -1265,7 +1386,12 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
     __shared__ uint32_t sOrder[kCand + 7];                             // the visiting order
     __shared__ uint32_t sGiveUp;
     __shared__ uint32_t sNext[2];                                      // {unit | fromQueue << 31, its table entry}
-    for (int i = threadIdx.x; i < kCand; i += kPNT) sOrder[i] = order32[i];      // once: the same for every unit
+    __shared__ uint16_t sInv[kCand + 1];                               // its inverse: where the order visits rank r
+    for (int i = threadIdx.x; i < kCand; i += kPNT) {                  // once: the same for every unit
+        const uint32_t o = order32[i];
+        sOrder[i] = o;
+        sInv[min(o & 0xFFFFu, (uint32_t)kCand)] = (uint16_t)i;
+    }
     // Thread 0 hands out the work.  Plan units: ctrl[0] is the next index (fetch-and-add).  Queue slots: ctrl[2] is the
     // next slot, also fetch-and-add -- a compare-and-swap loop collapses when hundreds of workgroups run out of plan
     // units together -- so a workgroup can come to OWN a slot that no segment has been pushed into yet.  It keeps the
@@ -1321,7 +1447,7 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
         if (next == kNoUnit) return;
         const bool fromQueue = (next >> 31) != 0u;
         prefilter_unit(prev, prevPitch, curr, currPitch, W, H, list, uminOut, countOut, tileFlags, flagTilesX, order32, sp,
-                       mv, mvPitch, rank2scan, segDone, (int)(next & 0x7FFFFFFFu), fromQueue, entry, sWin, sSlab, sOrder, sGiveUp);
+                       mv, mvPitch, rank2scan, segDone, (int)(next & 0x7FFFFFFFu), fromQueue, entry, sWin, sSlab, sOrder, sInv, sGiveUp);
         if (!fromQueue) {
             __syncthreads();               // every wave of the unit is past its pushes
             if (threadIdx.x == 0) atomicAdd(&ctrl[1], 1u);
@@ -1739,6 +1865,23 @@ PrefilterPlanHost prefilter_plan(uint32_t width, uint32_t height, int slots) {
             }
         }
     }
+    // Dispatch order.  Workgroups draw units in table order and the device holds only so many at once; the long units are
+    // the segments that touch the image border itself (the strip a pan exposes lies there, and so do the rows and columns the
+    // upscaler filters differently), so those go first -- all of them start at once -- then the other segments of the rim
+    // tiles, then the interior.
+    {
+        auto touchesBorder = [&](uint32_t um) {
+            if (((um >> 28) & 1u) == 0u) return false;
+            const int t = (int)(um & 0xFFFFFu), seg = (int)((um >> 29) & 3u);
+            const int ty = t / p.tilesX, tx = t - ty * p.tilesX;
+            const int bx0 = tx * kPTW - kB / 2, by0 = ty * kPTH - kB / 2 + kSeg * seg;
+            return !((bx0 >= 0) && (bx0 + kPTW + kB - 2 < W) && (by0 >= 0) && (by0 + kSegD - 1 < H));
+        };
+        std::vector<std::pair<uint32_t, uint32_t>> units(p.unitMap.size());
+        for (size_t i = 0; i < units.size(); ++i) units[i] = {p.unitMap[i], p.unitAux[i]};
+        std::stable_partition(units.begin(), units.end(), [&](const std::pair<uint32_t, uint32_t> &u) { return touchesBorder(u.first); });
+        for (size_t i = 0; i < units.size(); ++i) { p.unitMap[i] = units[i].first; p.unitAux[i] = units[i].second; }
+    }
     p.units = (int)p.unitMap.size();
     return p;
 }
@@ -1977,6 +2120,9 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
                        (int8_t *)mv.data, (int)mv.pitch, rank2scan, segDone, reinterpret_cast<uint32_t *>(workspace + l.ctrl));
     e = hipGetLastError();
     if (e != hipSuccess) return e;
+#ifdef LFG_DIAG_NO_SLOW
+    return hipSuccess;                 // (timing experiment: the prefilter alone; its output is not fit for the resolve kernel)
+#endif
 #ifdef LFG_MOTION_STAMPS
     {
         static int calls = 0;
@@ -1987,20 +2133,51 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
             const int n = std::min(sp.units, 8192);
             unsigned long long t0 = ~0ull, t1 = 0;
             for (int u = 0; u < n; ++u) for (int w = 0; w < 4; ++w) { const unsigned long long *o = &h[(u * 4 + w) * 8]; if (!o[1]) continue; t0 = std::min(t0, o[0]); t1 = std::max(t1, o[1]); }
-            double sum[2] = {0, 0}, mx[2] = {0, 0}, ev[2] = {0, 0}, stg[2] = {0, 0}, fst[2] = {0, 0}; int cnt[2] = {0, 0};
+            double sum[2] = {0, 0}, mx[2] = {0, 0}, ev[2] = {0, 0}, stg[2] = {0, 0}, fst[2] = {0, 0}, bat[2] = {0, 0}; int cnt[2] = {0, 0};
             for (int u = 0; u < n; ++u) {
-                unsigned long long a = ~0ull, b = 0, evals = 0; int rim = 0; double st = 0, fs = 0;
-                for (int w = 0; w < 4; ++w) { const unsigned long long *o = &h[(u * 4 + w) * 8]; if (!o[1]) continue; a = std::min(a, o[0]); b = std::max(b, o[1]); evals += o[2]; rim = (int)(o[3] >> 32);
+                unsigned long long a = ~0ull, b = 0, evals = 0, batches = 0; int rim = 0; double st = 0, fs = 0;
+                for (int w = 0; w < 4; ++w) { const unsigned long long *o = &h[(u * 4 + w) * 8]; if (!o[1]) continue; a = std::min(a, o[0]); b = std::max(b, o[1]); evals += o[2]; batches += o[3] & 0xFFFFFFFFull; rim = (int)(o[3] >> 32);
                     st = std::max(st, (double)(o[4] - o[0]) / 100.0); if (o[5]) fs = std::max(fs, (double)(o[5] - o[4]) / 100.0); }
                 if (!b) continue;
                 const double us = (double)(b - a) / 100.0;
-                sum[rim] += us; mx[rim] = std::max(mx[rim], us); ev[rim] += (double)evals / 4; stg[rim] += st; fst[rim] += fs; ++cnt[rim];
+                sum[rim] += us; mx[rim] = std::max(mx[rim], us); ev[rim] += (double)evals / 4; bat[rim] += (double)batches / 4; stg[rim] += st; fst[rim] += fs; ++cnt[rim];
                 if (u % 197 == 0) fprintf(stderr, "unit %d rim %d start %.1f us dur %.1f us evals/wave %.1f\n", u, rim, (double)(a - t0) / 100.0, us, (double)evals / 4);
             }
             for (int r = 0; r < 2; ++r)
-                fprintf(stderr, "%s units %d: mean %.1f us (staging %.1f, first batch %.1f), max %.1f us, evaluations per wave %.1f\n", r ? "rim" : "interior", cnt[r],
-                        sum[r] / std::max(cnt[r], 1), stg[r] / std::max(cnt[r], 1), fst[r] / std::max(cnt[r], 1), mx[r], ev[r] / std::max(cnt[r], 1));
+                fprintf(stderr, "%s units %d: mean %.1f us (staging %.1f, first batch %.1f), max %.1f us, evaluations per wave %.1f, batches per wave %.1f\n", r ? "rim" : "interior", cnt[r],
+                        sum[r] / std::max(cnt[r], 1), stg[r] / std::max(cnt[r], 1), fst[r] / std::max(cnt[r], 1), mx[r], ev[r] / std::max(cnt[r], 1), bat[r] / std::max(cnt[r], 1));
             fprintf(stderr, "span %.1f us\n", (double)(t1 - t0) / 100.0);
+            {   // handed-over segments (queue units follow the plan's units in the stamp array)
+                unsigned long long qa = ~0ull, qb = 0, qlast = 0; double qsum = 0; int qn = 0; double qev = 0;
+                for (int u = n; u < 8192; ++u) for (int w = 0; w < 4; ++w) {
+                    const unsigned long long *o = &h[(u * 4 + w) * 8]; if (!o[1] || !((o[6] >> 9) & 1)) continue;
+                    qa = std::min(qa, o[0]); qlast = std::max(qlast, o[0]); qb = std::max(qb, o[1]); qsum += (double)(o[1] - o[0]) / 100.0; qev += (double)o[2]; ++qn;
+                    t1 = std::max(t1, o[1]);
+                }
+                if (qn) fprintf(stderr, "queue units: %d waves, first start %.1f, last start %.1f, last end %.1f us, mean duration %.1f us, evaluations per wave %.1f\n", qn,
+                                (double)(qa - t0) / 100.0, (double)(qlast - t0) / 100.0, (double)(qb - t0) / 100.0, qsum / qn, qev / qn);
+                unsigned long long pe = 0; for (int u = 0; u < n; ++u) for (int w = 0; w < 4; ++w) { const unsigned long long *o = &h[(u * 4 + w) * 8]; if (o[1]) pe = std::max(pe, o[1]); }
+                fprintf(stderr, "plan units: last end %.1f us\n", (double)(pe - t0) / 100.0);
+            }
+            {   // the waves that finish last
+                std::vector<std::pair<unsigned long long, int>> ends;
+                for (int u = 0; u < n; ++u) for (int w = 0; w < 4; ++w) { const unsigned long long *o = &h[(u * 4 + w) * 8]; if (o[1]) ends.push_back({o[1], u * 4 + w}); }
+                std::sort(ends.begin(), ends.end());
+                for (size_t i = ends.size() > 14 ? ends.size() - 14 : 0; i < ends.size(); ++i) {
+                    const unsigned long long *o = &h[(size_t)ends[i].second * 8];
+                    fprintf(stderr, "  late: unit %d wave %d tile (%d,%d) seg %d start %.1f end %.1f us, evals %llu, batches %llu, staged after %.1f us\n", ends[i].second / 4, ends[i].second % 4,
+                            (int)((o[6] >> 12) & 0xFF), (int)((o[6] >> 20) & 0xFF), (int)((o[6] >> 10) & 3), (double)(o[0] - t0) / 100.0, (double)(o[1] - t0) / 100.0, o[2], o[3] & 0xFFFFFFFFull, (double)(o[4] - o[0]) / 100.0);
+                }
+            }
+            {   // a sample of the waves that evaluated more than 100 candidates in full: where, and against which thresholds
+                int shown = 0;
+                for (int u = 0; u < n; ++u) for (int w = 0; w < 4; ++w) {
+                    const unsigned long long *o = &h[(u * 4 + w) * 8]; if (!o[1]) continue;
+                    if (o[2] > 100 && (u % 7) == 0 && w == 1 && shown < 24) { ++shown;
+                        const uint32_t ta = (uint32_t)o[7], tb = (uint32_t)(o[7] >> 32); float fa, fb; memcpy(&fa, &ta, 4); memcpy(&fb, &tb, 4);
+                        fprintf(stderr, "  tile (%d,%d) seg %d: unit %d wave %d evals %llu dur %.1f us  waveThr after hints %.1f, at last batch %.1f, four-point still on %d\n", (int)((o[6] >> 12) & 0xFF), (int)((o[6] >> 20) & 0xFF), (int)((o[6] >> 10) & 3), u, w, o[2], (double)(o[1] - o[0]) / 100.0, fa, fb, (int)((o[6] >> 8) & 1)); }
+                }
+            }
             unsigned long long rs[12];
             hipMemcpyFromSymbol(rs, HIP_SYMBOL(gResolveStats), sizeof(rs));
             fprintf(stderr, "resolve (previous calls together): %llu working waves, mean gather %.2f us, mean rest %.2f us, longest wave %.1f us, "

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 C=${1:-translated}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pm_$C
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pm_$C -- python3 $R/tools/run_stage.py motion 20 $C > /tmp/pm_$C.out 2>&1
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pm_$C -- python3 $R/tools/run_stage.py motion 20 $C > /tmp/pm_$C.out 2>&1
 python3 - $(find /tmp/pm_$C -name "*kernel_stats.csv" | head -1) <<'PY'
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
