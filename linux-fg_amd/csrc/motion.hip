@@ -361,6 +361,21 @@ constexpr int kRunIn = kRun + kB - 1;             // 13
 #ifndef LFG_SIXTEEN
 #define LFG_SIXTEEN 1
 #endif
+// Narrow search (prefilter_unit, "Narrow search"): the band of pixel columns that holds a segment's pixels without a
+// match, at most sixteen columns wide, searched several candidates per pass.
+#ifndef LFG_NARROW
+#define LFG_NARROW 1
+#endif
+#ifndef LFG_NARROW_THR
+#define LFG_NARROW_THR 2048.0f                    // a pixel whose threshold is still this large after the hints has no match
+                                                  // (below it the sixteen-point test still drops wrong candidates)
+#endif
+constexpr int kNarrowMax = 16;                    // pixel columns of the band at most
+constexpr int kNarrowPitch = 164;                 // slab pitch of a row pair in the narrow passes (floats): = 4 mod 32, so the
+                                                  // transposed reads of 16 rows x 2 column groups fall into 32 distinct banks
+constexpr int kNarrowQ = 20;                      // ... whose columns are stored four-way interleaved (column c at (c & 3) * 20 + c / 4)
+constexpr int kSlabFloats = 8 * kNarrowPitch;     // a wave's slab: 4 row pairs x kSlabP (wide), 8 row pairs x kNarrowPitch (narrow)
+static_assert(kSlabFloats >= 4 * kSlabP && 2 * (3 * kNarrowQ + 15) + 1 < kNarrowPitch, "both layouts fit");
 #ifndef LFG_HINT_GRID
 #define LFG_HINT_GRID 16
 #endif
@@ -425,14 +440,14 @@ __device__ __forceinline__ void prefilter_unit(
     const uint32_t *__restrict__ order32, const PrefilterPlan &sp,
     int8_t *__restrict__ mv, int mvPitch, const uint32_t *__restrict__ rank2scan, uint32_t *__restrict__ segDone,
     const int unit, const bool fromQueue, const uint32_t um,
-    uint32_t *sWin, float (*sSlab)[4 * kSlabP], uint32_t *sOrder, const uint16_t *sInv, uint32_t &sGiveUp) {
+    uint32_t *sWin, float (*sSlab)[kSlabFloats], uint32_t *sOrder, const uint16_t *sInv, uint32_t &sGiveUp, uint32_t (*sNarrow)[2 * kSeg * kNarrowMax]) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         // wave index 0..3
 #ifdef LFG_MOTION_STAMPS
     const unsigned long long stampStart = __builtin_amdgcn_s_memrealtime();
-    unsigned stampEvals = 0u, stampBatches = 0u, stampThr = 0u, stampThrEnd = 0u, stampFour = 0u;
+    unsigned stampEvals = 0u, stampBatches = 0u, stampBox = 0u, stampNarrow = 0u, stampThr = 0u, stampThrEnd = 0u, stampFour = 0u;
     unsigned long long stampStaged = 0ull, stampFirst = 0ull;
 #endif
     // Work units (PrefilterPlan).  A tile is 4 segments of 16 rows, and a workgroup is either
@@ -1028,6 +1043,225 @@ __device__ __forceinline__ void prefilter_unit(
                 return 0;
             }
         }
+        // ---- Narrow search.  A segment that holds pixels without any match searches in full: no test can drop a
+        // candidate for the whole wave, and every candidate costs a full evaluation of all 16 x 56 pixels although only
+        // the unmatched ones can still record anything.  Often those lie in a narrow band of columns -- the strip a pan
+        // exposes at the left or right edge (ten columns for the benchmark's motion), the vertical edge of a moving
+        // object or of an occlusion: two thirds of the full-search waves on the benchmark's pan, a fifth to a third on
+        // the occluded and moving-object frames.  Once the hints have been tried the wave looks at its thresholds: if
+        // every pixel that is still above LFG_NARROW_THR lies within W <= 16 columns (W a multiple of four), those
+        // columns leave the wide machinery -- their thresholds and counts move to LDS, the registers hold -inf, which
+        // never passes a test and does not count in waveThr, so the lattice tests work again for the rest of the
+        // segment -- and are searched AFTER the wide batches, K = 64 / (W + 8) candidates per pass (5 | 4 | 3 | 2):
+        //   * lanes (candidate k, position column j) compute the band's W + 7 position columns for K candidates side
+        //     by side: window reads, distances and column sums are the wide code with per-lane offsets;
+        //   * the slab holds all sixteen rows (pitch 164, columns interleaved four ways: writes and reads conflict-free);
+        //   * lanes (pixel row, group of four columns) then take the K candidates one after the other: eleven reads,
+        //     22 adds, four comparisons each, with the pixel's threshold, count and list handled by this one lane as
+        //     in the wide code -- nothing shared, no atomics.
+        // Distances and column sums, two thirds of an evaluation, are paid once per K candidates, the row sums cover
+        // 16 x W pixels instead of 16 x 56.  At the end thresholds and counts go back to the lanes that own the pixels
+        // in the wide layout and the epilogue runs unchanged.
+        // (After the wide batches, not between them: by then the wide machinery's registers -- the lane's 23
+        //  current-frame texels and their squares above all -- are free.  Interleaved, the two sets did not fit and
+        //  every pass waited for scratch reloads behind its own record stores.)
+        bool narrow = false;
+        int nXb = 0, nW = 0;                                           // the band: pixel columns nXb .. nXb + nW - 1 of the tile
+        uint32_t *const nThr = sNarrow[wave];                          // [16][kNarrowMax] threshold words (float bits)
+        uint32_t *const nCnt = nThr + kSeg * kNarrowMax;               // [16][kNarrowMax] records so far | plateau member seen << 31
+        auto entryOf = [&](int idx) { return min(idx < nHead ? idx : eBegin + (idx - nHead), kCand - 1); };
+        auto enterNarrow = [&]() {
+            int lo = 99, hi = -1;
+#pragma unroll
+            for (int i = 0; i < kRun; ++i) {
+                const float fx = thr2[i].x, fy = thr2[i].y;            // (-inf: outside the image; +inf: nothing yet)
+                if (fx >= LFG_NARROW_THR || fy >= LFG_NARROW_THR) { lo = min(lo, kRun * q + i); hi = max(hi, kRun * q + i); }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_xor(lo, off)); hi = max(hi, __shfl_xor(hi, off)); }
+            lo = __builtin_amdgcn_readfirstlane(lo); hi = __builtin_amdgcn_readfirstlane(hi);
+            if (hi < lo || hi - lo >= kNarrowMax) return;
+            nW = ((hi - lo) / 4 + 1) * 4;
+            nXb = min(lo, kPTW - nW);
+            wave_lds_sync();
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+                for (int i = 0; i < kRun; ++i) {
+                    const int col = kRun * q + i - nXb;
+                    if (col >= 0 && col < nW) {
+                        const int cell = (8 * hb + r8) * kNarrowMax + col;
+                        const float fx = thr2[i].x, fy = thr2[i].y;
+                        nThr[cell] = __builtin_bit_cast(uint32_t, hb ? fy : fx);
+                        nCnt[cell] = ((cnt2[hb][i >> 1] >> (16 * (i & 1))) & 0xFFFFu) | (((plateauSeen >> (kRun * hb + i)) & 1u) << 31);
+                        if (hb) thr2[i].y = -__builtin_inff(); else thr2[i].x = -__builtin_inff();
+                    }
+                }
+            }
+            wave_lds_sync();
+            narrow = true;
+#ifdef LFG_MOTION_STAMPS
+            stampNarrow = (unsigned)(64 / ((nW + kB - 1 + 3) & ~3));
+#endif
+        };
+        auto narrowPhase = [&](int iBegin) -> bool {
+            const int iEnd = nEntries;
+            const int groups = nW / 4;
+            const int colsPer = (nW + kB - 1 + 3) & ~3;                // 12 | 16 | 20 | 24 slab columns per candidate
+            const int perPass = 64 / colsPer;                          // 5 | 4 | 3 | 2 candidates
+            // compute side: lane = (candidate kc, position column nXb + cl); spare lanes repeat the last one
+            int kc = lane / colsPer, cl = lane - kc * colsPer;
+            if (kc >= perPass) { kc = perPass - 1; cl = colsPer - 1; }
+            const int pcol = min(nXb + cl, kPTW + kB - 2);             // (the padding columns of a candidate compute sums nobody reads)
+            const lds_ro_u32_ptr nWin = (lds_ro_u32_ptr)(sWin + pcol * kWinH + kSeg * seg);
+            uint32_t cN[kSegD], ccN[kSegD], nValid = 0u;
+            {
+                const int gx = bx0 + pcol;
+#pragma unroll
+                for (int j = 0; j < kSegD; ++j) {
+                    const int gy = by0 + kSeg * seg + j;
+                    const bool ok = gx >= 0 && gx < W && gy >= 0 && gy < H;
+                    cN[j] = ok ? *reinterpret_cast<const uint32_t *>(curr + (size_t)gy * (size_t)currPitch + (size_t)gx * 4u) : 0u;
+                    nValid |= (ok ? 1u : 0u) << j;
+                }
+#pragma unroll
+                for (int j = 0; j < kSegD; ++j) ccN[j] = __builtin_amdgcn_udot4(cN[j], cN[j], 0x4B000000u, false);
+            }
+            f32x2 *const nSlabW = reinterpret_cast<f32x2 *>(sSlab[wave]) + ((lane & 3) * kNarrowQ + (lane >> 2));    // slab column = lane
+            // read side: lane = (pixel row r, group g of four columns)
+            const int r = lane & 15, g = lane >> 4;
+            const bool active = g < groups;
+            float thrN[4];
+            uint32_t cntN[4], platN = 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cell = r * kNarrowMax + 4 * (active ? g : 0) + j;
+                const uint32_t w = nCnt[cell];
+                thrN[j] = active ? __builtin_bit_cast(float, nThr[cell]) : -__builtin_inff();
+                cntN[j] = w & 0xFFFFu;
+                platN |= (w >> 31) << j;
+            }
+            // column sum i (0..10) of candidate k for this lane: slab column c = colsPer k + 4 g + i, stored at (c & 3) kNarrowQ + c / 4
+            const lds_ro_f32_ptr nSlabR = (lds_ro_f32_ptr)(sSlab[wave] + (r >> 1) * kNarrowPitch + (r & 1) + 2 * (active ? g : 0));
+            const uint32_t nLaneOff = (uint32_t)r * ((uint32_t)kListK * rowStride) + (uint32_t)(nXb + 4 * g);
+            const int segY0 = ty0 + kSeg * seg;
+            auto testCandidate = [&](const float (&X)[4 + kB - 1], uint32_t ord, uint32_t countIt) {
+                float h2[10], h4[8], sN[4];
+#pragma unroll
+                for (int i = 0; i < 10; ++i) h2[i] = X[i] + X[i + 1];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) h4[i] = h2[i] + h2[i + 2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sN[i] = h4[i] + h4[i + 4];
+                float top = thrN[0] - sN[0];
+#pragma unroll
+                for (int j = 1; j < 4; ++j) top = __builtin_fmaxf(top, thrN[j] - sN[j]);
+                if (__builtin_amdgcn_readfirstlane(__ballot(top >= 0.0f) == 0ull)) return;
+                const uint32_t cand = ord & 0xFFFFu;
+                const int candDx = (int)((ord >> 16) / (uint32_t)kWinH) - kR, candDy = (int)((ord >> 16) % (uint32_t)kWinH) - kR;
+                const uint32_t zeroCap = 0x00800000u + cand;
+                const bool candMayLeave = windowLeavesPrev &&
+                    block_leaves_prev_any(tx0 + nXb, min(tx0 + nXb + nW - 1, W - 1), segY0, min(segY0 + kSeg - 1, H - 1), candDx, candDy, W, H);
+                unsigned long long hit[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hit[j] = __ballot(sN[j] <= thrN[j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (hit[j] != 0ull) {                              // wave-uniform
+                        asm volatile("; some lane records a candidate (narrow)");
+                        const float s = sN[j];
+                        if (s <= thrN[j]) {                            // (the rules of rowSumsAndTest)
+                            const float cap = __builtin_fmaxf(s * kRatio, __builtin_bit_cast(float, zeroCap));
+                            thrN[j] = __builtin_fminf(thrN[j], cap);
+                            const uint32_t at = __umul24(min(cntN[j], (uint32_t)kListK - 1u), rowStride) + nLaneOff + (uint32_t)j;
+                            if (s != 0.0f) waveList[at] = rec_make(s, cand);
+                            uint32_t inc = (s != 0.0f && countIt != 0u) ? 1u : 0u;
+                            if (candMayLeave) {
+                                uint32_t l;
+                                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(l));
+                                const bool plateau = block_leaves_prev(tx0 + nXb + 4 * (int)(l >> 4) + j, segY0 + (int)(l & 15u), candDx, candDy, W, H);
+                                inc = (plateau && ((platN >> j) & 1u) != 0u) ? 0u : inc;
+                                platN |= (plateau && inc != 0u) ? (1u << j) : 0u;
+                            }
+                            cntN[j] += inc;
+                        }
+                    }
+                }
+            };
+            uint32_t p[kSegD];
+            float v8[kSeg];
+            bool pending = false;
+            int idx0 = iBegin, idxP = 0, started = 0;
+            for (;;) {
+                const bool have = idx0 < iEnd && started < 64;
+                if (!have && !pending) {                               // (the pipeline has drained) every 64 entries: give up?
+                    if (idx0 >= iEnd) break;
+                    started = 0;
+                    const bool over = cntN[0] > (uint32_t)kListK || cntN[1] > (uint32_t)kListK || cntN[2] > (uint32_t)kListK || cntN[3] > (uint32_t)kListK;
+                    if (__builtin_amdgcn_readfirstlane(__ballot(over) != 0ull)) sGiveUp = 1u;
+                    if (__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)&sGiveUp) != 0) return false;
+                    continue;
+                }
+                if (have) {
+                    const uint32_t ordC = ((lds_ro_u32_ptr)sOrder)[entryOf(min(idx0 + kc, iEnd - 1))];
+                    const lds_ro_u32_ptr w = nWin + (ordC >> 16);
+#pragma unroll
+                    for (int j = 0; j < kSegD; ++j) p[j] = w[j];
+                }
+                if (pending) {             // the slab holds the previous pass: sixteen rows of perPass candidates' column sums
+                    wave_lds_sync();
+#pragma nounroll                   // (one copy of the test: the loop has to fit the instruction cache)
+                    for (int k = 0; k < perPass && idxP + k < iEnd; ++k) {
+                        const lds_ro_f32_ptr base = nSlabR + 2 * (colsPer / 4) * k;
+                        float X[4 + kB - 1];
+#pragma unroll
+                        for (int i = 0; i < 4 + kB - 1; ++i) X[i] = base[2 * ((i & 3) * kNarrowQ + (i >> 2))];
+                        const uint32_t ord = ((lds_ro_u32_ptr)sOrder)[entryOf(idxP + k)];
+                        testCandidate(X, (uint32_t)__builtin_amdgcn_readfirstlane((int)ord), (idxP + k) >= nHead ? 1u : 0u);
+                    }
+                    wave_lds_sync();
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (have) {
+                    columnSums(p, cN, ccN, nValid, v8);
+                    wave_lds_sync();
+#pragma unroll
+                    for (int a = 0; a < 8; ++a) nSlabW[a * (kNarrowPitch / 2)] = f32x2{v8[2 * a], v8[2 * a + 1]};
+                    wave_lds_sync();
+                    started += perPass;
+                }
+                idxP = idx0; pending = have;
+                if (have) idx0 += perPass;
+            }
+            // the band's final thresholds and counts: through LDS back to the lanes that own the pixels in the wide layout
+            wave_lds_sync();
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int cell = r * kNarrowMax + 4 * g + j;
+                    nThr[cell] = __builtin_bit_cast(uint32_t, thrN[j]);
+                    nCnt[cell] = min(cntN[j], 0x7FFFu) | (((platN >> j) & 1u) << 31);
+                }
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+                for (int i = 0; i < kRun; ++i) {
+                    const int col = kRun * q + i - nXb;
+                    if (col >= 0 && col < nW) {
+                        const int cell = (8 * hb + r8) * kNarrowMax + col;
+                        const float t = __builtin_bit_cast(float, nThr[cell]);
+                        const uint32_t w = nCnt[cell];
+                        if (hb) thr2[i].y = t; else thr2[i].x = t;
+                        const uint32_t sh = 16u * (uint32_t)(i & 1);
+                        cnt2[hb][i >> 1] = (cnt2[hb][i >> 1] & ~(0xFFFFu << sh)) | ((w & 0xFFFFu) << sh);
+                        plateauSeen |= (w >> 31) << (kRun * hb + i);
+                    }
+                }
+            }
+            return true;
+        };
         // Batches: the top hint and zero motion; then the other hints of this call (at least six entries, so that units
         // which run the first eight for their thresholds see the same boundary); then sixty-four at a time.
         const int hintsEnd = nHead ? kHead : max(kHead, min((int)order32[kCand + 1], 2 + 62));
@@ -1065,7 +1299,23 @@ __device__ __forceinline__ void prefilter_unit(
                     return 2;
                 }
             }
+            if (LFG_NARROW && !narrow && !byRank && i0 == hintsEnd && !(waveThr < LFG_NARROW_THR)) {
+                enterNarrow();
+                if (narrow) refreshZeroBound();    // the largest threshold of the pixels that stay wide
+            }
 #ifdef LFG_MOTION_STAMPS
+            if (!byRank && i0 == hintsEnd && !narrow) {
+                int lo = 99, hi = -1, rlo = 99, rhi = -1;
+#pragma unroll
+                for (int i = 0; i < kRun; ++i) {
+                    const float fx = thr2[i].x, fy = thr2[i].y;
+                    if (fx >= 2048.0f) { lo = min(lo, q); hi = max(hi, q); rlo = min(rlo, r8); rhi = max(rhi, r8); }
+                    if (fy >= 2048.0f) { lo = min(lo, q); hi = max(hi, q); rlo = min(rlo, r8 + 8); rhi = max(rhi, r8 + 8); }
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_xor(lo, off)); hi = max(hi, __shfl_xor(hi, off)); rlo = min(rlo, __shfl_xor(rlo, off)); rhi = max(rhi, __shfl_xor(rhi, off)); }
+                stampBox = (unsigned)(lo & 0xFF) | ((unsigned)(hi & 0xFF) << 8) | ((unsigned)(rlo & 0xFF) << 16) | ((unsigned)(rhi & 0xFF) << 24);
+            }
             if (i0 == hintsEnd) stampThr = __builtin_bit_cast(uint32_t, waveThr);
             stampThrEnd = __builtin_bit_cast(uint32_t, waveThr);
             stampFour = useFourPoint ? 1u : 0u;
@@ -1125,6 +1375,7 @@ __device__ __forceinline__ void prefilter_unit(
             if (byRank) rank0 += 64;
             else { i0 += count; count = i0 == 2 ? hintsEnd - 2 : 64; }
         }
+        if (narrow && !narrowPhase(hintsEnd)) return 1;
         return __builtin_amdgcn_readfirstlane(__ballot(listsOverflowed()) != 0ull) ? 1 : 0;
     };
     const int outcome = run();
@@ -1133,7 +1384,7 @@ __device__ __forceinline__ void prefilter_unit(
     if (lane == 0 && (fromQueue ? sp.units + unit : unit) < 8192) {
         unsigned long long *o = gMotionStamps + ((size_t)(fromQueue ? sp.units + unit : unit) * 4 + wave) * 8;
         o[0] = stampStart; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = stampEvals; o[3] = ((unsigned long long)borderTile << 32) | stampBatches;
-        o[4] = stampStaged; o[5] = stampFirst; o[6] = (stampFour << 8) | ((unsigned long long)(fromQueue ? 1u : 0u) << 9) | ((unsigned long long)seg << 10) | ((unsigned long long)tileX << 12) | ((unsigned long long)tileY << 20);
+        o[4] = stampStaged; o[5] = stampFirst; o[6] = ((unsigned long long)stampBox << 32) | stampNarrow | (stampFour << 8) | ((unsigned long long)(fromQueue ? 1u : 0u) << 9) | ((unsigned long long)seg << 10) | ((unsigned long long)tileX << 12) | ((unsigned long long)tileY << 20);
         o[7] = ((unsigned long long)stampThrEnd << 32) | stampThr;
     }
 #endif
@@ -1382,7 +1633,8 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
     int8_t *__restrict__ mv, int mvPitch, const uint32_t *__restrict__ rank2scan, uint32_t *__restrict__ segDone,
     uint32_t *__restrict__ ctrl) {
     __shared__ uint32_t sWin[kWinH * kWinW];                           // 38.2 KB packed RGBA8 search window
-    __shared__ __attribute__((aligned(8))) float sSlab[kPNT / 64][4 * kSlabP];      // 4 x 2.1 KB
+    __shared__ __attribute__((aligned(8))) float sSlab[kPNT / 64][kSlabFloats];     // 4 x 5.1 KB (the wide passes use 2.1 KB of each)
+    __shared__ uint32_t sNarrow[kPNT / 64][2 * kSeg * kNarrowMax];     // 4 x 2 KB: thresholds and counts of a narrow band's pixels
     __shared__ uint32_t sOrder[kCand + 7];                             // the visiting order
     __shared__ uint32_t sGiveUp;
     __shared__ uint32_t sNext[2];                                      // {unit | fromQueue << 31, its table entry}
@@ -1447,7 +1699,7 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
         if (next == kNoUnit) return;
         const bool fromQueue = (next >> 31) != 0u;
         prefilter_unit(prev, prevPitch, curr, currPitch, W, H, list, uminOut, countOut, tileFlags, flagTilesX, order32, sp,
-                       mv, mvPitch, rank2scan, segDone, (int)(next & 0x7FFFFFFFu), fromQueue, entry, sWin, sSlab, sOrder, sInv, sGiveUp);
+                       mv, mvPitch, rank2scan, segDone, (int)(next & 0x7FFFFFFFu), fromQueue, entry, sWin, sSlab, sOrder, sInv, sGiveUp, sNarrow);
         if (!fromQueue) {
             __syncthreads();               // every wave of the unit is past its pushes
             if (threadIdx.x == 0) atomicAdd(&ctrl[1], 1u);
@@ -2168,6 +2420,28 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
                     fprintf(stderr, "  late: unit %d wave %d tile (%d,%d) seg %d start %.1f end %.1f us, evals %llu, batches %llu, staged after %.1f us\n", ends[i].second / 4, ends[i].second % 4,
                             (int)((o[6] >> 12) & 0xFF), (int)((o[6] >> 20) & 0xFF), (int)((o[6] >> 10) & 3), (double)(o[0] - t0) / 100.0, (double)(o[1] - t0) / 100.0, o[2], o[3] & 0xFFFFFFFFull, (double)(o[4] - o[0]) / 100.0);
                 }
+            }
+            {   // narrow search: waves by candidates per pass, their mean duration
+                double dur[8] = {0}; int nw[8] = {0}; double evs[8] = {0};
+                for (int u = 0; u < 8192; ++u) for (int w = 0; w < 4; ++w) {
+                    const unsigned long long *o = &h[(u * 4 + w) * 8]; if (!o[1]) continue;
+                    const int k = (int)(o[6] & 7u); if (!k) continue;
+                    dur[k] += (double)(o[1] - o[0]) / 100.0; evs[k] += (double)o[2]; ++nw[k];
+                }
+                for (int k = 1; k < 8; ++k) if (nw[k]) fprintf(stderr, "narrow search, %d candidates per pass: %d waves, mean %.1f us, wide evaluations per wave %.1f\n", k, nw[k], dur[k] / nw[k], evs[k] / nw[k]);
+            }
+            {   // full-search waves (plan and queue units) by the box of their pixels without a match
+                int byRuns[9] = {0}, half[3] = {0}, total = 0;
+                for (int u = 0; u < 8192; ++u) for (int w = 0; w < 4; ++w) {
+                    const unsigned long long *o = &h[(u * 4 + w) * 8]; if (!o[1] || o[2] <= 100) continue;
+                    const unsigned box = (unsigned)(o[6] >> 32); const int lo = box & 0xFF, hi = (box >> 8) & 0xFF, rlo = (box >> 16) & 0xFF, rhi = (box >> 24) & 0xFF;
+                    ++total;
+                    if (hi < lo || lo > 8) { ++byRuns[0]; continue; }
+                    ++byRuns[std::min(8, hi - lo + 1)];
+                    if (rhi < 8) ++half[0]; else if (rlo >= 8) ++half[1]; else ++half[2];
+                }
+                fprintf(stderr, "full-search waves %d; runs of 7 columns that hold unmatched pixels: none/unknown %d, 1: %d, 2: %d, 3: %d, 4: %d, 5: %d, 6: %d, 7: %d, 8: %d; rows 0-7 only %d, rows 8-15 only %d, both %d\n",
+                        total, byRuns[0], byRuns[1], byRuns[2], byRuns[3], byRuns[4], byRuns[5], byRuns[6], byRuns[7], byRuns[8], half[0], half[1], half[2]);
             }
             {   // a sample of the waves that evaluated more than 100 candidates in full: where, and against which thresholds
                 int shown = 0;
