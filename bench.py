@@ -68,6 +68,10 @@ def parse_args():
                     help="translated (default, SURVEY.md 8(d): curr = prev shifted by (3,-2)), occluded (the same with patches of fresh noise), objects (the same with patches that move on their own), noisy (the same with +-2 levels of noise everywhere), uncorrelated (independent noise frames), "
                          "static (curr = prev), fade (flat grey frames one level apart: every candidate ties at a "
                          "non-zero cost, the prefilter's worst case -- the rim tiles fall back to the literal kernel)")
+    ap.add_argument("--in-flight", type=int, default=3,
+                    help="frames in flight on one GPU (lanes of the C-ABI): each has its own stream, motion workspace and output "
+                         "buffers, so one frame's scale / hints / first prefilter units fill the CUs that the previous frame's last "
+                         "long units leave idle; 1 = strictly one frame at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip scale_only / scale_interpolate / content_sweep (profiling runs)")
     return ap.parse_args()
@@ -328,18 +332,54 @@ def main():
                      else sharding.CapiTransport(ctx, [f for _, f in prev_slots], src=0))
     shared_prev = sharding.SharedFrameBroadcaster(len(prev_slots), transport, world_size=world, is_source=rank == 0)
 
-    def interpolate_all(fp, fc, fm):
+    # Frames in flight (`pipeline` workload; include/linuxfg_hip.h "Lanes").  Step k runs on lane k % n: its own stream,
+    # motion workspace and prev4 / curr4 / mv / out buffers.  As in a stream of frames, a step waits for the previous
+    # step's upscales -- on the other lane -- and for nothing else of it; with several GPUs that wait also frees the
+    # broadcast slot the next shared frame is about to land in.
+    n_lanes = max(1, min(args.in_flight, capi.MAX_LANES)) if args.workload == "pipeline" else 1
+    lane_bufs = [(f_curr4, f_mv, f_outs, f_prev4)]
+    keep_alive = []
+    if n_lanes > 1:
+        ctx.lanes(n_lanes)
+        for j in range(1, n_lanes):
+            bufs = [empty_frame(w, h), empty_frame(w, h, capi.FORMAT_MV_S8X2)] + [empty_frame(w, h) for _ in factors]
+            fp4 = f_prev4
+            if share_input:                              # the shared previous frame is upscaled per step: a buffer per lane
+                bufs.append(empty_frame(w, h))
+                fp4 = bufs[-1][1]
+            keep_alive.append(bufs)
+            lane_bufs.append((bufs[0][1], bufs[1][1], [f for _, f in bufs[2:2 + len(factors)]], fp4))
+
+    def interpolate_all(fp, fc, fm, fouts=None):
+        fouts = f_outs if fouts is None else fouts
         if len(factors) == 1:
-            ctx.interpolate(fp, fc, fm, f_outs[0], factors[0])
+            ctx.interpolate(fp, fc, fm, fouts[0], factors[0])
         else:
-            ctx.interpolate_multi(fp, fc, fm, f_outs, factors)        # one pass over prev / curr / mv, every factor
+            ctx.interpolate_multi(fp, fc, fm, fouts, factors)        # one pass over prev / curr / mv, every factor
+
+    def pipeline_step(k, fc_in, lanes, shared=None):
+        """scale -> motion -> interpolate of step k on lane k % lanes (shared: the step's shared previous INPUT frame)"""
+        j = k % lanes
+        fc4, fmv, fouts, fp4 = lane_bufs[j]
+        if lanes > 1:
+            ctx.lane_select(j)
+            ctx.lane_wait((k - 1) % lanes)
+        if shared is not None:
+            f_shared = prev_slots[shared.acquire(k)][1]             # (waits for its broadcast, issues the next one)
+            ctx.scale(f_shared, fp4)
+        ctx.scale(fc_in, fc4)
+        if lanes > 1:
+            ctx.lane_mark()
+        ctx.motion(fp4, fc4, fmv, 8, 16.0)
+        interpolate_all(fp4, fc4, fmv, fouts)
 
     def step(k):
+        if args.workload == "pipeline":
+            pipeline_step(k, f_curr_in, n_lanes, shared_prev if share_input else None)
+            return
         # the shared previous frame of this step (waits for its broadcast, issues the next one)
         f_shared = prev_slots[shared_prev.acquire(k)][1]
         f_prev_step = f_shared if share_input else f_prev_in
-        if share_input and args.workload == "pipeline":
-            ctx.scale(f_shared, f_prev4)
         if args.workload == "pipeline_input_res":
             ctx.motion(f_prev_step, f_curr_in, f_mv_in, 8, 16.0)
             ctx.scale(f_curr_in, f_curr4)
@@ -347,9 +387,6 @@ def main():
                 ctx.interpolate_scale(f_prev_step, f_curr_in, f_mv_in, fo, t)
             return
         ctx.scale(f_curr_in, f_curr4)
-        if args.workload == "pipeline":
-            ctx.motion(f_prev4, f_curr4, f_mv, 8, 16.0)
-            interpolate_all(f_prev4, f_curr4, f_mv)
 
     def barrier_sync():
         torch.cuda.synchronize(dev)
@@ -369,7 +406,7 @@ def main():
     for k in range(warmup):
         step(k)
     ctx.profile_reset()
-    ctx.profile_enable(args.workload != "scale")      # events around every stage launch (ms-scale kernels)
+    ctx.profile_enable(args.workload != "scale" and n_lanes == 1)     # events around every stage launch (ms-scale kernels)
     barrier_sync()
     t0 = time.perf_counter()
     for k in range(warmup, warmup + steps):
@@ -379,6 +416,14 @@ def main():
     shared_prev.drain()
     torch.cuda.synchronize(dev)
 
+    if n_lanes > 1:
+        # stage durations from a second pass on ONE lane, event-bracketed: with frames in flight the stages of two steps
+        # overlap and an event pair around one of them times both
+        ctx.lane_select(0)
+        ctx.profile_enable(True)
+        for k in range(min(steps, 200)):
+            pipeline_step(k, f_curr_in, 1)           # (the shared previous frame, if any, stays as the last step left it)
+        torch.cuda.synchronize(dev)
     if args.workload == "scale":
         # kernel duration from a second, event-bracketed pass: per-launch events would dominate the
         # wall clock of a ~10 us kernel, so they stay out of the pass `value` is computed from.
@@ -434,14 +479,13 @@ def main():
             tc, fc = dev_frame(c_in)
             ctx.set_motion_mode(mode)
             ctx.scale(fp, f_prev4)
-            def one(k):
-                ctx.scale(fc, f_curr4)
-                ctx.motion(f_prev4, f_curr4, f_mv, 8, 16.0)
-                interpolate_all(f_prev4, f_curr4, f_mv)
-            timed(one, 2)
-            ctx.profile_reset(); ctx.profile_enable(True)
             n = 5 if mode == capi.MOTION_EXACT_ONLY else (20 if content in ("uncorrelated", "fade") else 100)
-            t = timed(one, n)
+            timed(lambda k: pipeline_step(k, fc, n_lanes), 2 * n_lanes)
+            t = timed(lambda k: pipeline_step(k, fc, n_lanes), n)                # frames/s: as `value`, frames in flight
+            if n_lanes > 1:
+                ctx.lane_select(0)
+            ctx.profile_reset(); ctx.profile_enable(True)
+            timed(lambda k: pipeline_step(k, fc, 1), max(2, n // 4))              # motion_ms: one lane, event-bracketed
             ms, cnt = ctx.profile_get(capi.STAGE_MOTION)
             ctx.profile_enable(False)
             entry = {"frames_per_s": round(n * len(factors) / t, 1), "motion_ms": round(ms / max(cnt, 1), 4), "steps": n}

@@ -97,8 +97,28 @@ void        lfg_context_destroy(lfg_context *ctx);
 int         lfg_context_set_stream(lfg_context *ctx, void *hip_stream);
 void       *lfg_context_get_stream(lfg_context *ctx);
 int         lfg_context_device(const lfg_context *ctx);
-/* vkQueueWaitIdle (src/scaler.cpp:393, src/frame_manager.cpp:194). */
+/* vkQueueWaitIdle (src/scaler.cpp:393, src/frame_manager.cpp:194): every lane of the context. */
 int         lfg_sync(lfg_context *ctx);
+
+/* Lanes: several frames in flight on one GPU.  The reference has one queue and waits for it after every
+ * submission (src/scaler.cpp:389-393, src/frame_manager.cpp:190-194); here a frame's last long motion units leave
+ * most CUs idle for a third of its time, and the next frame's scale, hints and first units can run there.  A lane
+ * is a stream plus the temporaries and the motion workspace (2.5 GB at 4K) of the calls made while it is selected;
+ * frames are plain device memory and may be used from any lane -- the caller orders producers and consumers:
+ *   lfg_lanes(ctx, n)       1 <= n <= LFG_MAX_LANES lanes (lane 0 is the context's own stream); shrinking waits
+ *                           for the lanes that go and frees what they own
+ *   lfg_lane_select(ctx, j) the calls that follow enqueue on lane j
+ *   lfg_lane_mark(ctx)      remember "here" on the selected lane
+ *   lfg_lane_wait(ctx, i)   the selected lane's later work waits until lane i has reached its last mark
+ * e.g. frame k on lane k % 2:  select; scale(curr_k); mark; wait(other lane: scale(curr_k-1)); motion; interpolate.
+ * lfg_context_set_stream applies to the selected lane. */
+#define LFG_MAX_LANES 4
+int         lfg_lanes(lfg_context *ctx, int count);
+int         lfg_lane_count(const lfg_context *ctx);
+int         lfg_lane_current(const lfg_context *ctx);
+int         lfg_lane_select(lfg_context *ctx, int lane);
+int         lfg_lane_mark(lfg_context *ctx);
+int         lfg_lane_wait(lfg_context *ctx, int other);
 /* Logger::GetLastError (src/logger.hpp:38).  ctx == NULL reads the creation-time error. */
 const char *lfg_last_error(const lfg_context *ctx);
 

@@ -22,6 +22,7 @@ MOTION_PREFILTERED, MOTION_EXACT_ONLY = 0, 1
 SEMANTICS_REFERENCE, SEMANTICS_INTENDED = 0, 1
 _BPP = {FORMAT_RGBA8: 4, FORMAT_MV_S8X2: 2}
 COMM_ID_BYTES = 128
+MAX_LANES = 4
 
 
 class LfgError(RuntimeError):
@@ -48,6 +49,12 @@ SIGNATURES = {
     "lfg_context_get_stream": (_vp, [_vp]),
     "lfg_context_device": (_i, [_vp]),
     "lfg_sync": (_i, [_vp]),
+    "lfg_lanes": (_i, [_vp, _i]),
+    "lfg_lane_count": (_i, [_vp]),
+    "lfg_lane_current": (_i, [_vp]),
+    "lfg_lane_select": (_i, [_vp, _i]),
+    "lfg_lane_mark": (_i, [_vp]),
+    "lfg_lane_wait": (_i, [_vp, _i]),
     "lfg_last_error": (ctypes.c_char_p, [_vp]),
     "lfg_frame_create": (_i, [_vp, _u32, _u32, _u32, _FP]),
     "lfg_frame_destroy": (None, [_vp, _FP]),
@@ -152,6 +159,25 @@ class Context:
 
     def sync(self):
         self._check(self.lib.lfg_sync(self.h), "lfg_sync")
+
+    # lanes: several frames in flight on one GPU (include/linuxfg_hip.h)
+    def lanes(self, count: int):
+        self._check(self.lib.lfg_lanes(self.h, int(count)), "lfg_lanes")
+
+    def lane_count(self) -> int:
+        return int(self.lib.lfg_lane_count(self.h))
+
+    def lane_current(self) -> int:
+        return int(self.lib.lfg_lane_current(self.h))
+
+    def lane_select(self, lane: int):
+        self._check(self.lib.lfg_lane_select(self.h, int(lane)), "lfg_lane_select")
+
+    def lane_mark(self):
+        self._check(self.lib.lfg_lane_mark(self.h), "lfg_lane_mark")
+
+    def lane_wait(self, other: int):
+        self._check(self.lib.lfg_lane_wait(self.h, int(other)), "lfg_lane_wait")
 
     # -- frames
     def create_frame(self, width: int, height: int, fmt: int = FORMAT_RGBA8) -> Frame:

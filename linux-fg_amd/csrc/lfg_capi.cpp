@@ -128,11 +128,19 @@ int build_axis_table(lfg_context *ctx, int in_size, int out_size, lfg::AxisTable
     return LFG_OK;
 }
 
+// Everything the context has enqueued, on every lane (a resource shared by the lanes is about to go or to be read).
+hipError_t sync_lanes(lfg_context *ctx) {
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    for (size_t j = 0; j < ctx->lanes.size() && e == hipSuccess; ++j)
+        if ((int)j != ctx->lane && ctx->lanes[j].stream) e = hipStreamSynchronize(ctx->lanes[j].stream);
+    return e;
+}
+
 // Bounded cache: called at the top of lfg_scale, before any table pointer is taken, so the two
 // lookups that follow can never evict each other.
 void trim_axis_tables(lfg_context *ctx) {
     while (ctx->tables.size() > 14) {
-        (void)hipStreamSynchronize(ctx->stream);               // a queued kernel may still read it
+        (void)sync_lanes(ctx);                                 // a queued kernel may still read it
         lfg::AxisTable &old = ctx->tables.front();
         (void)hipFree(old.d_start); (void)hipFree(old.d_weight); (void)hipFree(old.d_class); (void)hipFree(old.d_palette);
         ctx->tables.erase(ctx->tables.begin());
@@ -211,7 +219,7 @@ struct StageTimer {
 
 int drain_profile(lfg_context *ctx) {
     if (ctx->prof_pending.empty()) return LFG_OK;
-    LFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LFG_HIP(ctx, sync_lanes(ctx));
     for (auto &s : ctx->prof_pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, s.begin, s.end) == hipSuccess) { ctx->prof_ms[s.stage] += ms; ctx->prof_n[s.stage] += 1; }
@@ -270,12 +278,39 @@ LFG_EXPORT int lfg_context_create(int device_ordinal, lfg_context **out_ctx) {
     return LFG_OK;
 }
 
+// (lanes, further down: what a lane owns moves between the context's fields and its table entry)
+namespace {
+void lane_store(lfg_context *ctx, lfg_lane_state &l) {
+    l.own_stream = ctx->own_stream; l.stream = ctx->stream; l.mv_tmp = ctx->mv_tmp; l.mid_tmp = ctx->mid_tmp;
+    l.motion_ws = ctx->motion_ws; l.motion_ws_bytes = ctx->motion_ws_bytes; l.motion_ws_w = ctx->motion_ws_w; l.motion_ws_h = ctx->motion_ws_h;
+    l.motion_ws_layout = ctx->motion_ws_layout; l.motion_units = ctx->motion_units; l.mark = ctx->mark; l.marked = ctx->marked;
+}
+void lane_load(lfg_context *ctx, const lfg_lane_state &l) {
+    ctx->own_stream = l.own_stream; ctx->stream = l.stream; ctx->mv_tmp = l.mv_tmp; ctx->mid_tmp = l.mid_tmp;
+    ctx->motion_ws = l.motion_ws; ctx->motion_ws_bytes = l.motion_ws_bytes; ctx->motion_ws_w = l.motion_ws_w; ctx->motion_ws_h = l.motion_ws_h;
+    ctx->motion_ws_layout = l.motion_ws_layout; ctx->motion_units = l.motion_units; ctx->mark = l.mark; ctx->marked = l.marked;
+}
+void lane_release(lfg_lane_state &l) {
+    if (l.stream) (void)hipStreamSynchronize(l.stream);
+    if (l.own_stream && l.own_stream != l.stream) (void)hipStreamSynchronize(l.own_stream);
+    if (l.mv_tmp.data && l.mv_tmp.owned) (void)hipFree(l.mv_tmp.data);
+    if (l.mid_tmp.data && l.mid_tmp.owned) (void)hipFree(l.mid_tmp.data);
+    if (l.motion_ws) (void)hipFree(l.motion_ws);
+    if (l.mark) (void)hipEventDestroy(l.mark);
+    if (l.own_stream) (void)hipStreamDestroy(l.own_stream);
+    l = lfg_lane_state{};
+}
+}  // namespace
+
 LFG_EXPORT void lfg_context_destroy(lfg_context *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)lfg_comm_destroy(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream != ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    for (size_t j = 0; j < ctx->lanes.size(); ++j)
+        if ((int)j != ctx->lane) lane_release(ctx->lanes[j]);      // (the selected lane's resources are the context's own fields)
+    if (ctx->mark) (void)hipEventDestroy(ctx->mark);
     for (auto &s : ctx->prof_pending) { (void)hipEventDestroy(s.begin); (void)hipEventDestroy(s.end); }
     for (auto &p : ctx->prof_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto &t : ctx->tables) { (void)hipFree(t.d_start); (void)hipFree(t.d_weight); (void)hipFree(t.d_class); (void)hipFree(t.d_palette); }
@@ -298,11 +333,65 @@ LFG_EXPORT int lfg_context_set_stream(lfg_context *ctx, void *hip_stream) {
 
 LFG_EXPORT void *lfg_context_get_stream(lfg_context *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
+// ------------------------------------------------------------------ lanes: several frames in flight on one GPU
+
+LFG_EXPORT int lfg_lanes(lfg_context *ctx, int count) {
+    if (!ctx) return LFG_ERR_INVALID;
+    if (count < 1 || count > LFG_MAX_LANES) return fail(ctx, LFG_ERR_INVALID, "lfg_lanes: count must be 1 .. LFG_MAX_LANES");
+    LFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->lanes.empty()) { ctx->lanes.resize(1); ctx->lane = 0; }
+    if (ctx->lane >= count) {                  // the selected lane is about to go: back to lane 0 first
+        int rc = lfg_lane_select(ctx, 0);
+        if (rc != LFG_OK) return rc;
+    }
+    while ((int)ctx->lanes.size() > count) { lane_release(ctx->lanes.back()); ctx->lanes.pop_back(); }
+    while ((int)ctx->lanes.size() < count) {
+        lfg_lane_state l;
+        hipError_t e = hipStreamCreateWithFlags(&l.own_stream, hipStreamNonBlocking);
+        if (e != hipSuccess) return fail_hip(ctx, e, "hipStreamCreate (lane)");
+        l.stream = l.own_stream;
+        ctx->lanes.push_back(l);
+    }
+    return LFG_OK;
+}
+
+LFG_EXPORT int lfg_lane_count(const lfg_context *ctx) { return ctx ? std::max<int>(1, (int)ctx->lanes.size()) : 0; }
+LFG_EXPORT int lfg_lane_current(const lfg_context *ctx) { return ctx ? ctx->lane : -1; }
+
+LFG_EXPORT int lfg_lane_select(lfg_context *ctx, int lane) {
+    if (!ctx) return LFG_ERR_INVALID;
+    if (lane < 0 || lane >= std::max<int>(1, (int)ctx->lanes.size())) return fail(ctx, LFG_ERR_INVALID, "lfg_lane_select: no such lane (lfg_lanes first)");
+    if (lane == ctx->lane) return LFG_OK;
+    lane_store(ctx, ctx->lanes[(size_t)ctx->lane]);
+    lane_load(ctx, ctx->lanes[(size_t)lane]);
+    ctx->lane = lane;
+    return LFG_OK;
+}
+
+LFG_EXPORT int lfg_lane_mark(lfg_context *ctx) {
+    if (!ctx) return LFG_ERR_INVALID;
+    LFG_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->mark) LFG_HIP(ctx, hipEventCreateWithFlags(&ctx->mark, hipEventDisableTiming));
+    LFG_HIP(ctx, hipEventRecord(ctx->mark, ctx->stream));
+    ctx->marked = true;
+    return LFG_OK;
+}
+
+LFG_EXPORT int lfg_lane_wait(lfg_context *ctx, int other) {
+    if (!ctx) return LFG_ERR_INVALID;
+    if (other < 0 || other >= std::max<int>(1, (int)ctx->lanes.size())) return fail(ctx, LFG_ERR_INVALID, "lfg_lane_wait: no such lane");
+    if (other == ctx->lane) return LFG_OK;     // a stream is in order with itself
+    const lfg_lane_state &o = ctx->lanes[(size_t)other];
+    if (!o.marked) return LFG_OK;              // nothing to wait for yet
+    LFG_HIP(ctx, hipStreamWaitEvent(ctx->stream, o.mark, 0));
+    return LFG_OK;
+}
+
 LFG_EXPORT int lfg_context_device(const lfg_context *ctx) { return ctx ? ctx->device : -1; }
 
 LFG_EXPORT int lfg_sync(lfg_context *ctx) {
     if (!ctx) return LFG_ERR_INVALID;
-    LFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LFG_HIP(ctx, sync_lanes(ctx));             // every lane: "the device is idle" is what callers mean
     return LFG_OK;
 }
 
@@ -327,7 +416,7 @@ LFG_EXPORT int lfg_frame_create(lfg_context *ctx, uint32_t width, uint32_t heigh
 LFG_EXPORT void lfg_frame_destroy(lfg_context *ctx, lfg_frame *frame) {
     if (!frame) return;
     if (frame->data && frame->owned) {
-        if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+        if (ctx) { (void)hipSetDevice(ctx->device); (void)sync_lanes(ctx); }
         (void)hipFree(frame->data);
     }
     frame->data = nullptr; frame->width = frame->height = frame->pitch = 0; frame->owned = 0;
@@ -361,7 +450,7 @@ LFG_EXPORT int lfg_staging_create(lfg_context *ctx, size_t bytes, void **out_hos
 
 LFG_EXPORT void lfg_staging_destroy(lfg_context *ctx, void *host_ptr) {
     if (!host_ptr) return;
-    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx) (void)sync_lanes(ctx);
     (void)hipHostFree(host_ptr);
 }
 

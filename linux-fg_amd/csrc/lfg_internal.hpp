@@ -69,8 +69,27 @@ struct ProfileSlot {
 
 }  // namespace lfg
 
+// What a lane (lfg_lanes: one of several frames in flight on a GPU) owns apart from the context: its stream, the temporaries
+// and the motion workspace of its calls, and the event other lanes wait for.  The context's own fields ARE the selected
+// lane's; lfg_lane_select swaps them with the entry of this table.
+struct lfg_lane_state {
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    lfg_frame mv_tmp{}, mid_tmp{};
+    uint8_t *motion_ws = nullptr;
+    size_t motion_ws_bytes = 0;
+    uint32_t motion_ws_w = 0, motion_ws_h = 0;
+    lfg::MotionWorkspaceLayout motion_ws_layout{};
+    int motion_units = 0;
+    hipEvent_t mark = nullptr;
+    bool marked = false;
+};
+
 struct lfg_context {
     int device = 0;
+    std::vector<lfg_lane_state> lanes;         // empty until lfg_lanes(); entry `lane` is stale while that lane is selected
+    int lane = 0;
+    hipEvent_t mark = nullptr;                 // the selected lane's (see lfg_lane_state)
+    bool marked = false;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::string error;

@@ -23,6 +23,8 @@ static void PrintUsage() {
               << "  --interpolation-factor F Interpolation blend factor (0.0-1.0, default: 0.5)\n"
               << "  --factors A,B,...        Several generated frames per pair, in presentation order (e.g. 0.25,0.5,0.75\n"
               << "                           for 60 -> 240 fps); motion runs once per pair\n"
+              << "  --in-flight N            Frames in flight on the GPU, 1..3 (default 2): a frame's upscale and first motion units\n"
+              << "                           run while the previous frame's last long units finish; same frames, same order\n"
               << "  --ranks N --rank R --comm-file FILE\n"
               << "                           One process per GPU (BASELINE config 4): the batch shares its previous frame\n"
               << "                           (synthetic stream 0, captured on rank 0, broadcast over RCCL per frame); each\n"
@@ -44,7 +46,7 @@ int main(int argc, char* argv[]) {
     uint32_t stream = 0;
     int frames = 10, device = 0;
     std::string dumpDir, inputRaw, outputRaw, commFile;
-    int ranks = 0, rank = 0;
+    int ranks = 0, rank = 0, inFlight = 2;
     std::vector<float> factors;
     bool syncPresent = false;
 
@@ -66,6 +68,7 @@ int main(int argc, char* argv[]) {
                 p = *end == ',' ? end + 1 : end;
             }
         }
+        else if (strcmp(argv[i], "--in-flight") == 0 && i + 1 < argc) inFlight = std::atoi(argv[++i]);
         else if (strcmp(argv[i], "--ranks") == 0 && i + 1 < argc) ranks = std::atoi(argv[++i]);
         else if (strcmp(argv[i], "--rank") == 0 && i + 1 < argc) rank = std::atoi(argv[++i]);
         else if (strcmp(argv[i], "--comm-file") == 0 && i + 1 < argc) commFile = argv[++i];
@@ -113,6 +116,7 @@ int main(int argc, char* argv[]) {
     if (!inputRaw.empty()) Scaler::Get().SetFrameSource(std::make_unique<RawFileCapture>(inputRaw));
     else Scaler::Get().SetFrameSource(std::make_unique<SyntheticCapture>(stream));
     Scaler::Get().SetPipelined(!syncPresent);
+    Scaler::Get().SetFramesInFlight(inFlight);
     if (!factors.empty()) Scaler::Get().SetInterpolationFactors(factors);
     FILE* rawOut = nullptr;
     if (!outputRaw.empty()) {

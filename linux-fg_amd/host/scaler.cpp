@@ -1,5 +1,7 @@
 #include "scaler.hpp"
 
+#include <algorithm>
+
 namespace {
 lfg_context* Ctx() { return HipContext::Get().GetDevice(); }
 }
@@ -35,10 +37,17 @@ bool Scaler::Initialize(const ScalerConfig& config) {
         LOG_ERROR("Scaler::Initialize: at most ", LFG_MAX_FACTORS, " interpolation factors per pair");
         return false;
     }
+    m_lanes = (m_sharedSource || !m_pipelined || !config.enableInterpolation) ? 1 : m_framesInFlight;
+    if (m_lanes != m_framesInFlight)
+        LOG_WARN("Scaler::Initialize: frames in flight need a stream of frames, interpolation and pipelined presentation; using one lane");
+    if (lfg_lanes(Ctx(), m_lanes) != LFG_OK) {
+        LOG_ERROR("Failed to create the lanes: ", lfg_last_error(Ctx()));
+        return false;
+    }
     const size_t inBytes = (size_t)config.inputWidth * config.inputHeight * 4;
     const size_t outBytes = (size_t)config.outputWidth * config.outputHeight * 4;
-    if (lfg_ring_create(Ctx(), 3, inBytes, &m_uploadRing) != LFG_OK ||
-        lfg_ring_create(Ctx(), (uint32_t)(2 * (m_factors.size() + 1) + 2), outBytes, &m_readbackRing) != LFG_OK) {   // two calls' worth of frames + margin
+    if (lfg_ring_create(Ctx(), (uint32_t)(2 + m_lanes), inBytes, &m_uploadRing) != LFG_OK ||
+        lfg_ring_create(Ctx(), (uint32_t)((1 + m_lanes) * (m_factors.size() + 1) + 2), outBytes, &m_readbackRing) != LFG_OK) {   // the calls in flight + the one being presented + margin
         LOG_ERROR("Failed to create pinned frame rings: ", lfg_last_error(Ctx()));
         Cleanup();
         return false;
@@ -79,11 +88,32 @@ bool Scaler::CreateFrameResources() {
     }
     if (m_config.enableInterpolation && !m_previousOutput.data) {
         bool ok = fm.CreateFrame(m_previousOutput, m_config.outputWidth, m_config.outputHeight);
-        m_interpolatedFrames.resize(m_factors.size());
-        for (Frame& f : m_interpolatedFrames) ok = ok && fm.CreateFrame(f, m_config.outputWidth, m_config.outputHeight);
+        m_laneInterpolated.assign((size_t)m_lanes, std::vector<Frame>(m_factors.size()));
+        for (auto& lane : m_laneInterpolated)
+            for (Frame& f : lane) ok = ok && fm.CreateFrame(f, m_config.outputWidth, m_config.outputHeight);
+        m_interpolatedFrames = m_laneInterpolated[0];
+        // frames in flight: with n lanes the upscaled frame written by call k was last read by call k - n (as its
+        // current frame) and k - n + 1 (as its previous one): n + 1 buffers in rotation; inputs: one per lane
+        for (int i = 0; i + 1 < m_lanes && ok; ++i) {
+            Frame extraOut;
+            ok = fm.CreateFrame(extraOut, m_config.outputWidth, m_config.outputHeight);
+            if (ok) m_outputPool.push_back(extraOut);
+        }
         if (!ok) {
             LOG_ERROR("Failed to create interpolation frames");
             return false;
+        }
+    }
+    if (m_lanes > 1 && m_inputPool.empty()) {
+        m_inputPool.push_back(m_currentFrame);
+        m_inputPool.push_back(m_previousFrame);
+        for (int i = 2; i < m_lanes; ++i) {
+            Frame extra;
+            if (!fm.CreateFrame(extra, m_config.inputWidth, m_config.inputHeight)) {
+                LOG_ERROR("Failed to create an input frame");
+                return false;
+            }
+            m_inputPool.push_back(extra);
         }
     }
     return true;
@@ -192,6 +222,18 @@ bool Scaler::ProcessFrame() {
         }
         if (!IssueSharedPrevious(slot ^ 1)) return false;
     }
+    // Frames in flight: this call's uploads, kernels and read-backs go to lane k % n.  It waits -- on the device -- for
+    // the previous call's upscale (the other lane's mark): that is this call's previous frame, and everything that
+    // lane did before it is what last read the buffers this call is about to overwrite.
+    const int lane = (int)(m_calls % (uint64_t)m_lanes);
+    if (m_lanes > 1) {
+        if (lfg_lane_select(Ctx(), lane) != LFG_OK || (m_calls > 0 && lfg_lane_wait(Ctx(), (int)((m_calls - 1) % (uint64_t)m_lanes)) != LFG_OK)) {
+            LOG_ERROR("Failed to switch lanes: ", lfg_last_error(Ctx()));
+            return false;
+        }
+        m_currentFrame = m_inputPool[(size_t)lane];
+        m_interpolatedFrames = m_laneInterpolated[(size_t)lane];
+    }
     ++m_calls;
     if (!CaptureFrame(m_currentFrame)) {
         LOG_ERROR("Failed to capture frame");
@@ -206,6 +248,10 @@ bool Scaler::ProcessFrame() {
     fenceBeforeWrite(m_outputFrame);
     if (!ScaleFrame(m_currentFrame, m_outputFrame)) {
         LOG_ERROR("Failed to scale frame");
+        return false;
+    }
+    if (m_lanes > 1 && lfg_lane_mark(Ctx()) != LFG_OK) {
+        LOG_ERROR("Failed to mark the lane: ", lfg_last_error(Ctx()));
         return false;
     }
     const size_t inFlightBefore = m_pending.size();
@@ -231,13 +277,23 @@ bool Scaler::ProcessFrame() {
             if (!QueueReadback(f, true)) return false;
     }
     if (!QueueReadback(m_outputFrame, false)) return false;
-    // Pipelined: present what the previous call queued while this call's work runs; otherwise everything now.
-    if (!PresentPending(m_pipelined ? m_pending.size() - inFlightBefore : 0)) return false;
+    // Pipelined: present what earlier calls queued while this call's work runs (one call back; with n > 2 lanes the
+    // last n - 1 calls stay in flight); otherwise everything now.
+    m_queuedPerCall.push_back(m_pending.size() - inFlightBefore);
+    while (m_queuedPerCall.size() > (size_t)std::max(1, m_lanes - 1)) m_queuedPerCall.pop_front();
+    size_t keep = 0;
+    for (size_t q : m_queuedPerCall) keep += q;
+    if (!PresentPending(m_pipelined ? keep : 0)) return false;
 
     if (m_config.enableInterpolation && !m_sharedSource) {
-        // previous <- current: swap the handles instead of copying the image (src/scaler.cpp:616-621).
-        std::swap(m_previousFrame, m_currentFrame);
-        std::swap(m_previousOutput, m_outputFrame);
+        // previous <- current: move the handles instead of copying the image (src/scaler.cpp:616-621); the upscaled
+        // frames rotate through the pool (empty with one lane: a plain swap)
+        if (m_lanes == 1) std::swap(m_previousFrame, m_currentFrame);
+        else m_previousFrame = m_currentFrame;
+        m_outputPool.push_back(m_previousOutput);
+        m_previousOutput = m_outputFrame;
+        m_outputFrame = m_outputPool.front();
+        m_outputPool.pop_front();
         m_havePrevious = true;
     }
     return true;
@@ -251,16 +307,30 @@ void Scaler::Cleanup() {
     if (m_uploadRing) { lfg_ring_destroy(m_uploadRing); m_uploadRing = nullptr; }
     if (m_readbackRing) { lfg_ring_destroy(m_readbackRing); m_readbackRing = nullptr; }
     auto& fm = FrameManager::Get();
-    fm.DestroyFrame(m_currentFrame);
-    fm.DestroyFrame(m_previousFrame);
+    if (m_lanes > 1) {
+        // (the handles in m_currentFrame / m_previousFrame / m_interpolatedFrames are copies of pool entries)
+        for (Frame& f : m_inputPool) fm.DestroyFrame(f);
+        m_currentFrame = Frame{}; m_previousFrame = Frame{};
+    } else {
+        fm.DestroyFrame(m_currentFrame);
+        fm.DestroyFrame(m_previousFrame);
+    }
+    m_inputPool.clear();
     fm.DestroyFrame(m_outputFrame);
     fm.DestroyFrame(m_previousOutput);
+    for (Frame& f : m_outputPool) fm.DestroyFrame(f);
+    m_outputPool.clear();
+    m_queuedPerCall.clear();
     if (Ctx() && m_sharedSource && HipContext::Get().GetRanks() > 0) (void)fm.WaitBroadcasts();   // the look-ahead broadcast of the last call
     fm.DestroyFrame(m_sharedIn[0]);
     fm.DestroyFrame(m_sharedIn[1]);
     m_calls = 0;
-    for (Frame& f : m_interpolatedFrames) fm.DestroyFrame(f);
+    for (auto& lane : m_laneInterpolated)
+        for (Frame& f : lane) fm.DestroyFrame(f);
+    m_laneInterpolated.clear();
     m_interpolatedFrames.clear();
+    if (Ctx()) { (void)lfg_lane_select(Ctx(), 0); (void)lfg_lanes(Ctx(), 1); }
+    m_lanes = 1;
     m_factors.clear();
     m_havePrevious = false;
     m_frameTimings.clear();

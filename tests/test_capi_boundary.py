@@ -78,5 +78,9 @@ def test_null_arguments_are_rejected(capi):
     assert lib.lfg_scale(None, None, None) != 0
     assert lib.lfg_motion(None, None, None, None, 8, 16.0) != 0
     assert lib.lfg_interpolate(None, None, None, None, None, 0.5) != 0
+    # lanes (frames in flight): no context, no lanes
+    assert lib.lfg_lanes(None, 2) != 0 and lib.lfg_lane_select(None, 0) != 0
+    assert lib.lfg_lane_mark(None) != 0 and lib.lfg_lane_wait(None, 0) != 0
+    assert lib.lfg_lane_count(None) == 0 and lib.lfg_lane_current(None) == -1
     lib.lfg_context_destroy(None)                   # NULL-safe, like the reference's Cleanup()
     lib.lfg_frame_destroy(None, None)

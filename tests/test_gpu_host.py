@@ -147,6 +147,21 @@ def test_pipelined_presentation_matches_synchronous(host_binary, tmp_path):
         assert (x == y).all()
 
 
+def test_frames_in_flight_present_the_same_stream(host_binary, tmp_path):
+    """--in-flight N (lanes of the C-ABI: call k's upload, kernels and read-backs on lane k % N, the upscaled frames in a
+    rotation of N + 1 buffers): the presented stream is the one-frame-at-a-time stream, frame for frame, for one and for
+    three generated frames per pair."""
+    w, h, n = 96, 64, 8
+    for extra in ([], ["--factors", "0.25,0.5,0.75"]):
+        ref_info, ref_files, ref = _presented(tmp_path, w, h, ["--in-flight", "1"] + extra, frames=n)
+        assert ref_info["presented"] == (n - 1) * (1 + (3 if extra else 1)) + 1
+        for lanes in ("2", "3"):
+            info, files, got = _presented(tmp_path, w, h, ["--in-flight", lanes] + extra, frames=n)
+            assert files == ref_files and info["presented"] == ref_info["presented"] and info["checksum"] == ref_info["checksum"]
+            for x, y in zip(got, ref):
+                assert (x == y).all()
+
+
 def test_raw_file_source_and_sink(host_binary, tmp_path):
     """--input-raw / --output-raw: the headless stand-ins for capture and display.  Frames fed from a file must
     give the same presented stream as the built-in synthetic source producing the same frames."""

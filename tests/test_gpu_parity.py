@@ -1100,3 +1100,57 @@ def test_intended_interpolate_matches_oracle(intended, oracle, t):
     assert (d != 0).mean() < 1e-3                                         # in practice identical
     lit = oracle.interpolate(prev, curr, mv.astype(np.float32), t)
     assert (want != lit).any()
+
+
+def test_lanes_keep_frames_in_flight_apart():
+    """Lanes (include/linuxfg_hip.h): a stream of frames run with two and three frames in flight -- frame k on lane
+    k % n with its own curr / mv / out buffers, a frame's motion waiting for the previous frame's upscale on the other
+    lane -- gives, frame for frame, what one lane gives.  Sizes with more than one prefilter tile so that the lanes'
+    motion workspaces are really in use at the same time."""
+    from linux_fg_amd import capi
+    ctx = capi.Context(0)
+    try:
+        assert ctx.lane_count() == 1 and ctx.lane_current() == 0
+        with pytest.raises(capi.LfgError, match="no such lane"):
+            ctx.lane_select(1)
+        for bad in (0, capi.MAX_LANES + 1):
+            with pytest.raises(capi.LfgError, match="count must be"):
+                ctx.lanes(bad)
+        w, h, n_frames = 160, 96, 7
+        seed = synth.BASE_SEED + 77
+        inputs = [synth.make_prev(w, h, seed)]
+        for k in range(1, n_frames):
+            inputs.append(synth.translate(inputs[-1], (2 + (k % 3), -1 - (k % 2)), seed + k))
+        f_in = [ctx.frame_from(a) for a in inputs]
+
+        def run(lanes):
+            ctx.lanes(lanes)
+            assert ctx.lane_count() == lanes
+            ups = [ctx.create_frame(2 * w, 2 * h) for _ in range(n_frames)]
+            mvs = [ctx.create_frame(2 * w, 2 * h, capi.FORMAT_MV_S8X2) for _ in range(n_frames)]
+            outs = [ctx.create_frame(2 * w, 2 * h) for _ in range(n_frames)]
+            for k in range(n_frames):
+                ctx.lane_select(k % lanes)
+                assert ctx.lane_current() == k % lanes
+                ctx.lane_wait((k - 1) % lanes)              # (before the first mark of that lane: nothing to wait for)
+                ctx.scale(f_in[k], ups[k])
+                ctx.lane_mark()
+                if k:
+                    ctx.motion(ups[k - 1], ups[k], mvs[k], 8, 16.0)
+                    ctx.interpolate(ups[k - 1], ups[k], mvs[k], outs[k], 0.5)
+            ctx.sync()                                      # every lane
+            got = [(ctx.download(mvs[k]), ctx.download(outs[k])) for k in range(1, n_frames)]
+            ctx.lane_select(0)
+            for f in ups + mvs + outs:
+                ctx.destroy_frame(f)
+            return got
+
+        one = run(1)
+        assert len({m.tobytes() for m, _ in one}) > 1       # the frames differ from each other
+        for lanes in (2, 3):
+            for (m1, o1), (m2, o2) in zip(one, run(lanes)):
+                assert (m1 == m2).all() and (o1 == o2).all()
+        ctx.lanes(1)                                        # shrinking frees the other lanes' workspaces
+        assert ctx.lane_count() == 1
+    finally:
+        ctx.close()
