@@ -284,8 +284,8 @@ def main():
     w_in, h_in = SIZES[args.input]
     w, h = 2 * w_in, 2 * h_in
     factors = [float(x) for x in args.factors.split(",") if x]
-    # defaults: a timed region of about a second (0.7 ms per pipeline step, 13 us per scale step at 1080p -> 4K)
-    steps = args.steps if args.steps is not None else (40000 if args.workload == "scale" else 1000)
+    # defaults: a timed region of about a second (0.46 ms per pipeline step, 12 us per scale step at 1080p -> 4K)
+    steps = args.steps if args.steps is not None else (40000 if args.workload == "scale" else 2000)
     warmup = args.warmup if args.warmup is not None else (500 if args.workload == "scale" else 20)
 
     ctx = capi.Context(dev_index)

@@ -53,3 +53,51 @@ def test_one_rank_communicator_broadcast_and_refusals():
         ctx.comm_wait()
         ctx.sync()
         # lfg_context_destroy tears the communicator down
+
+
+def test_shared_frame_broadcast_with_frames_in_flight():
+    """bench.py's multi-GPU step with lanes, on one rank: the double-buffered broadcast of the shared previous frame
+    (SharedFrameBroadcaster over CapiTransport, a one-rank communicator standing in for the node's) while step k runs on
+    lane k % n.  The lane's wait for the previous step's upscales is also what frees the slot the next frame lands in:
+    every step must see ITS frame although the other lane is still busy with the step before."""
+    from linux_fg_amd import capi, sharding
+    w, h, steps = 320, 180, 7
+    frames = [synth.make_prev(w, h, seed=900 + k) for k in range(steps + 1)]
+    with capi.Context(0) as ctx:
+        ctx.comm_init(1, 0, capi.Context.comm_unique_id())
+        want = []
+        for k in range(steps):                                # one lane, no broadcast: what every step has to produce
+            f = ctx.frame_from(frames[k])
+            up = ctx.create_frame(2 * w, 2 * h)
+            ctx.scale(f, up)
+            want.append(ctx.download(up))
+            ctx.destroy_frame(f); ctx.destroy_frame(up)
+        for lanes in (2, 3):
+            ctx.lanes(lanes)
+            slots = [ctx.create_frame(w, h) for _ in range(2)]
+            ups = [ctx.create_frame(2 * w, 2 * h) for _ in range(steps)]
+            mvs = [ctx.create_frame(2 * w, 2 * h, capi.FORMAT_MV_S8X2) for _ in range(lanes)]
+            pinned = [ctx.staging_create(w * h * 4) for _ in range(steps + 1)]      # (asynchronous uploads: nothing here waits)
+            for a, f in zip(pinned, frames):
+                a[:] = f.reshape(-1)
+            bcast = sharding.SharedFrameBroadcaster(
+                2, sharding.CapiTransport(ctx, slots, src=0), world_size=2, is_source=True,
+                refill=lambda step, slot: ctx.upload_async(slots[slot], pinned[step]))
+            bcast.start(0)
+            for k in range(steps):
+                ctx.lane_select(k % lanes)
+                ctx.lane_wait((k - 1) % lanes)
+                slot = bcast.acquire(k)
+                ctx.scale(slots[slot], ups[k])
+                ctx.lane_mark()
+                ctx.motion(ups[k], ups[k], mvs[k % lanes], 8, 16.0)      # something long on this lane after its upscale
+            bcast.drain()
+            ctx.sync()
+            for k in range(steps):
+                assert (ctx.download(ups[k]) == want[k]).all(), (lanes, k)
+            ctx.lane_select(0)
+            for f in slots + ups + mvs:
+                ctx.destroy_frame(f)
+            for a in pinned:
+                ctx.staging_destroy(a)
+        ctx.lanes(1)
