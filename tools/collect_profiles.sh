@@ -14,7 +14,8 @@ stats() {   # $1 = name, rest = bench args [env prefix via LFG_MOTION_MODE]
       > $OUT/${TAG}_${name}_bench_under_rocprof.json 2> /tmp/prof_$name.err
   cp $(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${name}_kernel_stats.csv
 }
-stats pipeline --steps 200 --warmup 5
+stats pipeline --steps 300 --warmup 6                      # the default command: three frames in flight (kernels of neighbouring steps overlap)
+stats pipeline_one_lane --steps 200 --warmup 5 --in-flight 1   # one frame at a time: the durations bench.py's stages / dominant_stage quote
 stats scale --workload scale --steps 2000 --warmup 50
 LFG_MOTION_MODE=1 stats pipeline_exact_only --steps 5 --warmup 1
 echo "kernel stats done"
