@@ -440,7 +440,8 @@ __device__ __forceinline__ void prefilter_unit(
     const uint32_t *__restrict__ order32, const PrefilterPlan &sp,
     int8_t *__restrict__ mv, int mvPitch, const uint32_t *__restrict__ rank2scan, uint32_t *__restrict__ segDone,
     const int unit, const bool fromQueue, const uint32_t um,
-    uint32_t *sWin, float (*sSlab)[kSlabFloats], uint32_t *sOrder, const uint16_t *sInv, uint32_t &sGiveUp, uint32_t (*sNarrow)[2 * kSeg * kNarrowMax]) {
+    uint32_t *sWin, float (*sSlab)[kSlabFloats], uint32_t *sOrder, const uint16_t *sInv, uint32_t &sGiveUp, uint32_t (*sNarrow)[2 * kSeg * kNarrowMax],
+    uint32_t (*sPending)[128]) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -945,10 +946,18 @@ __device__ __forceinline__ void prefilter_unit(
                 need = need & !(pMin > bitsOf(waveThr * 1.000002f));
                 if (fullBatch && __builtin_popcountll(__ballot(need)) >= 48) useFourPoint = false;
             }
+            return __ballot(need);
+        };
 #ifndef LFG_SIXTEEN_MAX
 #define LFG_SIXTEEN_MAX 2048.0f
 #endif
-            if (useSixteen && !(waveThr < kOnePointMax) && waveThr < LFG_SIXTEEN_MAX && __builtin_popcountll(__ballot(need)) > 8) {
+        auto sixteenApplies = [&]() { return useSixteen && !(waveThr < kOnePointMax) && waveThr < LFG_SIXTEEN_MAX; };
+        // bit k of the result: lane k's candidate (ordL) still has to be evaluated in full
+        auto sixteenBatch = [&](const uint32_t ordL, const unsigned long long needMask, const bool fullBatch) -> unsigned long long {
+            uint32_t l16;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(l16));
+            bool need = ((needMask >> l16) & 1ull) != 0ull;
+            {
                 // SIXTEEN-point test, where four distances do not reach the threshold either: a match that is only nearly
                 // exact -- the rows and columns the upscaler filters differently next to the border, compression noise --
                 // costs several hundred, a wrong candidate ten thousand, and four of its 64 distances sum to 830 +- 140, of
@@ -1274,14 +1283,24 @@ __device__ __forceinline__ void prefilter_unit(
         // that is zeroBound / 64 batches instead of seventeen; the candidates looked at are the same.
         bool byRank = false;
         int rank0 = 0, visited = 0;
+        // DEFERRED sixteen-point test.  Where a match is only nearly exact everywhere -- sensor or compression noise: real
+        // video -- the four-point test leaves a dozen candidates of every batch, and running the sixteen-point test for
+        // them costs its 4,400 instructions with four fifths of the lanes idle: nineteen batches of both tests were 90 %
+        // of such a wave's time.  So the four-point survivors of a batch wait (128 entries of LDS per wave) until 64 of
+        // them are together, and the sixteen-point test runs with every lane busy: a fifth as often.  (A test may run at
+        // any later time: thresholds only fall.  The first full batch is tested at once -- the hand-over decision counts
+        // its survivors.)
+        uint32_t *const pend = sPending[wave];
+        int pendCount = 0;
         for (int i0 = 0, count = 2;;) {
-            if (byRank ? rank0 >= (int)min(zeroBound, (uint32_t)kCand) : i0 >= nEntries) break;
-            if (!byRank && i0 >= max(nHead, 2) && zeroBound < (uint32_t)kCand && (int)zeroBound + 64 <= nEntries - i0) {
+            const bool flushOnly = byRank ? rank0 >= (int)min(zeroBound, (uint32_t)kCand) : i0 >= nEntries;
+            if (flushOnly && pendCount == 0) break;
+            if (!flushOnly && !byRank && i0 >= max(nHead, 2) && zeroBound < (uint32_t)kCand && (int)zeroBound + 64 <= nEntries - i0) {
                 byRank = true; rank0 = 0; visited = i0;
             }
             // Hand the segment over?  Either no threshold to test against once every hint has been tried, or the test
             // let a quarter of the first full batch through.
-            if (!byRank && whole && !fromQueue && order32[kCand] != 0u &&
+            if (!flushOnly && !byRank && whole && !fromQueue && order32[kCand] != 0u &&
                 ((i0 == hintsEnd && !(waveThr < 4.0f * 510.0f)) || (i0 == hintsEnd + 64 && firstBatchSurvivors >= 16))) {
                 // LFG_DYN_PARTS parts of the candidate order, four per queue entry (one workgroup each); the entries of a
                 // segment are consecutive slots, so its private lists are the blocks 4 slot .. 4 slot + parts - 1
@@ -1299,7 +1318,7 @@ __device__ __forceinline__ void prefilter_unit(
                     return 2;
                 }
             }
-            if (LFG_NARROW && !narrow && !byRank && i0 == hintsEnd && !(waveThr < LFG_NARROW_THR)) {
+            if (LFG_NARROW && !flushOnly && !narrow && !byRank && i0 == hintsEnd && !(waveThr < LFG_NARROW_THR)) {
                 enterNarrow();
                 if (narrow) refreshZeroBound();    // the largest threshold of the pixels that stay wide
             }
@@ -1320,55 +1339,90 @@ __device__ __forceinline__ void prefilter_unit(
             stampThrEnd = __builtin_bit_cast(uint32_t, waveThr);
             stampFour = useFourPoint ? 1u : 0u;
 #endif
-            uint32_t ordL;
-            bool need;
-            {
-                uint32_t l;                // lane number; volatile, so that it is not hoisted out of the loop and spilled
-                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(l));
+            uint32_t ordL = 0u;            // this lane's candidate: an entry of the order; bit 31: count it when it is recorded
+            unsigned long long m = 0ull;   // the lanes whose candidate has to be evaluated in full
+            uint32_t l;                    // lane number; volatile, so that it is not hoisted out of the loop and spilled
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(l));
+            if (!flushOnly) {
+                bool need;
                 if (!byRank) {
                     const int idx = i0 + (int)l;
                     ordL = ((lds_ro_u32_ptr)sOrder)[min(idx < nHead ? idx : eBegin + (idx - nHead), kCand - 1)];
                     need = (int)l < count && idx < nEntries && (ordL & 0xFFFFu) < zeroBound;
+                    ordL |= idx >= nHead ? 0x80000000u : 0u;
                 } else {
                     const int r = rank0 + (int)l;
                     const int e = (int)sInv[min(r, kCand - 1)];                       // where the order visits rank r
-                    ordL = ((lds_ro_u32_ptr)sOrder)[e];
+                    ordL = ((lds_ro_u32_ptr)sOrder)[e] | 0x80000000u;
                     need = r < (int)zeroBound && e >= eBegin && e < eEnd && nHead + (e - eBegin) >= visited;
                 }
-            }
-            unsigned long long m = latticeBatch(ordL, need, byRank || count == 64);
-            if (!byRank && i0 == hintsEnd) firstBatchSurvivors = __builtin_popcountll(m);
+                m = latticeBatch(ordL & 0x7FFFFFFFu, need, byRank || count == 64);
+                const bool firstFull = !byRank && i0 == hintsEnd;
+                if (sixteenApplies() && __builtin_popcountll(m) > 8) {
+                    if (firstFull) m = sixteenBatch(ordL & 0x7FFFFFFFu, m, count == 64);
+                    else {                 // the survivors wait for company
+                        const uint32_t at = (uint32_t)pendCount + (uint32_t)__builtin_popcountll(m & ((1ull << l) - 1ull));
+                        wave_lds_sync();
+                        if ((m >> l) & 1ull) pend[at] = ordL;
+                        wave_lds_sync();
+                        pendCount += __builtin_popcountll(m);
+                        m = 0ull;
+                    }
+                }
+                if (firstFull) firstBatchSurvivors = __builtin_popcountll(m);
 #ifdef LFG_MOTION_STAMPS
-            stampBatches += 1u; stampEvals += (unsigned)__builtin_popcountll(m);
+                stampBatches += 1u;
 #endif
-            if (m != 0ull) {
-            // The survivors, software-pipelined: the window reads of one are in flight while the previous one is
-            // finished; a last pass drains the pipeline.
-            bool pending = false;
-            uint32_t ordP = 0u, cntP = 0u;
-            while (m != 0ull || pending) {
-                const bool have = m != 0ull;
-                uint32_t ord = 0u, cntIt = 0u;
-                if (have) {
-                    const int b = __builtin_ctzll(m);
-                    m &= m - 1ull;
-                    ord = (uint32_t)__builtin_amdgcn_readlane((int)ordL, b);
-                    cntIt = (byRank || (i0 + b) >= nHead) ? 1u : 0u;
-                    fetchWindow(p, ord);
-                }
-                if (pending) rowSumsAndTest(x, ordP, cntP);
-                __builtin_amdgcn_sched_barrier(0);
-                if (have) {
-                    columnSums(p, c, cc, valid, v8);
-                    transpose(v8, x, slabR);
-                }
-                ordP = ord; cntP = cntIt; pending = have;
             }
-            // lists full somewhere in the tile: stop early
-            if (__builtin_amdgcn_readfirstlane(__ballot(listsOverflowed()) != 0ull)) sGiveUp = 1u;
-            if (__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)&sGiveUp) != 0) return 1;
-            refreshZeroBound();
+            // two rounds of full evaluations: this batch's survivors, then -- when 64 candidates wait, or at the end -- the
+            // first 64 of the list after their sixteen-point test
+            for (int round = 0; round < 2; ++round) {
+                if (round == 1) {
+                    if (!(pendCount >= 64 || (flushOnly && pendCount > 0))) break;
+                    const int take = min(pendCount, 64);
+                    wave_lds_sync();
+                    ordL = pend[min((int)l, take - 1)];
+                    const uint32_t moved = pend[min((int)l + 64, 127)];
+                    wave_lds_sync();
+                    if ((int)l + 64 < pendCount) pend[l] = moved;      // the rest moves up
+                    wave_lds_sync();
+                    pendCount -= take;
+                    m = __ballot((int)l < take && (ordL & 0xFFFFu) < zeroBound);
+                    if (sixteenApplies() && __builtin_popcountll(m) > 8) m = sixteenBatch(ordL & 0x7FFFFFFFu, m, take == 64);
+                }
+#ifdef LFG_MOTION_STAMPS
+                stampEvals += (unsigned)__builtin_popcountll(m);
+#endif
+                if (m == 0ull) continue;
+                // The survivors, software-pipelined: the window reads of one are in flight while the previous one is
+                // finished; a last pass drains the pipeline.
+                bool pending = false;
+                uint32_t ordP = 0u, cntP = 0u;
+                while (m != 0ull || pending) {
+                    const bool have = m != 0ull;
+                    uint32_t ord = 0u, cntIt = 0u;
+                    if (have) {
+                        const int b = __builtin_ctzll(m);
+                        m &= m - 1ull;
+                        ord = (uint32_t)__builtin_amdgcn_readlane((int)ordL, b);
+                        cntIt = ord >> 31;
+                        ord &= 0x7FFFFFFFu;
+                        fetchWindow(p, ord);
+                    }
+                    if (pending) rowSumsAndTest(x, ordP, cntP);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (have) {
+                        columnSums(p, c, cc, valid, v8);
+                        transpose(v8, x, slabR);
+                    }
+                    ordP = ord; cntP = cntIt; pending = have;
+                }
+                // lists full somewhere in the tile: stop early
+                if (__builtin_amdgcn_readfirstlane(__ballot(listsOverflowed()) != 0ull)) sGiveUp = 1u;
+                if (__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)&sGiveUp) != 0) return 1;
+                refreshZeroBound();
             }
+            if (flushOnly) continue;           // (until the list is empty)
 #ifdef LFG_MOTION_STAMPS
             if (!byRank && i0 == 0) stampFirst = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1635,6 +1689,7 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
     __shared__ uint32_t sWin[kWinH * kWinW];                           // 38.2 KB packed RGBA8 search window
     __shared__ __attribute__((aligned(8))) float sSlab[kPNT / 64][kSlabFloats];     // 4 x 5.1 KB (the wide passes use 2.1 KB of each)
     __shared__ uint32_t sNarrow[kPNT / 64][2 * kSeg * kNarrowMax];     // 4 x 2 KB: thresholds and counts of a narrow band's pixels
+    __shared__ uint32_t sPending[kPNT / 64][128];                      // 4 x 0.5 KB: candidates waiting for the sixteen-point test
     __shared__ uint32_t sOrder[kCand + 7];                             // the visiting order
     __shared__ uint32_t sGiveUp;
     __shared__ uint32_t sNext[2];                                      // {unit | fromQueue << 31, its table entry}
@@ -1699,7 +1754,7 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
         if (next == kNoUnit) return;
         const bool fromQueue = (next >> 31) != 0u;
         prefilter_unit(prev, prevPitch, curr, currPitch, W, H, list, uminOut, countOut, tileFlags, flagTilesX, order32, sp,
-                       mv, mvPitch, rank2scan, segDone, (int)(next & 0x7FFFFFFFu), fromQueue, entry, sWin, sSlab, sOrder, sInv, sGiveUp, sNarrow);
+                       mv, mvPitch, rank2scan, segDone, (int)(next & 0x7FFFFFFFu), fromQueue, entry, sWin, sSlab, sOrder, sInv, sGiveUp, sNarrow, sPending);
         if (!fromQueue) {
             __syncthreads();               // every wave of the unit is past its pushes
             if (threadIdx.x == 0) atomicAdd(&ctrl[1], 1u);
