@@ -361,6 +361,9 @@ constexpr int kRunIn = kRun + kB - 1;             // 13
 #ifndef LFG_SIXTEEN
 #define LFG_SIXTEEN 1
 #endif
+#ifndef LFG_ZERO_COMPARE
+#define LFG_ZERO_COMPARE 1
+#endif
 // Narrow search (prefilter_unit, "Narrow search"): the band of pixel columns that holds a segment's pixels without a
 // match, at most sixteen columns wide, searched several candidates per pass.
 #ifndef LFG_NARROW
@@ -481,6 +484,26 @@ __device__ __forceinline__ void prefilter_unit(
     constexpr int kHead = LFG_HEAD;
     const int nHead = chunk > 0 ? kHead : 0;
 
+    // ---- this thread's 23 block positions (column bx0 + lane, rows by0 + 16 seg + j).  Loaded BEFORE the window is staged
+    // (their squares are taken after it): the two sets of loads are in flight together, and a unit pays one memory
+    // latency before its barrier, not two.
+    uint32_t c[kSegD], cc[kSegD];
+    uint32_t valid = 0u;                                               // bit j: position j lies inside the image
+    {
+        // branch-free: the load goes to the nearest texel inside the image and is dropped afterwards (a branch per
+        // position is thirty instructions of masks and address arithmetic, 5 KB of code)
+        const int gx = bx0 + lane;
+        const bool okx = gx >= 0 && gx < W;
+        const uint8_t *const column = curr + (size_t)clampi(gx, 0, W - 1) * 4u;
+#pragma unroll
+        for (int j = 0; j < kSegD; ++j) {
+            const int gy = by0 + kSeg * seg + j;
+            const bool ok = okx && gy >= 0 && gy < H;
+            const uint32_t t = *reinterpret_cast<const uint32_t *>(column + (size_t)clampi(gy, 0, H - 1) * (size_t)currPitch);
+            c[j] = ok ? t : 0u;
+            valid |= (ok ? 1u : 0u) << j;
+        }
+    }
     // ---- search window: prev(bx0 - R + wx, by0 - R + wy), zero outside the image (texelFetch semantics); a segment
     // unit stages its own 55 rows only.  Staging is a latency chain (load -> LDS store), so everything a thread loads is
     // in flight at once: ten 16-byte loads of four texels each -- the window starts 20 texels left of a tile whose
@@ -535,20 +558,8 @@ __device__ __forceinline__ void prefilter_unit(
         }
     }
 
-    // ---- this thread's 23 block positions (column bx0 + lane, rows by0 + 16 seg + j)
-    uint32_t c[kSegD], cc[kSegD];
-    uint32_t valid = 0u;                                               // bit j: position j lies inside the image
-    {
-        const int gx = bx0 + lane;
 #pragma unroll
-        for (int j = 0; j < kSegD; ++j) {
-            const int gy = by0 + kSeg * seg + j;
-            const bool ok = gx >= 0 && gx < W && gy >= 0 && gy < H;
-            c[j] = ok ? *reinterpret_cast<const uint32_t *>(curr + (size_t)gy * (size_t)currPitch + (size_t)gx * 4u) : 0u;
-            cc[j] = __builtin_amdgcn_udot4(c[j], c[j], 0x4B000000u, false);   // 2^23 + |c|^2 as float bits
-            valid |= (ok ? 1u : 0u) << j;
-        }
-    }
+    for (int j = 0; j < kSegD; ++j) cc[j] = __builtin_amdgcn_udot4(c[j], c[j], 0x4B000000u, false);   // 2^23 + |c|^2 as float bits
     // Interior tiles: every block position the outputs use (columns 0..62) lies inside the image.
     const int borderTile = __builtin_amdgcn_readfirstlane(
         !((bx0 >= 0) && (bx0 + kPTW + kB - 2 < W) && (by0 >= 0) && (by0 + kPTH + kB - 2 < H)));
@@ -873,11 +884,26 @@ __device__ __forceinline__ void prefilter_unit(
                         for (int t = 0; t < 3; ++t) tex[ci][t] = w[(3 + 8 * ci) * kWinH + 3 + 8 * t];
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    if (LFG_ZERO_COMPARE && waveThr < 0.5f) {
+                        // Every pixel of the wave owns a zero-cost candidate (the threshold words stand for ranks): the test
+                        // reads "some lattice distance is exactly 0", and a squared distance is 0 iff the two texels are
+                        // the same four bytes -- one compare per point instead of three dot products.  This is the state of
+                        // most of a frame under a pan or where nothing moves, seventeen batches per wave.
+                        bool same = false;
 #pragma unroll
-                    for (int ci = 0; ci < 8; ++ci) {
+                        for (int ci = 0; ci < 8; ++ci) {
 #pragma unroll
-                        for (int t = 0; t < 3; ++t)
-                            dMin = min(dMin, bitsOf(distanceOf((uint32_t)__builtin_amdgcn_readlane((int)c[3 + 8 * t], 3 + 8 * ci), tex[ci][t])));
+                            for (int t = 0; t < 3; ++t)
+                                same = same | (tex[ci][t] == (uint32_t)__builtin_amdgcn_readlane((int)c[3 + 8 * t], 3 + 8 * ci));
+                        }
+                        dMin = same ? 0u : 0x7F800000u;
+                    } else {
+#pragma unroll
+                        for (int ci = 0; ci < 8; ++ci) {
+#pragma unroll
+                            for (int t = 0; t < 3; ++t)
+                                dMin = min(dMin, bitsOf(distanceOf((uint32_t)__builtin_amdgcn_readlane((int)c[3 + 8 * t], 3 + 8 * ci), tex[ci][t])));
+                        }
                     }
                 }
                 // n > waveThr^2 (1 + 2^-21) => sqrt(n) > waveThr (1 + 2^-22), which v_sqrt_f32's 1 ulp cannot bring
@@ -906,16 +932,22 @@ __device__ __forceinline__ void prefilter_unit(
                 auto bitsOf = [](float d) { return __builtin_bit_cast(uint32_t, d); };
                 uint32_t pMin = 0x7F800000u;
                 float vPrev[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                int tx0L = tx0, rowsL = ty0 + kSeg * seg;
+                asm volatile("" : "+s"(tx0L), "+s"(rowsL));
+                uint32_t rowRelevant = 0u;                              // bit b: some pixel row inside the image maps to vertical group b
 #pragma unroll
+                for (int b = 0; b < 5; ++b) rowRelevant |= (!border || rowsL + max(0, 4 * b - 3) < H) ? (1u << b) : 0u;
+                // (a rolled loop, two columns per trip: sixteen unrolled columns are 2,000 instructions, and the kernel's code
+                //  has to share a 64 KB instruction cache with the neighbouring CU's)
+#pragma unroll 2
                 for (int a = 0; a < 16; ++a) {
-                    const int col = 4 * a;
                     // (the lane select goes through an empty asm: the current-frame texels are the same in every batch,
                     //  and hoisted out of the batch loop their 96 scalar registers are spilled)
-                    int colL = col, tx0L = tx0, rowsL = ty0 + kSeg * seg;
-                    asm volatile("" : "+s"(colL), "+s"(tx0L), "+s"(rowsL));
+                    int colL = 4 * a;
+                    asm volatile("" : "+s"(colL));
                     uint32_t tex[6];
 #pragma unroll
-                    for (int b = 0; b < 6; ++b) tex[b] = w[col * kWinH + 4 * b];
+                    for (int b = 0; b < 6; ++b) tex[b] = w[4 * b];
                     const uint32_t inImage = border ? (uint32_t)__builtin_amdgcn_readlane((int)valid, colL) : 0xFFFFFFFFu;
                     float d[6];
 #pragma unroll
@@ -927,21 +959,15 @@ __device__ __forceinline__ void prefilter_unit(
                     float v[5];
 #pragma unroll
                     for (int b = 0; b < 5; ++b) v[b] = d[b] + d[b + 1];
-                    if (a > 0) {
-                        // group (a - 1, b): its first pixel is (max(0, 4 (a-1) - 3), max(0, 4 b - 3))
-                        const bool colInImage = !border || tx0L + max(0, 4 * (a - 1) - 3) < W;
+                    // group (a - 1, b): its first pixel is (max(0, 4 (a-1) - 3), max(0, 4 b - 3))
+                    const bool colRelevant = a > 0 && (!border || tx0L + max(0, 4 * (a - 1) - 3) < W);
 #pragma unroll
-                        for (int b = 0; b < 5; ++b) {
-                            const bool relevant = colInImage && (!border || rowsL + max(0, 4 * b - 3) < H);
-                            const uint32_t g = bitsOf(vPrev[b] + v[b]);
-                            pMin = min(pMin, relevant ? g : 0x7F800000u);
-                        }
+                    for (int b = 0; b < 5; ++b) {
+                        const uint32_t g = bitsOf(vPrev[b] + v[b]);
+                        pMin = min(pMin, (colRelevant && ((rowRelevant >> b) & 1u)) ? g : 0x7F800000u);
+                        vPrev[b] = v[b];
                     }
-#pragma unroll
-                    for (int b = 0; b < 5; ++b) vPrev[b] = v[b];
-                    // Two columns' reads in flight, not all sixteen's (96 texels read up front end up in scratch): the next
-                    // pair's addresses are made to wait for this pair's result.
-                    if (a & 1) asm volatile("" : "+v"(w), "+v"(pMin));
+                    w += 4 * kWinH;
                 }
                 need = need & !(pMin > bitsOf(waveThr * 1.000002f));
                 if (fullBatch && __builtin_popcountll(__ballot(need)) >= 48) useFourPoint = false;
@@ -1126,11 +1152,14 @@ __device__ __forceinline__ void prefilter_unit(
             uint32_t cN[kSegD], ccN[kSegD], nValid = 0u;
             {
                 const int gx = bx0 + pcol;
+                const bool okx = gx >= 0 && gx < W;
+                const uint8_t *const column = curr + (size_t)clampi(gx, 0, W - 1) * 4u;
 #pragma unroll
                 for (int j = 0; j < kSegD; ++j) {
                     const int gy = by0 + kSeg * seg + j;
-                    const bool ok = gx >= 0 && gx < W && gy >= 0 && gy < H;
-                    cN[j] = ok ? *reinterpret_cast<const uint32_t *>(curr + (size_t)gy * (size_t)currPitch + (size_t)gx * 4u) : 0u;
+                    const bool ok = okx && gy >= 0 && gy < H;
+                    const uint32_t t = *reinterpret_cast<const uint32_t *>(column + (size_t)clampi(gy, 0, H - 1) * (size_t)currPitch);
+                    cN[j] = ok ? t : 0u;
                     nValid |= (ok ? 1u : 0u) << j;
                 }
 #pragma unroll
@@ -1288,8 +1317,8 @@ __device__ __forceinline__ void prefilter_unit(
         // them costs its 4,400 instructions with four fifths of the lanes idle: nineteen batches of both tests were 90 %
         // of such a wave's time.  So the four-point survivors of a batch wait (128 entries of LDS per wave) until 64 of
         // them are together, and the sixteen-point test runs with every lane busy: a fifth as often.  (A test may run at
-        // any later time: thresholds only fall.  The first full batch is tested at once -- the hand-over decision counts
-        // its survivors.)
+        // any later time: thresholds only fall.  Up to the first full batch the survivors are tested at once -- the
+        // hand-over decision counts that batch's.)
         uint32_t *const pend = sPending[wave];
         int pendCount = 0;
         for (int i0 = 0, count = 2;;) {
@@ -1339,6 +1368,7 @@ __device__ __forceinline__ void prefilter_unit(
             stampThrEnd = __builtin_bit_cast(uint32_t, waveThr);
             stampFour = useFourPoint ? 1u : 0u;
 #endif
+            bool firstFull = false, flushNow = false;
             uint32_t ordL = 0u;            // this lane's candidate: an entry of the order; bit 31: count it when it is recorded
             unsigned long long m = 0ull;   // the lanes whose candidate has to be evaluated in full
             uint32_t l;                    // lane number; volatile, so that it is not hoisted out of the loop and spilled
@@ -1357,19 +1387,17 @@ __device__ __forceinline__ void prefilter_unit(
                     need = r < (int)zeroBound && e >= eBegin && e < eEnd && nHead + (e - eBegin) >= visited;
                 }
                 m = latticeBatch(ordL & 0x7FFFFFFFu, need, byRank || count == 64);
-                const bool firstFull = !byRank && i0 == hintsEnd;
-                if (sixteenApplies() && __builtin_popcountll(m) > 8) {
-                    if (firstFull) m = sixteenBatch(ordL & 0x7FFFFFFFu, m, count == 64);
-                    else {                 // the survivors wait for company
-                        const uint32_t at = (uint32_t)pendCount + (uint32_t)__builtin_popcountll(m & ((1ull << l) - 1ull));
-                        wave_lds_sync();
-                        if ((m >> l) & 1ull) pend[at] = ordL;
-                        wave_lds_sync();
-                        pendCount += __builtin_popcountll(m);
-                        m = 0ull;
-                    }
+                firstFull = !byRank && i0 == hintsEnd;
+                if (sixteenApplies() && __builtin_popcountll(m) > 8) {     // the survivors wait for company
+                    const uint32_t at = (uint32_t)pendCount + (uint32_t)__builtin_popcountll(m & ((1ull << l) - 1ull));
+                    wave_lds_sync();
+                    if ((m >> l) & 1ull) pend[at] = ordL;
+                    wave_lds_sync();
+                    pendCount += __builtin_popcountll(m);
+                    m = 0ull;
+                    flushNow = !byRank && i0 <= hintsEnd;                  // (up to the first full batch: tested at once)
                 }
-                if (firstFull) firstBatchSurvivors = __builtin_popcountll(m);
+                if (firstFull && !flushNow) firstBatchSurvivors = __builtin_popcountll(m);
 #ifdef LFG_MOTION_STAMPS
                 stampBatches += 1u;
 #endif
@@ -1378,7 +1406,7 @@ __device__ __forceinline__ void prefilter_unit(
             // first 64 of the list after their sixteen-point test
             for (int round = 0; round < 2; ++round) {
                 if (round == 1) {
-                    if (!(pendCount >= 64 || (flushOnly && pendCount > 0))) break;
+                    if (!(pendCount >= 64 || flushNow || (flushOnly && pendCount > 0))) break;
                     const int take = min(pendCount, 64);
                     wave_lds_sync();
                     ordL = pend[min((int)l, take - 1)];
@@ -1389,6 +1417,8 @@ __device__ __forceinline__ void prefilter_unit(
                     pendCount -= take;
                     m = __ballot((int)l < take && (ordL & 0xFFFFu) < zeroBound);
                     if (sixteenApplies() && __builtin_popcountll(m) > 8) m = sixteenBatch(ordL & 0x7FFFFFFFu, m, take == 64);
+                    if (flushNow && firstFull) firstBatchSurvivors = __builtin_popcountll(m);
+                    flushNow = false;
                 }
 #ifdef LFG_MOTION_STAMPS
                 stampEvals += (unsigned)__builtin_popcountll(m);
@@ -1485,7 +1515,7 @@ __device__ __forceinline__ void prefilter_unit(
         }
     };
     const bool settlesHere = whole && !windowLeavesPrev;
-    if (!settlesHere) writeThresholds();
+    bool thresholdsNeeded = !settlesHere;  // (one call further down: the fourteen stores per lane are inlined once)
     // Whole tiles away from the rim settle their easy pixels here and now, while threshold and count are still in
     // registers: a zero-cost candidate (encoded in the threshold), a single record, or two records of which one
     // survives ARE the answer (motion_resolve_kernel's rules; no plateaus where the window stays inside prev).
@@ -1558,9 +1588,10 @@ __device__ __forceinline__ void prefilter_unit(
             }
             if (lane == 0) segDone[tile * (kPTH / kSeg) + seg] = 1u;
         } else {
-            writeThresholds();
+            thresholdsNeeded = true;
         }
     }
+    if (thresholdsNeeded) writeThresholds();
     // A segment unit does the same for its segment, its four waves pooling what each learnt about its part of the
     // candidate order: the tightest threshold of the four is the pixel's bound, every wave holds its own records
     // against it, and a pixel with exactly one survivor among all four (or a zero-cost candidate) is settled --

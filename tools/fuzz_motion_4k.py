@@ -9,7 +9,7 @@ from linux_fg_amd import capi, synth
 import test_gpu_parity as T
 ctx = capi.Context(0)
 bad = 0
-for case in range(48):
+for case in range(int(os.environ.get("LFG_FUZZ_CASES", "48"))):
     rng = np.random.default_rng(77000 + case)
     w, h = int(rng.integers(2500, 3900)), int(rng.integers(1400, 2200))
     prev, curr = T._mixed_pair(w, h, 77000 + case)
