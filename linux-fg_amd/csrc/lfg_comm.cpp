@@ -79,7 +79,13 @@ LFG_EXPORT int lfg_comm_init(lfg_context *ctx, int nranks, int rank, const lfg_c
     Rccl &r = rccl();
     if (!r.error.empty()) return fail(ctx, LFG_ERR_UNSUPPORTED, "lfg_comm_init: " + r.error);
     hipError_t e = hipSetDevice(ctx->device);
-    if (e == hipSuccess && !ctx->comm_stream) e = hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking);
+    if (e == hipSuccess && !ctx->comm_stream) {
+        // highest priority: the broadcast's few workgroups must not queue behind the compute lanes' kernels for the CUs
+        // that the persistent prefilter workgroups give back one by one
+        int least = 0, greatest = 0;
+        e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->comm_stream, hipStreamNonBlocking, greatest);
+    }
     if (e == hipSuccess && !ctx->comm_ready) e = hipEventCreateWithFlags(&ctx->comm_ready, hipEventDisableTiming);
     if (e == hipSuccess && !ctx->comm_done) e = hipEventCreateWithFlags(&ctx->comm_done, hipEventDisableTiming);
     if (e != hipSuccess) return fail(ctx, LFG_ERR_DEVICE, std::string("lfg_comm_init: ") + hipGetErrorString(e));
