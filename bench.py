@@ -17,12 +17,20 @@ frame pair per GPU, inputs already resident in HBM:
       Same deliverables per step (one real and one generated 4K frame) but NOT the same pixels as the
       north_star order; never the headline value.
 
+Frames in flight (--in-flight N, default 3; include/linuxfg_hip.h "Lanes"): step k runs on lane k % N of
+the context -- its own stream, motion workspace and curr / mv / out buffers -- so that one step's upscale, hints and first
+motion units fill the CUs that the previous step's last long motion units leave idle.  The dependencies of a stream of
+frames are kept (a step's motion waits for the previous step's upscale on the other lane); `value` is still steps over
+wall time between two device-wide synchronisations.  Per-stage durations (`stages`, `roofline.dominant_stage`) then come
+from a second pass on ONE lane, where an event pair around a stage times that stage alone.  --in-flight 1 is strictly
+one step at a time.
+
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), launched by torch.distributed.run.
 Frame pairs are independent, so the work shards one pair per GPU with no data-path collective except
 the one the path really has: the batch's shared previous frame is broadcast from rank 0 each step
 (double-buffered, issued one step ahead so it overlaps the kernels) -- as the 8.3 MB input frame, which
-every rank upscales itself (one more 17 us scale per step than at N = 1; 33 MB of upscaled frame per
-0.8 ms step would cost more on xGMI than that).  Weak scaling.
+every rank upscales itself (one more 13 us scale per step than at N = 1; 33 MB of upscaled frame per
+0.5 ms step would cost more on xGMI than that).  Weak scaling.
 
 Besides the headline line's `value`, rank 0 at N = 1 measures in the same run (short, after the timed region): the
 scale-only (BASELINE config 2) and scale + interpolate rates -- the two configurations SURVEY.md 8(d) says HBM is
@@ -582,6 +590,7 @@ def main():
                                                                     else "motion(8,16)+interpolate at input resolution, then scale real and generated frame" if in_res
                                                                     else "scale only")),
                        "input": [w_in, h_in], "output": [w, h], "factors": factors if args.workload != "scale" else [],
+                       "frames_in_flight": n_lanes,       # lanes of the C-ABI; 1 = strictly one frame at a time
                        "content": args.content + (" (the motion stage's best case but `static`; see content_sweep)" if args.content == "translated" and args.workload != "scale" else ""),
                        "parallelism": f"one frame pair per GPU x{world}" + (", lfg_broadcast_frame (RCCL) of the shared previous input frame per step, upscaled on every rank" if world > 1 else "")},
             "roofline": roofline,
