@@ -515,9 +515,14 @@ __device__ __forceinline__ void prefilter_unit(
         constexpr int kGroups = (kWinW + 3) / 4;                       // 24 groups per window row (the last holds 3 texels)
         constexpr int kRounds = (kWinH * kGroups + kPNT - 1) / kPNT;   // 10
         uint4 v[kRounds];
+        // (the thread number goes through an empty asm: its row / group split is the same for every unit a persistent
+        //  workgroup takes, and hoisted out of that loop the twenty values sit in scratch -- each reload, with the
+        //  s_waitcnt vmcnt(0) it brings, then waited for the previous window load: ten loads one after the other)
+        int tidL = tid;
+        asm volatile("" : "+v"(tidL));
 #pragma unroll
         for (int k = 0; k < kRounds; ++k) {
-            const int i = k * kPNT + tid;
+            const int i = k * kPNT + tidL;
             const int wy = stageRow0 + i / kGroups, g = i % kGroups;
             const int gx = bx0 - kR + 4 * g, gy = by0 - kR + wy;
             // branch-free: the load goes to the nearest group inside the image and is dropped afterwards
@@ -525,9 +530,10 @@ __device__ __forceinline__ void prefilter_unit(
                                                              (size_t)clampi(gx, 0, W - 4) * 4u);
             v[k] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? t : uint4{0u, 0u, 0u, 0u};
         }
+        asm volatile("" : "+v"(tidL));
 #pragma unroll
         for (int k = 0; k < kRounds; ++k) {
-            const int i = k * kPNT + tid;
+            const int i = k * kPNT + tidL;
             const int wy = stageRow0 + i / kGroups, g = i % kGroups;
             if (i < stageRows * kGroups) {
                 uint32_t *dst = sWin + (4 * g) * kWinH + wy;
@@ -1321,15 +1327,18 @@ __device__ __forceinline__ void prefilter_unit(
         // hand-over decision counts that batch's.)
         uint32_t *const pend = sPending[wave];
         int pendCount = 0;
+        const bool mayHandOver = whole && !fromQueue && order32[kCand] != 0u;     // (read once: the loop below runs ~19 times per wave)
         for (int i0 = 0, count = 2;;) {
             const bool flushOnly = byRank ? rank0 >= (int)min(zeroBound, (uint32_t)kCand) : i0 >= nEntries;
             if (flushOnly && pendCount == 0) break;
             if (!flushOnly && !byRank && i0 >= max(nHead, 2) && zeroBound < (uint32_t)kCand && (int)zeroBound + 64 <= nEntries - i0) {
                 byRank = true; rank0 = 0; visited = i0;
             }
+            // (the two batches at which a wave decides how to go on: hand-over, narrow search)
+            const bool decisionPoint = !flushOnly && !byRank && (i0 == hintsEnd || i0 == hintsEnd + 64);
             // Hand the segment over?  Either no threshold to test against once every hint has been tried, or the test
             // let a quarter of the first full batch through.
-            if (!flushOnly && !byRank && whole && !fromQueue && order32[kCand] != 0u &&
+            if (decisionPoint && mayHandOver &&
                 ((i0 == hintsEnd && !(waveThr < 4.0f * 510.0f)) || (i0 == hintsEnd + 64 && firstBatchSurvivors >= 16))) {
                 // LFG_DYN_PARTS parts of the candidate order, four per queue entry (one workgroup each); the entries of a
                 // segment are consecutive slots, so its private lists are the blocks 4 slot .. 4 slot + parts - 1
@@ -1347,7 +1356,7 @@ __device__ __forceinline__ void prefilter_unit(
                     return 2;
                 }
             }
-            if (LFG_NARROW && !flushOnly && !narrow && !byRank && i0 == hintsEnd && !(waveThr < LFG_NARROW_THR)) {
+            if (LFG_NARROW && decisionPoint && !narrow && i0 == hintsEnd && !(waveThr < LFG_NARROW_THR)) {
                 enterNarrow();
                 if (narrow) refreshZeroBound();    // the largest threshold of the pixels that stay wide
             }
@@ -1388,6 +1397,16 @@ __device__ __forceinline__ void prefilter_unit(
                 }
                 m = latticeBatch(ordL & 0x7FFFFFFFu, need, byRank || count == 64);
                 firstFull = !byRank && i0 == hintsEnd;
+                if (m == 0ull && pendCount < 64) {     // the common case: the tests dropped the whole batch and nothing is due
+                    if (firstFull) firstBatchSurvivors = 0;
+#ifdef LFG_MOTION_STAMPS
+                    stampBatches += 1u;
+                    if (!byRank && i0 == 0) stampFirst = __builtin_amdgcn_s_memrealtime();
+#endif
+                    if (byRank) rank0 += 64;
+                    else { i0 += count; count = i0 == 2 ? hintsEnd - 2 : 64; }
+                    continue;
+                }
                 if (sixteenApplies() && __builtin_popcountll(m) > 8) {     // the survivors wait for company
                     const uint32_t at = (uint32_t)pendCount + (uint32_t)__builtin_popcountll(m & ((1ull << l) - 1ull));
                     wave_lds_sync();
@@ -1494,22 +1513,23 @@ __device__ __forceinline__ void prefilter_unit(
     // Threshold and count of every pixel, for the resolve kernel -- which never looks at a segment that settles all of
     // its pixels below, so such a segment (most of a frame under a pan) does not write them at all.
     auto writeThresholds = [&]() {
+        // wave-uniform bases (whole tiles: the image-shaped arrays; shared tiles: the unit's private block) plus 32-bit lane
+        // offsets, like the lists: a per-lane 64-bit pointer here was spilled, and its reload -- s_waitcnt vmcnt(0) --
+        // made each of the 28 stores wait for the one before (20 us per wave that writes its thresholds)
+        const size_t first = whole ? (size_t)(ty0 + kSeg * seg) * (size_t)W + (size_t)tx0
+                                   : ((size_t)auxUnit * auxRows + (size_t)(kSeg * seg - auxRow0)) * (size_t)kPTW;
+        float *const uBase = (whole ? uminOut : auxUminBase) + first;
+        uint32_t *const cBase = (whole ? countOut : auxCountBase) + first;
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
             const int py = ty0 + kSeg * seg + 8 * hb + r8;
+            const uint32_t off = (uint32_t)(8 * hb + r8) * rowStride + (uint32_t)(kRun * q);
 #pragma unroll
             for (int i = 0; i < kRun; ++i) {
                 if (!gaveUp && py < H && px0 + i < W) {
                     const uint32_t cnt = (cnt2[hb][i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
-                    if (whole) {
-                        const size_t gp = (size_t)py * (size_t)W + (size_t)(px0 + i);
-                        uminOut[gp] = hb ? thr2[i].y : thr2[i].x;
-                        countOut[gp] = cnt;
-                    } else {
-                        const size_t ap = ((size_t)auxUnit * auxRows + (size_t)(py - ty0 - auxRow0)) * kPTW + (size_t)(px0 + i - tx0);
-                        auxUminBase[ap] = hb ? thr2[i].y : thr2[i].x;
-                        auxCountBase[ap] = cnt;
-                    }
+                    uBase[off + (uint32_t)i] = hb ? thr2[i].y : thr2[i].x;
+                    cBase[off + (uint32_t)i] = cnt;
                 }
             }
         }
@@ -1560,6 +1580,11 @@ __device__ __forceinline__ void prefilter_unit(
         // write requests per 4K frame for 16.6 MB of vectors).
         if (__builtin_amdgcn_readfirstlane(__ballot(!allSettled) == 0ull)) {
             uint16_t *const rows = reinterpret_cast<uint16_t *>(sSlab[wave]);          // [16][56] vectors (1,792 of 2,176 bytes)
+            // (the lane number goes through an empty asm: the slab addresses derived from it are the same for every unit,
+            //  and hoisted out of the workgroup's loop over units they are spilled and reloaded here behind a wait)
+            int laneE = lane;
+            asm volatile("" : "+v"(laneE));
+            const int r8E = laneE & 7, qE = laneE >> 3;
             wave_lds_sync();
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb) {
@@ -1567,16 +1592,16 @@ __device__ __forceinline__ void prefilter_unit(
                 for (int i = 0; i < kRun; ++i) {
                     const int scan = (int)rank2scan[best[hb][i] != 0xFFFFFFFFu ? best[hb][i] : 0u];     // (outside the image: never stored)
                     const int dyi = scan / kSide, dxi = scan - dyi * kSide;
-                    rows[(8 * hb + r8) * kPTW + kRun * q + i] = (uint16_t)(uint8_t)(int8_t)(dxi - kR) | (uint16_t)((uint16_t)(uint8_t)(int8_t)(dyi - kR) << 8);
+                    rows[(8 * hb + r8E) * kPTW + kRun * qE + i] = (uint16_t)(uint8_t)(int8_t)(dxi - kR) | (uint16_t)((uint16_t)(uint8_t)(int8_t)(dyi - kR) << 8);
                 }
             }
             wave_lds_sync();
             const bool wide = ((mvPitch & 3) == 0) && (((uintptr_t)mv & 3u) == 0u);       // 4-byte stores need 4-byte rows
-            const int half = lane / 28, d = lane - half * 28;                            // 28 dwords = one row of the tile
+            const int half = laneE / 28, d = laneE - half * 28;                          // 28 dwords = one row of the tile
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) {
                 const int row = 2 * rr + half, py = ty0 + kSeg * seg + row, px = tx0 + 2 * d;
-                if (lane < 56 && py < H && px < W) {
+                if (laneE < 56 && py < H && px < W) {
                     const uint32_t two = *reinterpret_cast<const uint32_t *>(rows + row * kPTW + 2 * d);
                     int8_t *dst = mv + (size_t)py * (size_t)mvPitch + (size_t)px * 2u;
                     if (wide && px + 1 < W) *reinterpret_cast<uint32_t *>(dst) = two;
