@@ -189,7 +189,7 @@ __device__ __forceinline__ void scale_2x_strip(
     const FusedSource &fs, const uint8_t *__restrict__ in, int inW, int inH, int inPitch,
     uint8_t *__restrict__ out, int outW, int outH, int outPitch,
     const uint8_t *__restrict__ classX, const float *__restrict__ paletteX, const float *__restrict__ weightY,
-    int rBegin, int n, int cg, int lane, SlabPtr slabW
+    int rBegin, int n, int cg, int laneArg, SlabPtr slabW
 #ifdef LFG_DIAG_STAMPS
     , unsigned long long *stamps, unsigned long long tStart, unsigned long long clk0, int st, int wv
 #endif
@@ -200,6 +200,12 @@ __device__ __forceinline__ void scale_2x_strip(
 #endif
     // (a strip reads n + 5 input rows; the unrolled sequence requests rows as if it had STEPS steps)
     constexpr int T = STEPS + 5;
+    // The lane number is taken afresh in every body (volatile: not merged across the three): kept alive from the kernel's
+    // entry across the three-way branch it was spilled, and the shortest body's reload -- s_waitcnt vmcnt(0) -- sat between
+    // its first two row loads and the rest.
+    int lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(lane));
+    (void)laneArg;
     const int c0 = cg * kOwnedCols - 4 + 2 * lane;        // the lane's even input column (c1 = c0 + 1)
     const bool owned = lane >= 2 && lane < 2 + kOwnedLanes && c0 < inW;
     const int rFirst = rBegin - 5;
