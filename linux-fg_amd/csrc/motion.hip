@@ -528,7 +528,10 @@ __device__ __forceinline__ void prefilter_unit(
             // branch-free: the load goes to the nearest group inside the image and is dropped afterwards
             const uint4 t = *reinterpret_cast<const uint4 *>(prev + (size_t)clampi(gy, 0, H - 1) * (size_t)prevPitch +
                                                              (size_t)clampi(gx, 0, W - 4) * 4u);
-            v[k] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? t : uint4{0u, 0u, 0u, 0u};
+            // (a mask, not a select: the compiler turns the select into a branch that waits for this load before the next
+            //  one is issued -- ten memory latencies in a row for every tile that touches the image border)
+            const uint32_t keep = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? 0xFFFFFFFFu : 0u;
+            v[k] = uint4{t.x & keep, t.y & keep, t.z & keep, t.w & keep};
         }
         asm volatile("" : "+v"(tidL));
 #pragma unroll
@@ -553,7 +556,7 @@ __device__ __forceinline__ void prefilter_unit(
                 const int gx = bx0 - kR + wx, gy = by0 - kR + wy;
                 const uint32_t t = *reinterpret_cast<const uint32_t *>(prev + (size_t)clampi(gy, 0, H - 1) * (size_t)prevPitch +
                                                                        (size_t)clampi(gx, 0, W - 1) * 4u);
-                v[k] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? t : 0u;
+                v[k] = t & ((gx >= 0 && gx < W && gy >= 0 && gy < H) ? 0xFFFFFFFFu : 0u);      // (a mask: see above)
             }
 #pragma unroll
             for (int k = 0; k < kStageAhead; ++k) {
