@@ -1589,11 +1589,20 @@ __device__ __forceinline__ void prefilter_unit(
             asm volatile("" : "+v"(laneE));
             const int r8E = laneE & 7, qE = laneE >> 3;
             wave_lds_sync();
+            // (all fourteen table reads first: interleaved with the slab stores -- through a generic pointer, which the
+            //  compiler must assume may alias -- each read waited for the one before, fourteen L2 round trips in a row)
+            int scanOf[2][kRun];
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+                for (int i = 0; i < kRun; ++i)
+                    scanOf[hb][i] = (int)rank2scan[best[hb][i] != 0xFFFFFFFFu ? best[hb][i] : 0u];     // (outside the image: never stored)
+            }
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb) {
 #pragma unroll
                 for (int i = 0; i < kRun; ++i) {
-                    const int scan = (int)rank2scan[best[hb][i] != 0xFFFFFFFFu ? best[hb][i] : 0u];     // (outside the image: never stored)
+                    const int scan = scanOf[hb][i];
                     const int dyi = scan / kSide, dxi = scan - dyi * kSide;
                     rows[(8 * hb + r8E) * kPTW + kRun * qE + i] = (uint16_t)(uint8_t)(int8_t)(dxi - kR) | (uint16_t)((uint16_t)(uint8_t)(int8_t)(dyi - kR) << 8);
                 }
