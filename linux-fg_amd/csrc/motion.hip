@@ -1870,8 +1870,11 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
     {
         const int y0 = (int)blockIdx.y * 4, x0 = (int)blockIdx.x * 64, x1 = min(x0 + 63, W - 1);
         const int row = (y0 / kPTH) * sp.tilesX, seg = (y0 % kPTH) / kSeg;
-        if (tileFlags[(y0 / kTH) * tilesX + (int)blockIdx.x] == 0u &&          // (a flagged tile's pixels are preset below)
-            segDone[(row + x0 / kPTW) * (kPTH / kSeg) + seg] != 0u && segDone[(row + x1 / kPTW) * (kPTH / kSeg) + seg] != 0u) return;
+        // (three independent scalar loads, one wait: with `&&` they were a chain of three round trips, and nine blocks in
+        //  ten of a frame under a pan do nothing but this)
+        const uint32_t flag = tileFlags[(y0 / kTH) * tilesX + (int)blockIdx.x];  // (a flagged tile's pixels are preset below)
+        const uint32_t doneA = segDone[(row + x0 / kPTW) * (kPTH / kSeg) + seg], doneB = segDone[(row + x1 / kPTW) * (kPTH / kSeg) + seg];
+        if ((flag == 0u) & (doneA != 0u) & (doneB != 0u)) return;
     }
 #ifdef LFG_MOTION_STAMPS
     const unsigned long long stampT0 = __builtin_amdgcn_s_memrealtime();
