@@ -1154,3 +1154,35 @@ def test_lanes_keep_frames_in_flight_apart():
         assert ctx.lane_count() == 1
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_narrow_bands_deferred_test_and_rank_walk_agree_with_the_literal_kernel(ctx, seed):
+    """The round-2 shortcuts of the prefilter, each provoked on purpose and compared with the literal kernel on the whole
+    frame: vertical strips of fresh noise 3 / 7 / 11 / 15 columns wide at arbitrary x (narrow search with 5 / 4 / 3 / 2
+    candidates per pass, inside the frame and at its left and right edge), a strip too wide for it, a band of sensor noise
+    (the four-point test's survivors wait for the deferred sixteen-point test), a static region and an exactly panned one
+    (every pixel owns a zero-cost candidate: the by-rank walk), and a pan that exposes strips at two borders."""
+    from linux_fg_amd import capi
+    rng = np.random.default_rng(9000 + seed)
+    w, h = 1176, 416                                  # 21 x 6.5 prefilter tiles: rim and interior tiles, a partial last row
+    prev = synth.make_prev(w, h, seed=9000 + seed)
+    curr = synth.translate(prev, (int(rng.integers(-4, 5)), int(rng.integers(-3, 4))), 9000 + seed)
+    curr[:, 300:600] = prev[:, 300:600]               # a static region
+    fresh = synth.noise_bytes(w, h, 9100 + seed)
+    x = 8
+    for width in (3, 7, 11, 15, 15, 11, 7, 3, 23):    # strips inside the frame ...
+        x += int(rng.integers(40, 90))
+        y0, y1 = sorted(int(v) for v in rng.integers(0, h, 2))
+        y1 = max(y1, min(h, y0 + 40))
+        curr[y0:y1, x:x + width] = fresh[y0:y1, x:x + width]
+        x += width
+    curr[:, :5] = fresh[:, :5]                        # ... and at both edges
+    curr[:, w - 9:] = fresh[:, w - 9:]
+    n = synth.noise_bytes(w, h, 9200 + seed) % 5      # sensor noise on a band of rows
+    noisy = np.clip(curr.astype(np.int16) + n.astype(np.int16) - 2, 0, 255).astype(np.uint8)
+    curr[330:400] = noisy[330:400]
+    a, st = run_motion_mode(ctx, prev, curr, capi.MOTION_PREFILTERED)
+    b, _ = run_motion_mode(ctx, prev, curr, capi.MOTION_EXACT_ONLY)
+    assert (a == b).all()
+    assert st[1] == 0                                 # no tile needed the literal kernel
