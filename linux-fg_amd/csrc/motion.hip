@@ -340,10 +340,11 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
 //     ds_read2_b32 per input pair, all 32 banks distinct);
 //   * row sums, per lane two runs of 7 pixels (rows r and r+8) packed side by side: 14 input pairs -> shared
 //     pairwise tree (31 packed adds) -> 7 + 7 S~, threshold test, list append.
-//   LDS: 38.2 KB window + 4 x 2.1 KB slabs + 4.3 KB visiting order = 51 KB -> three workgroups (12 waves) per CU.
+//   LDS: 38.2 KB window + 4 x 5.1 KB slabs (the wide passes use 2.1 KB of each) + 4.3 KB visiting order + 2.2 KB its
+//   inverse + 8 KB narrow-search state + 2 KB waiting candidates = 75 KB; 256 VGPRs -> two workgroups (8 waves) per CU.
 //   DS operations of one wave execute in order, so a slab needs neither double buffering nor barriers.  Loop order
 //   per surviving candidate e: window reads(e+1) issued | row sums + test(e) | column sums(e+1) | slab
-//   write/read(e+1); the slab round trip is the one exposed latency, covered by the other two waves of the SIMD.
+//   write/read(e+1); the slab round trip is the one exposed latency, covered by the other wave of the SIMD.
 
 constexpr int kPTW = 56, kPTH = 64;               // prefilter tile (pixels): 56 + 7 = 63 position columns <= 64 lanes
 constexpr int kPNT = 256;
