@@ -947,8 +947,8 @@ __device__ __forceinline__ void prefilter_unit(
                 uint32_t rowRelevant = 0u;                              // bit b: some pixel row inside the image maps to vertical group b
 #pragma unroll
                 for (int b = 0; b < 5; ++b) rowRelevant |= (!border || rowsL + max(0, 4 * b - 3) < H) ? (1u << b) : 0u;
-                // (a rolled loop, two columns per trip: sixteen unrolled columns are 2,000 instructions, and the kernel's code
-                //  has to share a 64 KB instruction cache with the neighbouring CU's)
+                // (a rolled loop, two columns per trip: sixteen unrolled columns were 2,000 instructions and 7 % slower where
+                //  this test dominates -- not for instruction-cache misses, SQC_ICACHE_MISSES stays at 0.01 %)
 #pragma unroll 2
                 for (int a = 0; a < 16; ++a) {
                     // (the lane select goes through an empty asm: the current-frame texels are the same in every batch,
@@ -1004,8 +1004,8 @@ __device__ __forceinline__ void prefilter_unit(
                 // tree, the group sum here in four levels.  Mean 3,300: every wrong candidate falls to it while the
                 // threshold stays below 2,048.  The lane walks the lattice column by column -- twelve distances, eleven
                 // pair sums, nine vertical sums of four, and the running sums over four columns -- 4,400 instructions per
-                // batch of 64 candidates: a sixth of evaluating them.  A rolled loop (the code of 32 columns would not
-                // fit the instruction cache); positions outside the image add nothing, groups that no pixel inside the
+                // batch of 64 candidates: a sixth of evaluating them.  A rolled loop (32 unrolled columns would be 4,000
+                // instructions); positions outside the image add nothing, groups that no pixel inside the
                 // image maps to are left out.
                 auto bitsOf = [](float d) { return __builtin_bit_cast(uint32_t, d); };
                 lds_ro_u32_ptr w = (lds_ro_u32_ptr)(sWin + kSeg * seg) + (ordL >> 16);
@@ -1258,7 +1258,7 @@ __device__ __forceinline__ void prefilter_unit(
                 }
                 if (pending) {             // the slab holds the previous pass: sixteen rows of perPass candidates' column sums
                     wave_lds_sync();
-#pragma nounroll                   // (one copy of the test: the loop has to fit the instruction cache)
+#pragma nounroll                   // (one copy of the test, not one per candidate)
                     for (int k = 0; k < perPass && idxP + k < iEnd; ++k) {
                         const lds_ro_f32_ptr base = nSlabR + 2 * (colsPer / 4) * k;
                         float X[4 + kB - 1];
