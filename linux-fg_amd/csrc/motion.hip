@@ -2328,9 +2328,17 @@ void motion_tables(bool intended, uint32_t *rank2scan, uint32_t *order32, uint32
 
 constexpr int kHintWin = kB + 2 * kR;                // 40 x 40 texels of prev around a sample block
 
-constexpr int kHintThreads = 1024;                   // one or two candidates per thread: the kernel is a latency chain, not work
+// 256 threads, four or five candidates each, at most 128 VGPRs: a workgroup fits into the room ONE workgroup of a running
+// prefilter launch leaves on a CU.  With 1,024 threads (one or two candidates each, 10 us on an idle chip instead of 13)
+// it needed a CU with no prefilter workgroup at all, and with frames in flight (lanes) the next frame's hints waited
+// 300-500 us for one (kernel trace; the frame rate is the same -- the prefilter's workgroup slots are the bound -- but the
+// lanes' latency is not).
+#ifndef LFG_HINT_THREADS
+#define LFG_HINT_THREADS 256
+#endif
+constexpr int kHintThreads = LFG_HINT_THREADS;
 
-__global__ __launch_bounds__(kHintThreads) void motion_hint_kernel(
+__global__ __launch_bounds__(kHintThreads, kHintThreads <= 256 ? 4 : 1) void motion_hint_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int W, int H, uint32_t *__restrict__ hints) {
     __shared__ uint32_t sP[kHintWin * kHintWin];
