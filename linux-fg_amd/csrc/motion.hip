@@ -365,6 +365,9 @@ constexpr int kRunIn = kRun + kB - 1;             // 13
 #ifndef LFG_ZERO_COMPARE
 #define LFG_ZERO_COMPARE 1
 #endif
+#ifndef LFG_LOOKAHEAD
+#define LFG_LOOKAHEAD 1
+#endif
 // Narrow search (prefilter_unit, "Narrow search"): the band of pixel columns that holds a segment's pixels without a
 // match, at most sixteen columns wide, searched several candidates per pass.
 #ifndef LFG_NARROW
@@ -1387,18 +1390,74 @@ __device__ __forceinline__ void prefilter_unit(
             uint32_t l;                    // lane number; volatile, so that it is not hoisted out of the loop and spilled
             asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(l));
             if (!flushOnly) {
-                bool need;
-                if (!byRank) {
-                    const int idx = i0 + (int)l;
-                    ordL = ((lds_ro_u32_ptr)sOrder)[min(idx < nHead ? idx : eBegin + (idx - nHead), kCand - 1)];
-                    need = (int)l < count && idx < nEntries && (ordL & 0xFFFFu) < zeroBound;
-                    ordL |= idx >= nHead ? 0x80000000u : 0u;
-                } else {
-                    const int r = rank0 + (int)l;
+                // this lane's candidate `ahead` entries (ranks) beyond the batch's first
+                auto candidateAt = [&](int ahead, uint32_t &ord) -> bool {
+                    if (!byRank) {
+                        const int idx = i0 + ahead + (int)l;
+                        ord = ((lds_ro_u32_ptr)sOrder)[min(idx < nHead ? idx : eBegin + (idx - nHead), kCand - 1)];
+                        const bool nd = (ahead != 0 || (int)l < count) && idx < nEntries && (ord & 0xFFFFu) < zeroBound;
+                        ord |= idx >= nHead ? 0x80000000u : 0u;
+                        return nd;
+                    }
+                    const int r = rank0 + ahead + (int)l;
                     const int e = (int)sInv[min(r, kCand - 1)];                       // where the order visits rank r
-                    ordL = ((lds_ro_u32_ptr)sOrder)[e] | 0x80000000u;
-                    need = r < (int)zeroBound && e >= eBegin && e < eEnd && nHead + (e - eBegin) >= visited;
+                    ord = ((lds_ro_u32_ptr)sOrder)[e] | 0x80000000u;
+                    return r < (int)zeroBound && e >= eBegin && e < eEnd && nHead + (e - eBegin) >= visited;
+                };
+                // LOOKAHEAD.  While the thresholds are small (the one-point test alone decides, and nearly always "no") a
+                // batch is three LDS round trips of latency around a few dozen instructions -- and a workgroup's time on
+                // its CU slot, not its instruction count, is what a frame costs once frames overlap.  So
+                // the wave first asks about the next 128 candidates at once -- two per lane, their window reads in flight
+                // together, the current-frame texels of the lattice points fetched once for both -- and if none of them
+                // has to be looked at, skips both batches.  Otherwise the batches are taken one by one as usual.
+                if (LFG_LOOKAHEAD && !border && waveThr < kOnePointMax && pendCount < 64 && (byRank || (count == 64 && i0 != hintsEnd)) &&
+                    (byRank ? rank0 + 64 < (int)min(zeroBound, (uint32_t)kCand) : i0 + 64 < nEntries)) {
+                    uint32_t ordA, ordB;
+                    const bool needA = candidateAt(0, ordA), needB = candidateAt(64, ordB);
+                    const lds_ro_u32_ptr wA = (lds_ro_u32_ptr)(sWin + kSeg * seg) + ((ordA & 0x7FFFFFFFu) >> 16);
+                    const lds_ro_u32_ptr wB = (lds_ro_u32_ptr)(sWin + kSeg * seg) + ((ordB & 0x7FFFFFFFu) >> 16);
+                    uint32_t texA[8][3], texB[8][3];
+#pragma unroll
+                    for (int ci = 0; ci < 8; ++ci) {
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) { texA[ci][t] = wA[(3 + 8 * ci) * kWinH + 3 + 8 * t]; texB[ci][t] = wB[(3 + 8 * ci) * kWinH + 3 + 8 * t]; }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    bool keepA, keepB;                 // some lattice distance does not exceed the wave's largest threshold
+                    if (waveThr < 0.5f) {              // (zero-cost thresholds: "exceeds" means "differs"; see latticeBatch)
+                        bool sameA = false, sameB = false;
+#pragma unroll
+                        for (int ci = 0; ci < 8; ++ci) {
+#pragma unroll
+                            for (int t = 0; t < 3; ++t) {
+                                const uint32_t cT = (uint32_t)__builtin_amdgcn_readlane((int)c[3 + 8 * t], 3 + 8 * ci);
+                                sameA = sameA | (texA[ci][t] == cT); sameB = sameB | (texB[ci][t] == cT);
+                            }
+                        }
+                        keepA = sameA; keepB = sameB;
+                    } else {
+                        uint32_t dA = 0x7F800000u, dB = 0x7F800000u;
+#pragma unroll
+                        for (int ci = 0; ci < 8; ++ci) {
+#pragma unroll
+                            for (int t = 0; t < 3; ++t) {
+                                const uint32_t cT = (uint32_t)__builtin_amdgcn_readlane((int)c[3 + 8 * t], 3 + 8 * ci);
+                                dA = min(dA, __builtin_bit_cast(uint32_t, distanceOf(cT, texA[ci][t])));
+                                dB = min(dB, __builtin_bit_cast(uint32_t, distanceOf(cT, texB[ci][t])));
+                            }
+                        }
+                        const uint32_t thrSqBits = __builtin_bit_cast(uint32_t, (waveThr * waveThr) * 1.000001f);
+                        keepA = !(dA > thrSqBits); keepB = !(dB > thrSqBits);
+                    }
+                    if (__ballot((needA && keepA) || (needB && keepB)) == 0ull) {
+#ifdef LFG_MOTION_STAMPS
+                        stampBatches += 2u;
+#endif
+                        if (byRank) rank0 += 128; else i0 += 128;
+                        continue;
+                    }
                 }
+                bool need = candidateAt(0, ordL);
                 m = latticeBatch(ordL & 0x7FFFFFFFu, need, byRank || count == 64);
                 firstFull = !byRank && i0 == hintsEnd;
                 if (m == 0ull && pendCount < 64) {     // the common case: the tests dropped the whole batch and nothing is due
