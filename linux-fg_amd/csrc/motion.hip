@@ -368,6 +368,9 @@ constexpr int kRunIn = kRun + kB - 1;             // 13
 #ifndef LFG_LOOKAHEAD
 #define LFG_LOOKAHEAD 1
 #endif
+#ifndef LFG_FIRST_BATCH
+#define LFG_FIRST_BATCH 1                // entries of the first batch: the top hint alone (2: with zero motion, as in round 1)
+#endif
 // Narrow search (prefilter_unit, "Narrow search"): the band of pixel columns that holds a segment's pixels without a
 // match, at most sixteen columns wide, searched several candidates per pass.
 #ifndef LFG_NARROW
@@ -1313,8 +1316,10 @@ __device__ __forceinline__ void prefilter_unit(
             }
             return true;
         };
-        // Batches: the top hint and zero motion; then the other hints of this call (at least six entries, so that units
-        // which run the first eight for their thresholds see the same boundary); then sixty-four at a time.
+        // Batches: the top hint alone (under a pan its evaluation is all a wave ever evaluates: zero motion, next in the
+        // order, then fails the cheap test or is skipped by rank instead of costing a second evaluation); then zero motion
+        // and the other hints of this call (at least seven entries, so that units which run the first eight for their
+        // thresholds see the same boundary); then sixty-four at a time.
         const int hintsEnd = nHead ? kHead : max(kHead, min((int)order32[kCand + 1], 2 + 62));
         int firstBatchSurvivors = 0;
         // BY RANK.  Once every pixel of the wave owns a zero-cost candidate only candidates that come EARLIER in the tie
@@ -1335,10 +1340,10 @@ __device__ __forceinline__ void prefilter_unit(
         uint32_t *const pend = sPending[wave];
         int pendCount = 0;
         const bool mayHandOver = whole && !fromQueue && order32[kCand] != 0u;     // (read once: the loop below runs ~19 times per wave)
-        for (int i0 = 0, count = 2;;) {
+        for (int i0 = 0, count = LFG_FIRST_BATCH;;) {
             const bool flushOnly = byRank ? rank0 >= (int)min(zeroBound, (uint32_t)kCand) : i0 >= nEntries;
             if (flushOnly && pendCount == 0) break;
-            if (!flushOnly && !byRank && i0 >= max(nHead, 2) && zeroBound < (uint32_t)kCand && (int)zeroBound + 64 <= nEntries - i0) {
+            if (!flushOnly && !byRank && i0 >= max(nHead, LFG_FIRST_BATCH) && zeroBound < (uint32_t)kCand && (int)zeroBound + 64 <= nEntries - i0) {
                 byRank = true; rank0 = 0; visited = i0;
             }
             // (the two batches at which a wave decides how to go on: hand-over, narrow search)
@@ -1467,7 +1472,7 @@ __device__ __forceinline__ void prefilter_unit(
                     if (!byRank && i0 == 0) stampFirst = __builtin_amdgcn_s_memrealtime();
 #endif
                     if (byRank) rank0 += 64;
-                    else { i0 += count; count = i0 == 2 ? hintsEnd - 2 : 64; }
+                    else { i0 += count; count = i0 == LFG_FIRST_BATCH ? hintsEnd - LFG_FIRST_BATCH : 64; }
                     continue;
                 }
                 if (sixteenApplies() && __builtin_popcountll(m) > 8) {     // the survivors wait for company
@@ -1539,7 +1544,7 @@ __device__ __forceinline__ void prefilter_unit(
             if (!byRank && i0 == 0) stampFirst = __builtin_amdgcn_s_memrealtime();
 #endif
             if (byRank) rank0 += 64;
-            else { i0 += count; count = i0 == 2 ? hintsEnd - 2 : 64; }
+            else { i0 += count; count = i0 == LFG_FIRST_BATCH ? hintsEnd - LFG_FIRST_BATCH : 64; }
         }
         if (narrow && !narrowPhase(hintsEnd)) return 1;
         return __builtin_amdgcn_readfirstlane(__ballot(listsOverflowed()) != 0ull) ? 1 : 0;
