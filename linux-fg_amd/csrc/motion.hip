@@ -1552,9 +1552,12 @@ __device__ __forceinline__ void prefilter_unit(
     const int outcome = run();
     const bool gaveUp = outcome == 1;
 #ifdef LFG_MOTION_STAMPS
+    const unsigned long long stampRunEnd = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef LFG_MOTION_STAMPS
     if (lane == 0 && (fromQueue ? sp.units + unit : unit) < 8192) {
         unsigned long long *o = gMotionStamps + ((size_t)(fromQueue ? sp.units + unit : unit) * 4 + wave) * 8;
-        o[0] = stampStart; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = stampEvals; o[3] = ((unsigned long long)borderTile << 32) | stampBatches;
+        o[0] = stampStart; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = stampEvals; o[3] = ((unsigned long long)borderTile << 32) | stampBatches | (((stampRunEnd - stampStart) & 0x3FFFFFFFull) << 33);
         o[4] = stampStaged; o[5] = stampFirst; o[6] = ((unsigned long long)stampBox << 32) | stampNarrow | (stampFour << 8) | ((unsigned long long)(fromQueue ? 1u : 0u) << 9) | ((unsigned long long)seg << 10) | ((unsigned long long)tileX << 12) | ((unsigned long long)tileY << 20);
         o[7] = ((unsigned long long)stampThrEnd << 32) | stampThr;
     }
@@ -1740,39 +1743,59 @@ __device__ __forceinline__ void prefilter_unit(
             }
         }
         __syncthreads();
+        // (three passes over this wave's share of the fourteen slots -- decide, read the table, store -- so that the table
+        //  reads are in flight together: read and stored slot by slot, each read waited for the store before it)
         bool open = false;
+        uint32_t bestOf[2][kRun];
+        bool singleOf[2][kRun];
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
             const int py = ty0 + kSeg * seg + 8 * hb + r8;
 #pragma unroll
             for (int i = 0; i < kRun; ++i) {
+                bestOf[hb][i] = 0xFFFFFFFFu; singleOf[hb][i] = false;
                 if (((kRun * hb + i) & 3) != wave) continue;           // the fourteen slots are dealt out to the four waves
-                if (!(py < H && px0 + i < W)) continue;
+                if (!(py < H && px0 + i < W)) { bestOf[hb][i] = 0xFFFFFFFEu; continue; }      // (outside the image: nothing to do)
                 const int at = (kRun * hb + i) * 64 + lane;
                 const float bound = __builtin_fminf(__builtin_fminf(sBound[at], sBound[kPix + at]),
                                                     __builtin_fminf(sBound[2 * kPix + at], sBound[3 * kPix + at]));
-                uint32_t best = 0xFFFFFFFFu;
-                bool single = false;
                 if (bound < 0.5f) {
-                    best = __builtin_bit_cast(uint32_t, bound) - 0x00800000u;
+                    bestOf[hb][i] = __builtin_bit_cast(uint32_t, bound) - 0x00800000u;
                 } else {
-                    uint32_t n = 0u, any = 0u, all = 0xFFFFFFFFu;
+                    uint32_t n = 0u, any = 0u;
 #pragma unroll
                     for (int w = 0; w < 4; ++w) {
                         const uint32_t word = sMine[w * kPix + at];
                         n += word != 0u ? 1u : 0u;
                         any |= word;
-                        all &= word != 0u ? word : 0xFFFFFFFFu;
                     }
-                    // exactly one wave reports, and it reports a single rank (any == all == that word)
-                    if (n == 1u && any != 0xFFFFFFFFu) { best = any & 0x7FFFFFFFu; single = true; }
-                    (void)all;
+                    // exactly one wave reports, and it reports a single rank
+                    if (n == 1u && any != 0xFFFFFFFFu) { bestOf[hb][i] = any & 0x7FFFFFFFu; singleOf[hb][i] = true; }
                 }
-                bool settled = best != 0xFFFFFFFFu;
+            }
+        }
+        int scanOfSeg[2][kRun];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+            for (int i = 0; i < kRun; ++i) {
+                scanOfSeg[hb][i] = 0;
+                if (((kRun * hb + i) & 3) != wave) continue;
+                scanOfSeg[hb][i] = (int)rank2scan[bestOf[hb][i] < (uint32_t)kCand ? bestOf[hb][i] : 0u];
+            }
+        }
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            const int py = ty0 + kSeg * seg + 8 * hb + r8;
+#pragma unroll
+            for (int i = 0; i < kRun; ++i) {
+                if (((kRun * hb + i) & 3) != wave) continue;
+                if (bestOf[hb][i] == 0xFFFFFFFEu) continue;            // outside the image
+                bool settled = bestOf[hb][i] != 0xFFFFFFFFu;
                 if (settled) {
-                    const int scan = (int)rank2scan[best];
+                    const int scan = scanOfSeg[hb][i];
                     const int dyi = scan / kSide, dxi = scan - dyi * kSide;
-                    if (single && block_leaves_prev(px0 + i, py, dxi - kR, dyi - kR, W, H)) settled = false;
+                    if (singleOf[hb][i] && block_leaves_prev(px0 + i, py, dxi - kR, dyi - kR, W, H)) settled = false;
                     if (settled) {
                         int8_t *dst = mv + (size_t)py * (size_t)mvPitch + (size_t)(px0 + i) * 2u;
                         *reinterpret_cast<uint16_t *>(dst) = (uint16_t)(uint8_t)(int8_t)(dxi - kR) | (uint16_t)((uint16_t)(uint8_t)(int8_t)(dyi - kR) << 8);   // both components, one store
@@ -1785,6 +1808,10 @@ __device__ __forceinline__ void prefilter_unit(
         __syncthreads();
         if (tid == 0 && *sOpen == 0u) segDone[tile * (kPTH / kSeg) + seg] = 1u;
     }
+#ifdef LFG_MOTION_STAMPS
+    if (lane == 0 && (fromQueue ? sp.units + unit : unit) < 8192)      // (the end of the unit with its epilogue)
+        gMotionStamps[((size_t)(fromQueue ? sp.units + unit : unit) * 4 + wave) * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // The prefilter's launch: as many workgroups as the device holds at once (prefilter_slots), each taking work units
@@ -2584,19 +2611,19 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
             const int n = std::min(sp.units, 8192);
             unsigned long long t0 = ~0ull, t1 = 0;
             for (int u = 0; u < n; ++u) for (int w = 0; w < 4; ++w) { const unsigned long long *o = &h[(u * 4 + w) * 8]; if (!o[1]) continue; t0 = std::min(t0, o[0]); t1 = std::max(t1, o[1]); }
-            double sum[2] = {0, 0}, mx[2] = {0, 0}, ev[2] = {0, 0}, stg[2] = {0, 0}, fst[2] = {0, 0}, bat[2] = {0, 0}; int cnt[2] = {0, 0};
+            double sum[2] = {0, 0}, mx[2] = {0, 0}, ev[2] = {0, 0}, stg[2] = {0, 0}, fst[2] = {0, 0}, bat[2] = {0, 0}, srch[2] = {0, 0}; int cnt[2] = {0, 0};
             for (int u = 0; u < n; ++u) {
-                unsigned long long a = ~0ull, b = 0, evals = 0, batches = 0; int rim = 0; double st = 0, fs = 0;
-                for (int w = 0; w < 4; ++w) { const unsigned long long *o = &h[(u * 4 + w) * 8]; if (!o[1]) continue; a = std::min(a, o[0]); b = std::max(b, o[1]); evals += o[2]; batches += o[3] & 0xFFFFFFFFull; rim = (int)(o[3] >> 32);
+                unsigned long long a = ~0ull, b = 0, evals = 0, batches = 0; int rim = 0; double st = 0, fs = 0, se = 0;
+                for (int w = 0; w < 4; ++w) { const unsigned long long *o = &h[(u * 4 + w) * 8]; if (!o[1]) continue; a = std::min(a, o[0]); b = std::max(b, o[1]); evals += o[2]; batches += o[3] & 0xFFFFFFFFull; rim = (int)((o[3] >> 32) & 1); se = std::max(se, (double)(o[3] >> 33) / 100.0);
                     st = std::max(st, (double)(o[4] - o[0]) / 100.0); if (o[5]) fs = std::max(fs, (double)(o[5] - o[4]) / 100.0); }
                 if (!b) continue;
                 const double us = (double)(b - a) / 100.0;
-                sum[rim] += us; mx[rim] = std::max(mx[rim], us); ev[rim] += (double)evals / 4; bat[rim] += (double)batches / 4; stg[rim] += st; fst[rim] += fs; ++cnt[rim];
+                sum[rim] += us; mx[rim] = std::max(mx[rim], us); ev[rim] += (double)evals / 4; bat[rim] += (double)batches / 4; srch[rim] += se; stg[rim] += st; fst[rim] += fs; ++cnt[rim];
                 if (u % 197 == 0) fprintf(stderr, "unit %d rim %d start %.1f us dur %.1f us evals/wave %.1f\n", u, rim, (double)(a - t0) / 100.0, us, (double)evals / 4);
             }
             for (int r = 0; r < 2; ++r)
-                fprintf(stderr, "%s units %d: mean %.1f us (staging %.1f, first batch %.1f), max %.1f us, evaluations per wave %.1f, batches per wave %.1f\n", r ? "rim" : "interior", cnt[r],
-                        sum[r] / std::max(cnt[r], 1), stg[r] / std::max(cnt[r], 1), fst[r] / std::max(cnt[r], 1), mx[r], ev[r] / std::max(cnt[r], 1), bat[r] / std::max(cnt[r], 1));
+                fprintf(stderr, "%s units %d: mean %.1f us (staging %.1f, first batch %.1f, search over after %.1f), max %.1f us, evaluations per wave %.1f, batches per wave %.1f\n", r ? "rim" : "interior", cnt[r],
+                        sum[r] / std::max(cnt[r], 1), stg[r] / std::max(cnt[r], 1), fst[r] / std::max(cnt[r], 1), srch[r] / std::max(cnt[r], 1), mx[r], ev[r] / std::max(cnt[r], 1), bat[r] / std::max(cnt[r], 1));
             fprintf(stderr, "span %.1f us\n", (double)(t1 - t0) / 100.0);
             {   // handed-over segments (queue units follow the plan's units in the stamp array)
                 unsigned long long qa = ~0ull, qb = 0, qlast = 0; double qsum = 0; int qn = 0; double qev = 0;
