@@ -4,6 +4,7 @@
 // two roundings unless the source says __builtin_fmaf.  The motion and interpolate kernels rely on
 // that to reproduce the reference shaders' arithmetic (as fixed in SURVEY.md section 8(c)) bit for bit.
 #pragma once
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 
@@ -130,5 +131,25 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// The largest of a wave's 64 unsigned values, as a wave-uniform (scalar) result.  Six DPP steps in the VALU -- within
+// quads (quad_perm), within half rows and rows (row_half_mirror, row_mirror), then across rows (row_bcast15, row_bcast31:
+// lane 63 ends up with everything) -- instead of six ds_bpermute round trips through the LDS pipeline, which is what
+// __shfl_xor compiles to (6 x ~120 cycles of latency in a chain).
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    // __builtin_amdgcn_update_dpp(old, src, dpp_ctrl, row_mask, bank_mask, bound_ctrl): lanes whose source is invalid keep
+    // `old` = 0, the identity of max over unsigned values
+    auto step = [](uint32_t x, auto ctrl, auto rowMask) {
+        const uint32_t moved = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, decltype(ctrl)::value, decltype(rowMask)::value, 0xF, false);
+        return x > moved ? x : moved;
+    };
+    v = step(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xF>{});    // quad_perm [1,0,3,2]
+    v = step(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xF>{});    // quad_perm [2,3,0,1]
+    v = step(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xF>{});   // row_half_mirror
+    v = step(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xF>{});   // row_mirror
+    v = step(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});   // row_bcast15 into rows 1 and 3
+    v = step(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});   // row_bcast31 into rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 
 }  // namespace lfg

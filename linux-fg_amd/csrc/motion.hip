@@ -829,9 +829,7 @@ __device__ __forceinline__ void prefilter_unit(
                 k = max(k, b0 == 0xFF800000u ? 0u : b0);               // -inf: a pixel outside the image
                 k = max(k, b1 == 0xFF800000u ? 0u : b1);
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) k = max(k, (uint32_t)__shfl_xor((int)k, off));
-            k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+            k = wave_max_u32(k);
             zeroBound = k < 0x00800000u + (uint32_t)kCand ? (k >= 0x00800000u ? k - 0x00800000u : 0u) : 0xFFFFFFFFu;
             zeroBound = (uint32_t)__builtin_amdgcn_readfirstlane((int)zeroBound);
             waveThr = __builtin_bit_cast(float, k);                    // largest threshold of the wave's pixels (+inf: none yet)
