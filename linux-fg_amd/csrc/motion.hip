@@ -366,7 +366,7 @@ constexpr int kRunIn = kRun + kB - 1;             // 13
 #define LFG_ZERO_COMPARE 1
 #endif
 #ifndef LFG_LOOKAHEAD
-#define LFG_LOOKAHEAD 1
+#define LFG_LOOKAHEAD 2                 // candidates per lane of the lookahead (0 or 1: off)
 #endif
 #ifndef LFG_FIRST_BATCH
 #define LFG_FIRST_BATCH 1                // entries of the first batch: the top hint alone (2: with zero motion, as in round 1)
@@ -1410,53 +1410,66 @@ __device__ __forceinline__ void prefilter_unit(
                 // LOOKAHEAD.  While the thresholds are small (the one-point test alone decides, and nearly always "no") a
                 // batch is three LDS round trips of latency around a few dozen instructions -- and a workgroup's time on
                 // its CU slot, not its instruction count, is what a frame costs once frames overlap.  So
-                // the wave first asks about the next 128 candidates at once -- two per lane, their window reads in flight
+                // the wave first asks about the next 128 candidates at once -- two per lane (LFG_LOOKAHEAD), their window reads in flight
                 // together, the current-frame texels of the lattice points fetched once for both -- and if none of them
                 // has to be looked at, skips both batches.  Otherwise the batches are taken one by one as usual.
-                if (LFG_LOOKAHEAD && !border && waveThr < kOnePointMax && pendCount < 64 && (byRank || (count == 64 && i0 != hintsEnd)) &&
-                    (byRank ? rank0 + 64 < (int)min(zeroBound, (uint32_t)kCand) : i0 + 64 < nEntries)) {
-                    uint32_t ordA, ordB;
-                    const bool needA = candidateAt(0, ordA), needB = candidateAt(64, ordB);
-                    const lds_ro_u32_ptr wA = (lds_ro_u32_ptr)(sWin + kSeg * seg) + ((ordA & 0x7FFFFFFFu) >> 16);
-                    const lds_ro_u32_ptr wB = (lds_ro_u32_ptr)(sWin + kSeg * seg) + ((ordB & 0x7FFFFFFFu) >> 16);
-                    uint32_t texA[8][3], texB[8][3];
+                constexpr int kAhead = LFG_LOOKAHEAD;                  // candidates per lane (0: off)
+                if (kAhead > 1 && !border && waveThr < kOnePointMax && pendCount < 64 && (byRank || (count == 64 && i0 != hintsEnd)) &&
+                    (byRank ? rank0 + 64 * (kAhead - 1) < (int)min(zeroBound, (uint32_t)kCand) : i0 + 64 * (kAhead - 1) < nEntries)) {
+                    constexpr int kA = kAhead > 1 ? kAhead : 1;
+                    uint32_t ordA[kA];
+                    bool needA[kA];
+                    uint32_t tex[kA][8][3];
 #pragma unroll
-                    for (int ci = 0; ci < 8; ++ci) {
+                    for (int a = 0; a < kA; ++a) needA[a] = candidateAt(64 * a, ordA[a]);
 #pragma unroll
-                        for (int t = 0; t < 3; ++t) { texA[ci][t] = wA[(3 + 8 * ci) * kWinH + 3 + 8 * t]; texB[ci][t] = wB[(3 + 8 * ci) * kWinH + 3 + 8 * t]; }
+                    for (int a = 0; a < kA; ++a) {
+                        const lds_ro_u32_ptr w = (lds_ro_u32_ptr)(sWin + kSeg * seg) + ((ordA[a] & 0x7FFFFFFFu) >> 16);
+#pragma unroll
+                        for (int ci = 0; ci < 8; ++ci) {
+#pragma unroll
+                            for (int t = 0; t < 3; ++t) tex[a][ci][t] = w[(3 + 8 * ci) * kWinH + 3 + 8 * t];
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    bool keepA, keepB;                 // some lattice distance does not exceed the wave's largest threshold
+                    bool keep[kA];                     // some lattice distance does not exceed the wave's largest threshold
                     if (waveThr < 0.5f) {              // (zero-cost thresholds: "exceeds" means "differs"; see latticeBatch)
-                        bool sameA = false, sameB = false;
+#pragma unroll
+                        for (int a = 0; a < kA; ++a) keep[a] = false;
 #pragma unroll
                         for (int ci = 0; ci < 8; ++ci) {
 #pragma unroll
                             for (int t = 0; t < 3; ++t) {
                                 const uint32_t cT = (uint32_t)__builtin_amdgcn_readlane((int)c[3 + 8 * t], 3 + 8 * ci);
-                                sameA = sameA | (texA[ci][t] == cT); sameB = sameB | (texB[ci][t] == cT);
+#pragma unroll
+                                for (int a = 0; a < kA; ++a) keep[a] = keep[a] | (tex[a][ci][t] == cT);
                             }
                         }
-                        keepA = sameA; keepB = sameB;
                     } else {
-                        uint32_t dA = 0x7F800000u, dB = 0x7F800000u;
+                        uint32_t dMinA[kA];
+#pragma unroll
+                        for (int a = 0; a < kA; ++a) dMinA[a] = 0x7F800000u;
 #pragma unroll
                         for (int ci = 0; ci < 8; ++ci) {
 #pragma unroll
                             for (int t = 0; t < 3; ++t) {
                                 const uint32_t cT = (uint32_t)__builtin_amdgcn_readlane((int)c[3 + 8 * t], 3 + 8 * ci);
-                                dA = min(dA, __builtin_bit_cast(uint32_t, distanceOf(cT, texA[ci][t])));
-                                dB = min(dB, __builtin_bit_cast(uint32_t, distanceOf(cT, texB[ci][t])));
+#pragma unroll
+                                for (int a = 0; a < kA; ++a) dMinA[a] = min(dMinA[a], __builtin_bit_cast(uint32_t, distanceOf(cT, tex[a][ci][t])));
                             }
                         }
                         const uint32_t thrSqBits = __builtin_bit_cast(uint32_t, (waveThr * waveThr) * 1.000001f);
-                        keepA = !(dA > thrSqBits); keepB = !(dB > thrSqBits);
+#pragma unroll
+                        for (int a = 0; a < kA; ++a) keep[a] = !(dMinA[a] > thrSqBits);
                     }
-                    if (__ballot((needA && keepA) || (needB && keepB)) == 0ull) {
+                    bool any = false;
+#pragma unroll
+                    for (int a = 0; a < kA; ++a) any = any | (needA[a] && keep[a]);
+                    if (__ballot(any) == 0ull) {
 #ifdef LFG_MOTION_STAMPS
-                        stampBatches += 2u;
+                        stampBatches += (unsigned)kA;
 #endif
-                        if (byRank) rank0 += 128; else i0 += 128;
+                        if (byRank) rank0 += 64 * kA; else i0 += 64 * kA;
                         continue;
                     }
                 }
