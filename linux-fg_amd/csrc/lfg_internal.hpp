@@ -35,7 +35,7 @@ struct AxisTable {
 };
 
 struct MotionWorkspaceLayout { size_t list, umin, count, tileFlags, segDone, segMap, queueCount, ctrl, order, plan, auxList, auxUmin, auxCount,
-                               queue, dynList, dynUmin, dynCount, total; int queueCap, slots; };
+                               queue, dynList, dynUmin, dynCount, dynInit, total; int queueCap, slots; };
 // Work units of the motion prefilter (motion.hip: prefilter_plan).  A unit is a 56 x 64 tile, or one of nChunks
 // contiguous parts of a tile's candidate order, or one 16-row segment of a tile with its four waves on four parts of
 // the order; parts have private lists in the aux arrays (merged by the resolve kernel).
@@ -56,6 +56,7 @@ struct PrefilterPlan {               // passed by value to the kernels
     uint32_t *dynList;
     float *dynUmin;
     uint32_t *dynCount;
+    uint32_t *dynInit;               // per handed-over segment: the 16 x 56 thresholds of the wave that handed it over
 };
 struct PrefilterPlanHost {
     int tilesX = 0, tiles = 0, units = 0, auxUnits = 0;

@@ -365,6 +365,9 @@ constexpr int kRunIn = kRun + kB - 1;             // 13
 #ifndef LFG_ZERO_COMPARE
 #define LFG_ZERO_COMPARE 1
 #endif
+#ifndef LFG_QUEUE_INIT
+#define LFG_QUEUE_INIT 1
+#endif
 #ifndef LFG_LOOKAHEAD
 #define LFG_LOOKAHEAD 2                 // candidates per lane of the lookahead (0 or 1: off)
 #endif
@@ -489,7 +492,9 @@ __device__ __forceinline__ void prefilter_unit(
 #define LFG_HEAD 8
 #endif
     constexpr int kHead = LFG_HEAD;
-    const int nHead = chunk > 0 ? kHead : 0;
+    // (the parts of a segment handed over at run time start from the thresholds of the wave that handed it over --
+    //  which had tried every hint -- instead: see the push and `run` below)
+    const int nHead = (chunk > 0 && !(fromQueue && LFG_QUEUE_INIT)) ? kHead : 0;
 
     // ---- this thread's 23 block positions (column bx0 + lane, rows by0 + 16 seg + j).  Loaded BEFORE the window is staged
     // (their squares are taken after it): the two sets of loads are in flight together, and a unit pays one memory
@@ -1318,7 +1323,10 @@ __device__ __forceinline__ void prefilter_unit(
         // order, then fails the cheap test or is skipped by rank instead of costing a second evaluation); then zero motion
         // and the other hints of this call (at least seven entries, so that units which run the first eight for their
         // thresholds see the same boundary); then sixty-four at a time.
-        const int hintsEnd = nHead ? kHead : max(kHead, min((int)order32[kCand + 1], 2 + 62));
+        // (a part of a handed-over segment starts with thresholds that already reflect the hints: full batches from its
+        //  first entry on, and the narrow-search decision before the first of them)
+        const bool inherited = LFG_QUEUE_INIT && fromQueue;
+        const int hintsEnd = inherited ? 0 : nHead ? kHead : max(kHead, min((int)order32[kCand + 1], 2 + 62));
         int firstBatchSurvivors = 0;
         // BY RANK.  Once every pixel of the wave owns a zero-cost candidate only candidates that come EARLIER in the tie
         // order than the latest of those can still matter (zeroBound).  Walking on through the visiting order would
@@ -1337,8 +1345,25 @@ __device__ __forceinline__ void prefilter_unit(
         // hand-over decision counts that batch's.)
         uint32_t *const pend = sPending[wave];
         int pendCount = 0;
+        if (LFG_QUEUE_INIT && fromQueue) {                             // the thresholds of the wave that handed the segment over
+            const uint32_t *const init = sp.dynInit + (size_t)(unit / (LFG_DYN_PARTS / 4)) * (size_t)(kSeg * kPTW);
+            uint32_t theirs[2][kRun];
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+                for (int i = 0; i < kRun; ++i)
+                    theirs[hb][i] = __hip_atomic_load(init + (2 * i + hb) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int i = 0; i < kRun; ++i) {                            // (pixels outside the image keep -inf)
+                const float fx = thr2[i].x, fy = thr2[i].y;
+                if (fx > 0.0f) thr2[i].x = __builtin_bit_cast(float, theirs[0][i]);
+                if (fy > 0.0f) thr2[i].y = __builtin_bit_cast(float, theirs[1][i]);
+            }
+            refreshZeroBound();
+        }
         const bool mayHandOver = whole && !fromQueue && order32[kCand] != 0u;     // (read once: the loop below runs ~19 times per wave)
-        for (int i0 = 0, count = LFG_FIRST_BATCH;;) {
+        for (int i0 = 0, count = inherited ? 64 : LFG_FIRST_BATCH;;) {
             const bool flushOnly = byRank ? rank0 >= (int)min(zeroBound, (uint32_t)kCand) : i0 >= nEntries;
             if (flushOnly && pendCount == 0) break;
             if (!flushOnly && !byRank && i0 >= max(nHead, LFG_FIRST_BATCH) && zeroBound < (uint32_t)kCand && (int)zeroBound + 64 <= nEntries - i0) {
@@ -1357,6 +1382,23 @@ __device__ __forceinline__ void prefilter_unit(
                 if (lane == 0) slot = atomicAdd(sp.queueCount, kEntries);
                 slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
                 if (slot + kEntries <= (uint32_t)sp.queueCap) {
+                    if (LFG_QUEUE_INIT) {
+                        // what this wave knows after the hints is where the segment's parts start: each of them would
+                        // otherwise evaluate the head of the order for its thresholds, eight evaluations in each of eight
+                        // waves.  (Agent scope: the parts run on other XCDs.  Every word is some candidate's evaluated cost
+                        // x kRatio, or a zero-cost word: a valid bound for its pixel in any part.)
+                        uint32_t *const init = sp.dynInit + (size_t)(slot / kEntries) * (size_t)(kSeg * kPTW);
+#pragma unroll
+                        for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+                            for (int i = 0; i < kRun; ++i) {
+                                const float fx = thr2[i].x, fy = thr2[i].y;
+                                __hip_atomic_store(init + (2 * i + hb) * 64 + lane, __builtin_bit_cast(uint32_t, hb ? fy : fx),     // (lane-major: whole lines)
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        }
+                        __threadfence();                               // before the entries that announce the segment
+                    }
                     if (lane == 0) {
                         sp.segMap[tile * (kPTH / kSeg) + seg] = (4u * slot) | ((uint32_t)LFG_DYN_PARTS << 24) | (1u << 31);    // (read by the resolve kernel)
                         // the entry itself is the "slot filled" signal (never 0): an atomic, like the read that waits for it
@@ -2290,7 +2332,8 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, Motion
     l.slots = slots;
     l.dynUmin = align(l.dynList + dynBlocks * kSeg * kPTW * kListK * sizeof(Rec));
     l.dynCount = align(l.dynUmin + dynBlocks * kSeg * kPTW * sizeof(float));
-    l.total = align(l.dynCount + dynBlocks * kSeg * kPTW * sizeof(uint32_t));
+    l.dynInit = align(l.dynCount + dynBlocks * kSeg * kPTW * sizeof(uint32_t));
+    l.total = align(l.dynInit + (size_t)l.queueCap / (LFG_DYN_PARTS / 4) * kSeg * kPTW * sizeof(uint32_t));
     if (layout) *layout = l;
     return l.total;
 }
@@ -2588,6 +2631,7 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
     sp.dynList = reinterpret_cast<uint32_t *>(workspace + l.dynList);
     sp.dynUmin = reinterpret_cast<float *>(workspace + l.dynUmin);
     sp.dynCount = reinterpret_cast<uint32_t *>(workspace + l.dynCount);
+    sp.dynInit = reinterpret_cast<uint32_t *>(workspace + l.dynInit);
     uint32_t *segDone = reinterpret_cast<uint32_t *>(workspace + l.segDone);
     hipError_t e = hipMemsetAsync(flags, 0, l.order - l.tileFlags, s);             // tile flags, segment marks and map, counters, queue
     if (e != hipSuccess) return e;
