@@ -365,6 +365,9 @@ constexpr int kRunIn = kRun + kB - 1;             // 13
 #ifndef LFG_ZERO_COMPARE
 #define LFG_ZERO_COMPARE 1
 #endif
+#ifndef LFG_BAND
+#define LFG_BAND 1
+#endif
 #ifndef LFG_QUEUE_INIT
 #define LFG_QUEUE_INIT 1
 #endif
@@ -461,7 +464,7 @@ __device__ __forceinline__ void prefilter_unit(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         // wave index 0..3
 #ifdef LFG_MOTION_STAMPS
     const unsigned long long stampStart = __builtin_amdgcn_s_memrealtime();
-    unsigned stampEvals = 0u, stampBatches = 0u, stampBox = 0u, stampNarrow = 0u, stampThr = 0u, stampThrEnd = 0u, stampFour = 0u;
+    unsigned stampEvals = 0u, stampBatches = 0u, stampBox = 0u, stampBand = 0u, stampNarrow = 0u, stampThr = 0u, stampThrEnd = 0u, stampFour = 0u;
     unsigned long long stampStaged = 0ull, stampFirst = 0ull;
 #endif
     // Work units (PrefilterPlan).  A tile is 4 segments of 16 rows, and a workgroup is either
@@ -871,6 +874,61 @@ __device__ __forceinline__ void prefilter_unit(
 #endif
         constexpr float kOnePointMax = LFG_ONEPOINT_MAX;   // below: the one-point test alone (cheap, and strong while thresholds are small)
         bool useFourPoint = true, useSixteen = LFG_SIXTEEN != 0;
+        // "Some lattice point of the candidate is the same four bytes in both frames": what a pixel that already owns a
+        // zero-cost candidate needs before another candidate can matter to it (its S~ would have to be 0: every distance
+        // of its block exactly 0, the lattice point inside the block among them).  One compare per point.
+        auto zeroHit = [&](const uint32_t ordL) -> bool {
+            const lds_ro_u32_ptr w = (lds_ro_u32_ptr)(sWin + kSeg * seg) + (ordL >> 16);
+            bool same = false;
+            if (border) {
+                uint32_t tex[4];
+#pragma unroll
+                for (int col = 4; col <= kPTW; col += 4) {
+#pragma unroll
+                    for (int row = 4; row <= 16; row += 4) tex[row / 4 - 1] = w[col * kWinH + row];
+                    const uint32_t inImage = (uint32_t)__builtin_amdgcn_readlane((int)valid, col);
+#pragma unroll
+                    for (int row = 4; row <= 16; row += 4)         // (a point outside the image is no point: scalar mask)
+                        same = same | ((tex[row / 4 - 1] == (uint32_t)__builtin_amdgcn_readlane((int)c[row], col)) & (((inImage >> row) & 1u) != 0u));
+                }
+            } else {
+                uint32_t tex[8][3];
+#pragma unroll
+                for (int ci = 0; ci < 8; ++ci) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) tex[ci][t] = w[(3 + 8 * ci) * kWinH + 3 + 8 * t];
+                }
+#pragma unroll
+                for (int ci = 0; ci < 8; ++ci) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+                        same = same | (tex[ci][t] == (uint32_t)__builtin_amdgcn_readlane((int)c[3 + 8 * t], 3 + 8 * ci));
+                }
+            }
+            return same;
+        };
+        // THE BAND.  Once the hints have been tried, the pixels that do not own a zero-cost candidate yet often lie in a few
+        // columns -- next to the left and right border the upscaler filters a shifted frame differently, so the match is
+        // only nearly exact there, costs a few hundred, and the four- and sixteen-point tests run for every candidate of
+        // the segment (a fifth of the prefilter's time on a pan).  Their lattice walks then cover only the groups that hold
+        // a pixel of the band [bandLo, bandHi] (pixel columns of the tile); every other pixel is settled at zero cost and
+        // is answered for by zeroHit.  (The set of unsettled pixels only shrinks: the band stays valid once computed.)
+        int bandLo = 0, bandHi = kPTW - 1;
+        auto computeBand = [&]() {
+            uint32_t lo = 0u, hi = 0u;                                 // kPTW - first column, last column + 1 (0: none)
+#pragma unroll
+            for (int i = 0; i < kRun; ++i) {
+                const float fx = thr2[i].x, fy = thr2[i].y;
+                const int b0 = __builtin_bit_cast(int, fx), b1 = __builtin_bit_cast(int, fy);     // (-inf is negative: outside the image or narrow)
+                if (b0 >= 0x3F000000 || b1 >= 0x3F000000) { lo = max(lo, (uint32_t)(kPTW - (kRun * q + i))); hi = max(hi, (uint32_t)(kRun * q + i + 1)); }
+            }
+            lo = wave_max_u32(lo); hi = wave_max_u32(hi);
+            lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo); hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi);
+            if (hi != 0u) { bandLo = kPTW - (int)lo; bandHi = (int)hi - 1; }
+#ifdef LFG_MOTION_STAMPS
+            stampBand = 0x10000u | (unsigned)bandLo | ((unsigned)bandHi << 8);
+#endif
+        };
         // bit k of the result: candidate i0 + k of the staged order has to be evaluated in full
         // (ordL: this lane's candidate, an entry of the order; need: it has to be looked at; fullBatch: 64 candidates)
         auto latticeBatch = [&](const uint32_t ordL, bool need, const bool fullBatch) -> unsigned long long {
@@ -883,7 +941,9 @@ __device__ __forceinline__ void prefilter_unit(
                 // the order of their bit patterns (one v_min_u32 per point, no NaN handling)
                 uint32_t dMin = 0x7F800000u;
                 auto bitsOf = [](float d) { return __builtin_bit_cast(uint32_t, d); };
-                if (border) {
+                if (border && LFG_ZERO_COMPARE && waveThr < 0.5f) {
+                    dMin = zeroHit(ordL) ? 0u : 0x7F800000u;           // (see the interior case below)
+                } else if (border) {
 #pragma unroll
                     for (int col = 4; col <= kPTW; col += 4) {
                         const uint32_t inImage = (uint32_t)__builtin_amdgcn_readlane((int)valid, col);
@@ -958,8 +1018,15 @@ __device__ __forceinline__ void prefilter_unit(
                 for (int b = 0; b < 5; ++b) rowRelevant |= (!border || rowsL + max(0, 4 * b - 3) < H) ? (1u << b) : 0u;
                 // (a rolled loop, two columns per trip: sixteen unrolled columns were 2,000 instructions and 7 % slower where
                 //  this test dominates -- not for instruction-cache misses, SQC_ICACHE_MISSES stays at 0.01 %)
+                const int gLo = (bandLo + 3) >> 2, gHi = (bandHi + 3) >> 2;   // groups ceil(i / 4) of the band's pixel columns i
+                const bool restricted = LFG_BAND && (bandLo > 0 || bandHi < kPTW - 1);
+                // (two copies of the walk, with and without the band's bounds: the bounds' tests in the one walk cost the
+                //  segments whose band is the whole width -- noise everywhere -- 6 %)
+                auto walk = [&](auto banded) {
+                constexpr bool kBanded = decltype(banded)::value;
 #pragma unroll 2
-                for (int a = 0; a < 16; ++a) {
+                for (int a = 0; a < 16; ++a, w += 4 * kWinH) {
+                    if (kBanded && (a < gLo || a > gHi + 1)) continue;  // (wave-uniform)
                     // (the lane select goes through an empty asm: the current-frame texels are the same in every batch,
                     //  and hoisted out of the batch loop their 96 scalar registers are spilled)
                     int colL = 4 * a;
@@ -979,16 +1046,19 @@ __device__ __forceinline__ void prefilter_unit(
 #pragma unroll
                     for (int b = 0; b < 5; ++b) v[b] = d[b] + d[b + 1];
                     // group (a - 1, b): its first pixel is (max(0, 4 (a-1) - 3), max(0, 4 b - 3))
-                    const bool colRelevant = a > 0 && (!border || tx0L + max(0, 4 * (a - 1) - 3) < W);
+                    const bool colRelevant = a > (kBanded ? gLo : 0) && (!border || tx0L + max(0, 4 * (a - 1) - 3) < W);
 #pragma unroll
                     for (int b = 0; b < 5; ++b) {
                         const uint32_t g = bitsOf(vPrev[b] + v[b]);
                         pMin = min(pMin, (colRelevant && ((rowRelevant >> b) & 1u)) ? g : 0x7F800000u);
                         vPrev[b] = v[b];
                     }
-                    w += 4 * kWinH;
                 }
-                need = need & !(pMin > bitsOf(waveThr * 1.000002f));
+                };
+                if (restricted) walk(std::true_type{}); else walk(std::false_type{});
+                bool pass = !(pMin > bitsOf(waveThr * 1.000002f));
+                if (restricted) pass = zeroHit(ordL) || pass;          // (the settled pixels outside the band)
+                need = need && pass;
                 if (fullBatch && __builtin_popcountll(__ballot(need)) >= 48) useFourPoint = false;
             }
             return __ballot(need);
@@ -1027,8 +1097,13 @@ __device__ __forceinline__ void prefilter_unit(
                 uint32_t rowRelevant = 0u;                              // bit a: some pixel row inside the image maps to vertical group a
 #pragma unroll
                 for (int a = 0; a < 9; ++a) rowRelevant |= (!border || rowsL + max(0, 2 * a - 1) < H) ? (1u << a) : 0u;
+                const int bLo = (bandLo + 1) >> 1, bHi = (bandHi + 1) >> 1;   // groups ceil(i / 2) of the band's pixel columns i
+                const bool restricted = LFG_BAND && (bandLo > 0 || bandHi < kPTW - 1);
+                auto walk = [&](auto banded) {                          // (two copies: see the four-point test)
+                constexpr bool kBanded = decltype(banded)::value;
 #pragma unroll 2
-                for (int t = 0; t < 32; ++t) {
+                for (int t = 0; t < 32; ++t, w += 2 * kWinH) {
+                    if (kBanded && (t < bLo || t > bHi + 3)) continue;  // (wave-uniform)
                     int colL = 2 * t;
                     asm volatile("" : "+s"(colL));
                     uint32_t tex[12];
@@ -1049,7 +1124,7 @@ __device__ __forceinline__ void prefilter_unit(
                     for (int a = 0; a < 9; ++a) v[a] = pr[a] + pr[a + 2];
                     // columns t-1, t; with the pair sum of columns t-3, t-2 the group b = t - 3, whose first pixel
                     // column is max(0, 2 b - 1)
-                    const bool colRelevant = t >= 3 && (!border || tx0 + max(0, 2 * (t - 3) - 1) < W);
+                    const bool colRelevant = t >= (kBanded ? bLo : 0) + 3 && (!border || tx0 + max(0, 2 * (t - 3) - 1) < W);
                     const int sel = t & 1;                             // hOld[sel] holds the pair sum made two columns ago
 #pragma unroll
                     for (int a = 0; a < 9; ++a) {
@@ -1059,9 +1134,12 @@ __device__ __forceinline__ void prefilter_unit(
                         if (sel) hOld[1][a] = h; else hOld[0][a] = h;
                         vOld[a] = v[a];
                     }
-                    w += 2 * kWinH;
                 }
-                need = need & !(gMin > bitsOf(waveThr * 1.000002f));
+                };
+                if (restricted) walk(std::true_type{}); else walk(std::false_type{});
+                bool pass = !(gMin > bitsOf(waveThr * 1.000002f));
+                if (restricted) pass = zeroHit(ordL) || pass;          // (the settled pixels outside the band)
+                need = need && pass;
                 if (fullBatch && __builtin_popcountll(__ballot(need)) >= 48) useSixteen = false;
             }
             return __ballot(need);
@@ -1412,6 +1490,7 @@ __device__ __forceinline__ void prefilter_unit(
                 enterNarrow();
                 if (narrow) refreshZeroBound();    // the largest threshold of the pixels that stay wide
             }
+            if (LFG_BAND && decisionPoint && i0 == hintsEnd && !(waveThr < kOnePointMax)) computeBand();
 #ifdef LFG_MOTION_STAMPS
             if (!byRank && i0 == hintsEnd && !narrow) {
                 int lo = 99, hi = -1, rlo = 99, rhi = -1;
@@ -1424,6 +1503,7 @@ __device__ __forceinline__ void prefilter_unit(
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_xor(lo, off)); hi = max(hi, __shfl_xor(hi, off)); rlo = min(rlo, __shfl_xor(rlo, off)); rhi = max(rhi, __shfl_xor(rhi, off)); }
                 stampBox = (unsigned)(lo & 0xFF) | ((unsigned)(hi & 0xFF) << 8) | ((unsigned)(rlo & 0xFF) << 16) | ((unsigned)(rhi & 0xFF) << 24);
+                if (hi < lo && stampBand) stampBox = (stampBand & 0xFFFFu) | (0xEEu << 16);      // (no such pixel: the band of the unsettled ones instead)
             }
             if (i0 == hintsEnd) stampThr = __builtin_bit_cast(uint32_t, waveThr);
             stampThrEnd = __builtin_bit_cast(uint32_t, waveThr);
@@ -2701,6 +2781,27 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
                     fprintf(stderr, "  late: unit %d wave %d tile (%d,%d) seg %d start %.1f end %.1f us, evals %llu, batches %llu, staged after %.1f us\n", ends[i].second / 4, ends[i].second % 4,
                             (int)((o[6] >> 12) & 0xFF), (int)((o[6] >> 20) & 0xFF), (int)((o[6] >> 10) & 3), (double)(o[0] - t0) / 100.0, (double)(o[1] - t0) / 100.0, o[2], o[3] & 0xFFFFFFFFull, (double)(o[4] - o[0]) / 100.0);
                 }
+            }
+            {   // rim units by where they lie: mean duration, evaluations and batches per wave
+                const char *names[6] = {"top", "bottom, last segment", "bottom, other segments", "left", "right", "corner or other"};
+                double dur[6] = {0}, evs[6] = {0}, bts[6] = {0}, thrA[6] = {0}, thrB[6] = {0}; int nu[6] = {0}, nNarrow[6] = {0}, nWaves[6] = {0}, nZero[6] = {0}, nBand[6] = {0}; double wBand[6] = {0};
+                int maxTx = 0, maxTy = 0;
+                for (int u = 0; u < n; ++u) { const unsigned long long *o = &h[(u * 4) * 8]; if (!o[1]) continue; maxTx = std::max(maxTx, (int)((o[6] >> 12) & 0xFF)); maxTy = std::max(maxTy, (int)((o[6] >> 20) & 0xFF)); }
+                for (int u = 0; u < n; ++u) {
+                    unsigned long long a = ~0ull, b = 0, evals = 0, batches = 0; int rim = 0, tx = 0, ty = 0, sg = 0, nw = 0;
+                    for (int w = 0; w < 4; ++w) { const unsigned long long *o = &h[(u * 4 + w) * 8]; if (!o[1]) continue; a = std::min(a, o[0]); b = std::max(b, o[1]); evals += o[2]; batches += o[3] & 0xFFFFFFFFull;
+                        rim = (int)((o[3] >> 32) & 1); tx = (int)((o[6] >> 12) & 0xFF); ty = (int)((o[6] >> 20) & 0xFF); sg = (int)((o[6] >> 10) & 3); ++nw; }
+                    if (!b || !rim) continue;
+                    const bool l = tx == 0, r = tx == maxTx, t = ty == 0, bo = ty == maxTy;
+                    const int k = (l + r + t + bo) != 1 ? 5 : t ? 0 : bo ? (sg == 2 ? 1 : 2) : l ? 3 : 4;
+                    dur[k] += (double)(b - a) / 100.0; evs[k] += (double)evals / nw; bts[k] += (double)batches / nw; ++nu[k];
+                    for (int w = 0; w < 4; ++w) { const unsigned long long *o = &h[(u * 4 + w) * 8]; if (!o[1]) continue; ++nWaves[k]; if (o[6] & 7u) ++nNarrow[k];
+                        const uint32_t ta = (uint32_t)o[7], tb = (uint32_t)(o[7] >> 32); float fa, fb; memcpy(&fa, &ta, 4); memcpy(&fb, &tb, 4);
+                        if (fa < 0.5f) ++nZero[k]; else { thrA[k] += std::min(fa, 1e5f); thrB[k] += std::min(fb, 1e5f); }
+                        const unsigned box = (unsigned)(o[6] >> 32); if (((box >> 16) & 0xFF) == 0xEE) { ++nBand[k]; wBand[k] += (double)(((box >> 8) & 0xFF) - (box & 0xFF) + 1); } }
+                }
+                for (int k = 0; k < 6; ++k) if (nu[k]) fprintf(stderr, "rim units, %s: %d, mean %.1f us, evaluations per wave %.1f, batches per wave %.1f; waves %d, narrow %d, all-zero thresholds after the hints %d, others' mean threshold after hints %.0f, at the end %.0f; band known in %d waves, mean width %.1f columns\n", names[k], nu[k], dur[k] / nu[k], evs[k] / nu[k], bts[k] / nu[k],
+                                                        nWaves[k], nNarrow[k], nZero[k], thrA[k] / std::max(1, nWaves[k] - nZero[k]), thrB[k] / std::max(1, nWaves[k] - nZero[k]), nBand[k], wBand[k] / std::max(1, nBand[k]));
             }
             {   // narrow search: waves by candidates per pass, their mean duration
                 double dur[8] = {0}; int nw[8] = {0}; double evs[8] = {0};

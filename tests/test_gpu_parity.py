@@ -1156,6 +1156,41 @@ def test_lanes_keep_frames_in_flight_apart():
         ctx.close()
 
 
+@pytest.mark.parametrize("seed", [21, 22, 23])
+def test_band_restricted_lattice_tests_agree_with_the_literal_kernel(ctx, seed):
+    """Segments in which most pixels own a zero-cost candidate and a few columns only nearly match (costs of a few hundred:
+    the columns an upscaler filters differently next to the border, mild noise on a vertical strip): the four- and
+    sixteen-point tests walk the band's lattice groups only and the settled pixels are answered for by an exact-texel
+    compare.  Strips of +-1 .. +-3 levels at arbitrary x and width, inside the frame and at both edges, with duplicated
+    texels sprinkled in (lattice points that DO compare equal), on a pan and on a static pair; whole frame against the
+    literal kernel."""
+    from linux_fg_amd import capi
+    rng = np.random.default_rng(9500 + seed)
+    w, h = 1176, 416
+    prev = synth.make_prev(w, h, seed=9500 + seed)
+    shift = (int(rng.integers(-5, 6)), int(rng.integers(-3, 4))) if seed != 23 else (0, 0)
+    curr = synth.translate(prev, shift, 9500 + seed)
+    base = curr.copy()
+    x = 4
+    for k in range(12):
+        x += int(rng.integers(30, 90))
+        width = int(rng.integers(1, 20))
+        amp = int(rng.integers(1, 4))
+        y0, y1 = sorted(int(v) for v in rng.integers(0, h, 2))
+        y1 = max(y1, min(h, y0 + 24))
+        n = rng.integers(-amp, amp + 1, size=(y1 - y0, width, curr.shape[2]), dtype=np.int16)
+        curr[y0:y1, x:x + width] = np.clip(base[y0:y1, x:x + width].astype(np.int16) + n, 0, 255).astype(np.uint8)
+        x += width
+    for x0, x1 in ((0, 6), (w - 7, w)):               # ... and at both edges, full height
+        n = rng.integers(-2, 3, size=(h, x1 - x0, curr.shape[2]), dtype=np.int16)
+        curr[:, x0:x1] = np.clip(base[:, x0:x1].astype(np.int16) + n, 0, 255).astype(np.uint8)
+    ys, xs = rng.integers(0, h, 400), rng.integers(0, w, 400)      # texels that repeat elsewhere in prev
+    prev[ys, xs] = prev[(ys + 5) % h, (xs + 3) % w]
+    a, st = run_motion_mode(ctx, prev, curr, capi.MOTION_PREFILTERED)
+    b, _ = run_motion_mode(ctx, prev, curr, capi.MOTION_EXACT_ONLY)
+    assert (a == b).all()
+
+
 @pytest.mark.parametrize("seed", [11, 12, 13])
 def test_narrow_bands_deferred_test_and_rank_walk_agree_with_the_literal_kernel(ctx, seed):
     """The round-2 shortcuts of the prefilter, each provoked on purpose and compared with the literal kernel on the whole
