@@ -365,6 +365,9 @@ constexpr int kRunIn = kRun + kB - 1;             // 13
 #ifndef LFG_ZERO_COMPARE
 #define LFG_ZERO_COMPARE 1
 #endif
+#ifndef LFG_RANK_ALWAYS
+#define LFG_RANK_ALWAYS 1
+#endif
 #ifndef LFG_BAND
 #define LFG_BAND 1
 #endif
@@ -464,8 +467,8 @@ __device__ __forceinline__ void prefilter_unit(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         // wave index 0..3
 #ifdef LFG_MOTION_STAMPS
     const unsigned long long stampStart = __builtin_amdgcn_s_memrealtime();
-    unsigned stampEvals = 0u, stampBatches = 0u, stampBox = 0u, stampBand = 0u, stampNarrow = 0u, stampThr = 0u, stampThrEnd = 0u, stampFour = 0u;
-    unsigned long long stampStaged = 0ull, stampFirst = 0ull;
+    unsigned stampEvals = 0u, stampBatches = 0u, stampBox = 0u, stampBand = 0u, stampPass = 0u, stampNarrow = 0u, stampThr = 0u, stampThrEnd = 0u, stampFour = 0u;
+    unsigned long long stampStaged = 0ull, stampFirst = 0ull, stampLattice = 0ull, stampAhead = 0ull, stampAheadFirst = 0ull, stampPass7 = 0ull;
 #endif
     // Work units (PrefilterPlan).  A tile is 4 segments of 16 rows, and a workgroup is either
     //   * a whole tile: wave = segment, the entire candidate order;
@@ -488,6 +491,9 @@ __device__ __forceinline__ void prefilter_unit(
     const int tx0 = tileX * kPTW, ty0 = tileY * kPTH;                  // tile origin (pixels)
     const int bx0 = tx0 - kB / 2, by0 = ty0 - kB / 2;                  // image coords of block position (0,0)
     if (tid == 0) sGiveUp = 0u;
+    // (the two flags of this call's order, requested here: read where they are used -- behind the staging barrier -- each
+    //  was a scalar load from memory with nothing to hide its latency, two microseconds per unit)
+    const uint32_t orderHandOver = order32[kCand], orderHints = order32[kCand + 1];
     // A unit that shares its tile first runs the head of the order -- zero motion and the first hints -- for the
     // thresholds only (not recorded: the unit that owns those entries records them).  Without it a unit whose part
     // of the order holds no good candidate starts from nothing and records far more than it needs to.
@@ -817,6 +823,10 @@ __device__ __forceinline__ void prefilter_unit(
     };
 
     auto run = [&]() -> int {              // 0: done, 1: lists overflowed (tile flagged), 2: segment handed over
+#ifdef LFG_STAMP_LATTICE4
+        unsigned long long stampU[4] = {0ull, 0ull, 0ull, 0ull};
+        stampU[0] = __builtin_amdgcn_s_memrealtime();
+#endif
         uint32_t p[kSegD];
         float v8[kSeg];
         f32x2 x[kRunIn];
@@ -879,17 +889,29 @@ __device__ __forceinline__ void prefilter_unit(
         // of its block exactly 0, the lattice point inside the block among them).  One compare per point.
         auto zeroHit = [&](const uint32_t ordL) -> bool {
             const lds_ro_u32_ptr w = (lds_ro_u32_ptr)(sWin + kSeg * seg) + (ordL >> 16);
-            bool same = false;
+            // (the smallest XOR over the points is 0: VALU only -- see the lookahead of the batch loop)
+            uint32_t acc = 0xFFFFFFFFu;
             if (border) {
-                uint32_t tex[4];
+                static_assert(kPTW / 4 == 14, "two halves of seven lattice columns");
 #pragma unroll
-                for (int col = 4; col <= kPTW; col += 4) {
+                for (int half = 0; half < 2; ++half) {                 // (28 reads in flight at once: two LDS round trips, not fourteen)
+                    uint32_t tex[7][4];
 #pragma unroll
-                    for (int row = 4; row <= 16; row += 4) tex[row / 4 - 1] = w[col * kWinH + row];
-                    const uint32_t inImage = (uint32_t)__builtin_amdgcn_readlane((int)valid, col);
+                    for (int k = 0; k < 7; ++k) {
 #pragma unroll
-                    for (int row = 4; row <= 16; row += 4)         // (a point outside the image is no point: scalar mask)
-                        same = same | ((tex[row / 4 - 1] == (uint32_t)__builtin_amdgcn_readlane((int)c[row], col)) & (((inImage >> row) & 1u) != 0u));
+                        for (int row = 4; row <= 16; row += 4) tex[k][row / 4 - 1] = w[(4 + 4 * (7 * half + k)) * kWinH + row];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) {
+                        const int col = 4 + 4 * (7 * half + k);
+                        const uint32_t inImage = (uint32_t)__builtin_amdgcn_readlane((int)valid, col);
+#pragma unroll
+                        for (int row = 4; row <= 16; row += 4) {
+                            const uint32_t drop = ((inImage >> row) & 1u) - 1u;          // a point outside the image is no point (scalar: 0 or all ones)
+                            acc = min(acc, (tex[k][row / 4 - 1] ^ (uint32_t)__builtin_amdgcn_readlane((int)c[row], col)) | drop);
+                        }
+                    }
                 }
             } else {
                 uint32_t tex[8][3];
@@ -902,9 +924,10 @@ __device__ __forceinline__ void prefilter_unit(
                 for (int ci = 0; ci < 8; ++ci) {
 #pragma unroll
                     for (int t = 0; t < 3; ++t)
-                        same = same | (tex[ci][t] == (uint32_t)__builtin_amdgcn_readlane((int)c[3 + 8 * t], 3 + 8 * ci));
+                        acc = min(acc, tex[ci][t] ^ (uint32_t)__builtin_amdgcn_readlane((int)c[3 + 8 * t], 3 + 8 * ci));
                 }
             }
+            const bool same = acc == 0u;
             return same;
         };
         // THE BAND.  Once the hints have been tried, the pixels that do not own a zero-cost candidate yet often lie in a few
@@ -968,14 +991,14 @@ __device__ __forceinline__ void prefilter_unit(
                         // reads "some lattice distance is exactly 0", and a squared distance is 0 iff the two texels are
                         // the same four bytes -- one compare per point instead of three dot products.  This is the state of
                         // most of a frame under a pan or where nothing moves, seventeen batches per wave.
-                        bool same = false;
+                        uint32_t acc = 0xFFFFFFFFu;                     // (smallest XOR: see the lookahead below)
 #pragma unroll
                         for (int ci = 0; ci < 8; ++ci) {
 #pragma unroll
                             for (int t = 0; t < 3; ++t)
-                                same = same | (tex[ci][t] == (uint32_t)__builtin_amdgcn_readlane((int)c[3 + 8 * t], 3 + 8 * ci));
+                                acc = min(acc, tex[ci][t] ^ (uint32_t)__builtin_amdgcn_readlane((int)c[3 + 8 * t], 3 + 8 * ci));
                         }
-                        dMin = same ? 0u : 0x7F800000u;
+                        dMin = acc == 0u ? 0u : 0x7F800000u;
                     } else {
 #pragma unroll
                         for (int ci = 0; ci < 8; ++ci) {
@@ -1158,11 +1181,14 @@ __device__ __forceinline__ void prefilter_unit(
             bool flat = true;
             constexpr int kRows = kSegD + 2 * kR;                      // 55 window rows serve this segment
             for (int r0 = 0; r0 < kRows && flat; r0 += kRows / 5) {
-                bool same = true;
+                // (all 22 reads of a chunk in flight, then one OR of XORs: `&&` made each read wait for the one before)
+                uint32_t a[kRows / 5], b[kRows / 5];
 #pragma unroll
-                for (int r = 0; r < kRows / 5; ++r)
-                    same = same && wb[colA * kWinH + r0 + r] == ref && wb[colB * kWinH + r0 + r] == ref;
-                flat = __builtin_amdgcn_readfirstlane(__ballot(!same) == 0ull);
+                for (int r = 0; r < kRows / 5; ++r) { a[r] = wb[colA * kWinH + r0 + r]; b[r] = wb[colB * kWinH + r0 + r]; }
+                uint32_t diff = 0u;
+#pragma unroll
+                for (int r = 0; r < kRows / 5; ++r) diff |= (a[r] ^ ref) | (b[r] ^ ref);
+                flat = __builtin_amdgcn_readfirstlane(__ballot(diff != 0u) == 0ull);
             }
             if (flat) {
                 const float first = __builtin_bit_cast(float, 0x00800000u);          // "zero-cost" word of rank 0
@@ -1404,7 +1430,7 @@ __device__ __forceinline__ void prefilter_unit(
         // (a part of a handed-over segment starts with thresholds that already reflect the hints: full batches from its
         //  first entry on, and the narrow-search decision before the first of them)
         const bool inherited = LFG_QUEUE_INIT && fromQueue;
-        const int hintsEnd = inherited ? 0 : nHead ? kHead : max(kHead, min((int)order32[kCand + 1], 2 + 62));
+        const int hintsEnd = inherited ? 0 : nHead ? kHead : max(kHead, min((int)orderHints, 2 + 62));
         int firstBatchSurvivors = 0;
         // BY RANK.  Once every pixel of the wave owns a zero-cost candidate only candidates that come EARLIER in the tie
         // order than the latest of those can still matter (zeroBound).  Walking on through the visiting order would
@@ -1440,11 +1466,22 @@ __device__ __forceinline__ void prefilter_unit(
             }
             refreshZeroBound();
         }
-        const bool mayHandOver = whole && !fromQueue && order32[kCand] != 0u;     // (read once: the loop below runs ~19 times per wave)
+        const bool mayHandOver = whole && !fromQueue && orderHandOver != 0u;
+#ifdef LFG_STAMP_LATTICE3
+        unsigned long long stampT[4] = {0ull, 0ull, 0ull, 0ull};
+        stampT[0] = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef LFG_STAMP_LATTICE4
+        stampU[1] = __builtin_amdgcn_s_memrealtime();
+#endif
         for (int i0 = 0, count = inherited ? 64 : LFG_FIRST_BATCH;;) {
             const bool flushOnly = byRank ? rank0 >= (int)min(zeroBound, (uint32_t)kCand) : i0 >= nEntries;
             if (flushOnly && pendCount == 0) break;
-            if (!flushOnly && !byRank && i0 >= max(nHead, LFG_FIRST_BATCH) && zeroBound < (uint32_t)kCand && (int)zeroBound + 64 <= nEntries - i0) {
+            // (a wave with the whole order turns to the ranks as soon as it can, even where that saves no batch: consecutive
+            //  ranks are neighbouring window offsets, so the lattice reads of a batch fall into 64 different LDS banks, while
+            //  64 consecutive entries of the visiting order hit the same bank three or four times)
+            if (!flushOnly && !byRank && i0 >= max(nHead, LFG_FIRST_BATCH) && zeroBound < (uint32_t)kCand &&
+                ((whole && LFG_RANK_ALWAYS) || (int)zeroBound + 64 <= nEntries - i0)) {
                 byRank = true; rank0 = 0; visited = i0;
             }
             // (the two batches at which a wave decides how to go on: hand-over, narrow search)
@@ -1536,14 +1573,20 @@ __device__ __forceinline__ void prefilter_unit(
                 // together, the current-frame texels of the lattice points fetched once for both -- and if none of them
                 // has to be looked at, skips both batches.  Otherwise the batches are taken one by one as usual.
                 constexpr int kAhead = LFG_LOOKAHEAD;                  // candidates per lane (0: off)
-                if (kAhead > 1 && !border && waveThr < kOnePointMax && pendCount < 64 && (byRank || (count == 64 && i0 != hintsEnd)) &&
-                    (byRank ? rank0 + 64 * (kAhead - 1) < (int)min(zeroBound, (uint32_t)kCand) : i0 + 64 * (kAhead - 1) < nEntries)) {
+#ifdef LFG_STAMP_LATTICE
+                const unsigned long long ta0 = __builtin_amdgcn_s_memrealtime();
+                if (!stampAheadFirst && kAhead > 1 && !border && waveThr < kOnePointMax && pendCount < 64 && (byRank || (count == 64 && i0 != hintsEnd))) stampAheadFirst = ta0;
+#endif
+                // (From the second batch on, whatever its length: once the thresholds are this small the decisions taken at the
+                //  end of the hints -- hand-over, narrow search, the band -- cannot apply any more, thresholds only fall.)
+                if (kAhead > 1 && !border && waveThr < kOnePointMax && pendCount < 64 && (byRank || i0 >= LFG_FIRST_BATCH) &&
+                    (byRank ? rank0 + 64 * (kAhead - 1) < (int)min(zeroBound, (uint32_t)kCand) : i0 + count + 64 * (kAhead - 2) < nEntries)) {
                     constexpr int kA = kAhead > 1 ? kAhead : 1;
                     uint32_t ordA[kA];
                     bool needA[kA];
                     uint32_t tex[kA][8][3];
 #pragma unroll
-                    for (int a = 0; a < kA; ++a) needA[a] = candidateAt(64 * a, ordA[a]);
+                    for (int a = 0; a < kA; ++a) needA[a] = candidateAt(a == 0 ? 0 : (byRank ? 64 : count) + 64 * (a - 1), ordA[a]);
 #pragma unroll
                     for (int a = 0; a < kA; ++a) {
                         const lds_ro_u32_ptr w = (lds_ro_u32_ptr)(sWin + kSeg * seg) + ((ordA[a] & 0x7FFFFFFFu) >> 16);
@@ -1556,17 +1599,23 @@ __device__ __forceinline__ void prefilter_unit(
                     __builtin_amdgcn_sched_barrier(0);
                     bool keep[kA];                     // some lattice distance does not exceed the wave's largest threshold
                     if (waveThr < 0.5f) {              // (zero-cost thresholds: "exceeds" means "differs"; see latticeBatch)
+                        // ("some point is the same four bytes" as the smallest XOR being 0: v_xor + half a v_min3 per point and
+                        //  nothing but VALU.  A compare per point puts a lane mask into VCC that an s_or has to pick up before
+                        //  the next compare may write it -- 48 VALU -> SALU -> VALU hand-overs per pass, four times the cycles.)
+                        uint32_t accA[kA];
 #pragma unroll
-                        for (int a = 0; a < kA; ++a) keep[a] = false;
+                        for (int a = 0; a < kA; ++a) accA[a] = 0xFFFFFFFFu;
 #pragma unroll
                         for (int ci = 0; ci < 8; ++ci) {
 #pragma unroll
                             for (int t = 0; t < 3; ++t) {
                                 const uint32_t cT = (uint32_t)__builtin_amdgcn_readlane((int)c[3 + 8 * t], 3 + 8 * ci);
 #pragma unroll
-                                for (int a = 0; a < kA; ++a) keep[a] = keep[a] | (tex[a][ci][t] == cT);
+                                for (int a = 0; a < kA; ++a) accA[a] = min(accA[a], tex[a][ci][t] ^ cT);
                             }
                         }
+#pragma unroll
+                        for (int a = 0; a < kA; ++a) keep[a] = accA[a] == 0u;
                     } else {
                         uint32_t dMinA[kA];
 #pragma unroll
@@ -1591,12 +1640,30 @@ __device__ __forceinline__ void prefilter_unit(
 #ifdef LFG_MOTION_STAMPS
                         stampBatches += (unsigned)kA;
 #endif
-                        if (byRank) rank0 += 64 * kA; else i0 += 64 * kA;
+                        if (byRank) rank0 += 64 * kA; else { i0 += count + 64 * (kA - 1); count = 64; }
+#ifdef LFG_STAMP_LATTICE
+                        stampAhead += __builtin_amdgcn_s_memrealtime() - ta0;
+                        stampPass += 1u;
+#endif
                         continue;
+                    }
+#ifdef LFG_STAMP_LATTICE
+                    stampPass += 0x10000u;
+#endif
+                    if (false) {
                     }
                 }
                 bool need = candidateAt(0, ordL);
+#ifdef LFG_STAMP_LATTICE4
+                if (!byRank && i0 == 0) { asm volatile("" :: "v"(ordL)); stampU[2] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+#ifdef LFG_STAMP_LATTICE     // (experiment: o[5] carries the time spent in the lattice tests instead of the first batch's end)
+                const unsigned long long tl0 = __builtin_amdgcn_s_memrealtime();
+#endif
                 m = latticeBatch(ordL & 0x7FFFFFFFu, need, byRank || count == 64);
+#ifdef LFG_STAMP_LATTICE
+                stampLattice += __builtin_amdgcn_s_memrealtime() - tl0;
+#endif
                 firstFull = !byRank && i0 == hintsEnd;
                 if (m == 0ull && pendCount < 64) {     // the common case: the tests dropped the whole batch and nothing is due
                     if (firstFull) firstBatchSurvivors = 0;
@@ -1624,6 +1691,13 @@ __device__ __forceinline__ void prefilter_unit(
             }
             // two rounds of full evaluations: this batch's survivors, then -- when 64 candidates wait, or at the end -- the
             // first 64 of the list after their sixteen-point test
+#ifdef LFG_STAMP_LATTICE3
+            if (!byRank && i0 == 0) stampT[1] = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef LFG_STAMP_LATTICE4
+            if (!byRank && i0 == 0) { stampU[3] = __builtin_amdgcn_s_memrealtime();
+                stampPass7 = ((stampU[0] - stampStaged) & 0xFFFFull) | (((stampU[1] - stampStaged) & 0xFFFFull) << 16) | (((stampU[2] - stampStaged) & 0xFFFFull) << 32) | (((stampU[3] - stampStaged) & 0xFFFFull) << 48); }
+#endif
             for (int round = 0; round < 2; ++round) {
                 if (round == 1) {
                     if (!(pendCount >= 64 || flushNow || (flushOnly && pendCount > 0))) break;
@@ -1670,7 +1744,14 @@ __device__ __forceinline__ void prefilter_unit(
                 // lists full somewhere in the tile: stop early
                 if (__builtin_amdgcn_readfirstlane(__ballot(listsOverflowed()) != 0ull)) sGiveUp = 1u;
                 if (__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)&sGiveUp) != 0) return 1;
+#ifdef LFG_STAMP_LATTICE3
+                if (!byRank && i0 == 0 && round == 0) stampT[2] = __builtin_amdgcn_s_memrealtime();
+#endif
                 refreshZeroBound();
+#ifdef LFG_STAMP_LATTICE3
+                if (!byRank && i0 == 0 && round == 0) { stampT[3] = __builtin_amdgcn_s_memrealtime();
+                    stampPass7 = ((stampT[0] - stampStaged) & 0xFFFFull) | (((stampT[1] - stampStaged) & 0xFFFFull) << 16) | (((stampT[2] - stampStaged) & 0xFFFFull) << 32) | (((stampT[3] - stampStaged) & 0xFFFFull) << 48); }
+#endif
             }
             if (flushOnly) continue;           // (until the list is empty)
 #ifdef LFG_MOTION_STAMPS
@@ -1691,8 +1772,21 @@ __device__ __forceinline__ void prefilter_unit(
     if (lane == 0 && (fromQueue ? sp.units + unit : unit) < 8192) {
         unsigned long long *o = gMotionStamps + ((size_t)(fromQueue ? sp.units + unit : unit) * 4 + wave) * 8;
         o[0] = stampStart; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = stampEvals; o[3] = ((unsigned long long)borderTile << 32) | stampBatches | (((stampRunEnd - stampStart) & 0x3FFFFFFFull) << 33);
+#ifdef LFG_STAMP_LATTICE
+        stampFirst = stampStaged + stampLattice;      // ("first batch": the time in the lattice tests; "staging": in lookahead passes that skipped)
+        stampStaged = stampStart + stampAhead;
+#ifdef LFG_STAMP_LATTICE2
+        stampStaged = stampAheadFirst ? stampAheadFirst : stampStart;     // ("staging": when the first lookahead pass began)
+#endif
+#endif
         o[4] = stampStaged; o[5] = stampFirst; o[6] = ((unsigned long long)stampBox << 32) | stampNarrow | (stampFour << 8) | ((unsigned long long)(fromQueue ? 1u : 0u) << 9) | ((unsigned long long)seg << 10) | ((unsigned long long)tileX << 12) | ((unsigned long long)tileY << 20);
         o[7] = ((unsigned long long)stampThrEnd << 32) | stampThr;
+#ifdef LFG_STAMP_LATTICE
+        o[7] = stampPass;
+#endif
+#if defined(LFG_STAMP_LATTICE3) || defined(LFG_STAMP_LATTICE4)
+        o[7] = stampPass7;
+#endif
     }
 #endif
     if (gaveUp) {
@@ -2756,6 +2850,19 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
                 sum[rim] += us; mx[rim] = std::max(mx[rim], us); ev[rim] += (double)evals / 4; bat[rim] += (double)batches / 4; srch[rim] += se; stg[rim] += st; fst[rim] += fs; ++cnt[rim];
                 if (u % 197 == 0) fprintf(stderr, "unit %d rim %d start %.1f us dur %.1f us evals/wave %.1f\n", u, rim, (double)(a - t0) / 100.0, us, (double)evals / 4);
             }
+#if defined(LFG_STAMP_LATTICE3) || defined(LFG_STAMP_LATTICE4)
+            {
+                double t[4] = {0, 0, 0, 0}; int nwv = 0;
+                for (int u = 0; u < n; ++u) for (int w = 0; w < 4; ++w) { const unsigned long long *o = &h[(u * 4 + w) * 8]; if (!o[1] || ((o[3] >> 32) & 1) || !o[7]) continue; for (int k = 0; k < 4; ++k) t[k] += (double)((o[7] >> (16 * k)) & 0xFFFF) / 100.0; ++nwv; }
+                fprintf(stderr, "interior waves %d, after the staging barrier: batch loop entered %.2f us, first candidate chosen %.2f, evaluated %.2f, thresholds reduced %.2f\n", nwv, t[0] / std::max(nwv, 1), t[1] / std::max(nwv, 1), t[2] / std::max(nwv, 1), t[3] / std::max(nwv, 1));
+            }
+#elif defined(LFG_STAMP_LATTICE)
+            {
+                double sk = 0, fl = 0; int nwv = 0;
+                for (int u = 0; u < n; ++u) for (int w = 0; w < 4; ++w) { const unsigned long long *o = &h[(u * 4 + w) * 8]; if (!o[1] || ((o[3] >> 32) & 1)) continue; const unsigned box = (unsigned)o[7]; sk += box & 0xFFFF; fl += box >> 16; ++nwv; }
+                fprintf(stderr, "interior waves %d: lookahead passes that skipped %.2f, that did not %.2f per wave\n", nwv, sk / std::max(nwv, 1), fl / std::max(nwv, 1));
+            }
+#endif
             for (int r = 0; r < 2; ++r)
                 fprintf(stderr, "%s units %d: mean %.1f us (staging %.1f, first batch %.1f, search over after %.1f), max %.1f us, evaluations per wave %.1f, batches per wave %.1f\n", r ? "rim" : "interior", cnt[r],
                         sum[r] / std::max(cnt[r], 1), stg[r] / std::max(cnt[r], 1), fst[r] / std::max(cnt[r], 1), srch[r] / std::max(cnt[r], 1), mx[r], ev[r] / std::max(cnt[r], 1), bat[r] / std::max(cnt[r], 1));
@@ -2784,23 +2891,24 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
             }
             {   // rim units by where they lie: mean duration, evaluations and batches per wave
                 const char *names[6] = {"top", "bottom, last segment", "bottom, other segments", "left", "right", "corner or other"};
-                double dur[6] = {0}, evs[6] = {0}, bts[6] = {0}, thrA[6] = {0}, thrB[6] = {0}; int nu[6] = {0}, nNarrow[6] = {0}, nWaves[6] = {0}, nZero[6] = {0}, nBand[6] = {0}; double wBand[6] = {0};
+                double dur[6] = {0}, evs[6] = {0}, bts[6] = {0}, thrA[6] = {0}, thrB[6] = {0}; int nu[6] = {0}, nNarrow[6] = {0}, nWaves[6] = {0}, nZero[6] = {0}, nBand[6] = {0}; double wBand[6] = {0}, srchK[6] = {0}, fstK[6] = {0};
                 int maxTx = 0, maxTy = 0;
                 for (int u = 0; u < n; ++u) { const unsigned long long *o = &h[(u * 4) * 8]; if (!o[1]) continue; maxTx = std::max(maxTx, (int)((o[6] >> 12) & 0xFF)); maxTy = std::max(maxTy, (int)((o[6] >> 20) & 0xFF)); }
                 for (int u = 0; u < n; ++u) {
-                    unsigned long long a = ~0ull, b = 0, evals = 0, batches = 0; int rim = 0, tx = 0, ty = 0, sg = 0, nw = 0;
+                    unsigned long long a = ~0ull, b = 0, evals = 0, batches = 0; int rim = 0, tx = 0, ty = 0, sg = 0, nw = 0; double se = 0, fs = 0;
                     for (int w = 0; w < 4; ++w) { const unsigned long long *o = &h[(u * 4 + w) * 8]; if (!o[1]) continue; a = std::min(a, o[0]); b = std::max(b, o[1]); evals += o[2]; batches += o[3] & 0xFFFFFFFFull;
+                        se = std::max(se, (double)(o[3] >> 33) / 100.0); if (o[5]) fs = std::max(fs, (double)(o[5] - o[0]) / 100.0);
                         rim = (int)((o[3] >> 32) & 1); tx = (int)((o[6] >> 12) & 0xFF); ty = (int)((o[6] >> 20) & 0xFF); sg = (int)((o[6] >> 10) & 3); ++nw; }
                     if (!b || !rim) continue;
                     const bool l = tx == 0, r = tx == maxTx, t = ty == 0, bo = ty == maxTy;
                     const int k = (l + r + t + bo) != 1 ? 5 : t ? 0 : bo ? (sg == 2 ? 1 : 2) : l ? 3 : 4;
-                    dur[k] += (double)(b - a) / 100.0; evs[k] += (double)evals / nw; bts[k] += (double)batches / nw; ++nu[k];
+                    dur[k] += (double)(b - a) / 100.0; evs[k] += (double)evals / nw; bts[k] += (double)batches / nw; ++nu[k]; srchK[k] += se; fstK[k] += fs;
                     for (int w = 0; w < 4; ++w) { const unsigned long long *o = &h[(u * 4 + w) * 8]; if (!o[1]) continue; ++nWaves[k]; if (o[6] & 7u) ++nNarrow[k];
                         const uint32_t ta = (uint32_t)o[7], tb = (uint32_t)(o[7] >> 32); float fa, fb; memcpy(&fa, &ta, 4); memcpy(&fb, &tb, 4);
                         if (fa < 0.5f) ++nZero[k]; else { thrA[k] += std::min(fa, 1e5f); thrB[k] += std::min(fb, 1e5f); }
                         const unsigned box = (unsigned)(o[6] >> 32); if (((box >> 16) & 0xFF) == 0xEE) { ++nBand[k]; wBand[k] += (double)(((box >> 8) & 0xFF) - (box & 0xFF) + 1); } }
                 }
-                for (int k = 0; k < 6; ++k) if (nu[k]) fprintf(stderr, "rim units, %s: %d, mean %.1f us, evaluations per wave %.1f, batches per wave %.1f; waves %d, narrow %d, all-zero thresholds after the hints %d, others' mean threshold after hints %.0f, at the end %.0f; band known in %d waves, mean width %.1f columns\n", names[k], nu[k], dur[k] / nu[k], evs[k] / nu[k], bts[k] / nu[k],
+                for (int k = 0; k < 6; ++k) if (nu[k]) fprintf(stderr, "rim units, %s: %d, mean %.1f us (first batch done after %.1f, search over after %.1f), evaluations per wave %.1f, batches per wave %.1f; waves %d, narrow %d, all-zero thresholds after the hints %d, others' mean threshold after hints %.0f, at the end %.0f; band known in %d waves, mean width %.1f columns\n", names[k], nu[k], dur[k] / nu[k], fstK[k] / nu[k], srchK[k] / nu[k], evs[k] / nu[k], bts[k] / nu[k],
                                                         nWaves[k], nNarrow[k], nZero[k], thrA[k] / std::max(1, nWaves[k] - nZero[k]), thrB[k] / std::max(1, nWaves[k] - nZero[k]), nBand[k], wBand[k] / std::max(1, nBand[k]));
             }
             {   // narrow search: waves by candidates per pass, their mean duration
