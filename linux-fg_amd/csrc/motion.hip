@@ -494,6 +494,7 @@ __device__ __forceinline__ void prefilter_unit(
     // (the two flags of this call's order, requested here: read where they are used -- behind the staging barrier -- each
     //  was a scalar load from memory with nothing to hide its latency, two microseconds per unit)
     const uint32_t orderHandOver = order32[kCand], orderHints = order32[kCand + 1];
+    const uint32_t unitAuxFirst = (!whole && !fromQueue) ? sp.unitAux[unit] : 0u;      // (likewise: its lists are addressed behind the barrier)
     // A unit that shares its tile first runs the head of the order -- zero motion and the first hints -- for the
     // thresholds only (not recorded: the unit that owns those entries records them).  Without it a unit whose part
     // of the order holds no good candidate starts from nothing and records far more than it needs to.
@@ -675,7 +676,7 @@ __device__ __forceinline__ void prefilter_unit(
     // Whole tiles write into the image-shaped arrays (row stride W), shared tiles into their unit's private
     // 56 x 64 block of the auxiliary arrays (row stride 56).
     // (auxiliary blocks: a tile's 64 rows for the units of the plan, a segment's 16 rows for queued units)
-    const int auxUnit = whole ? 0 : (fromQueue ? 4 * unit + wave : (int)sp.unitAux[unit] + chunk);
+    const int auxUnit = whole ? 0 : (fromQueue ? 4 * unit + wave : (int)unitAuxFirst + chunk);
     const int auxRows = fromQueue ? kSeg : kPTH, auxRow0 = fromQueue ? kSeg * seg : 0;
     Rec *const auxListBase = fromQueue ? sp.dynList : sp.auxList;
     float *const auxUminBase = fromQueue ? sp.dynUmin : sp.auxUmin;
