@@ -103,7 +103,7 @@ int         lfg_sync(lfg_context *ctx);
 /* Lanes: several frames in flight on one GPU.  The reference has one queue and waits for it after every
  * submission (src/scaler.cpp:389-393, src/frame_manager.cpp:190-194); here a frame's last long motion units leave
  * most CUs idle for a third of its time, and the next frame's scale, hints and first units can run there.  A lane
- * is a stream plus the temporaries and the motion workspace (2.5 GB at 4K) of the calls made while it is selected;
+ * is a stream plus the temporaries and the motion workspace (2.2 GB at 4K: lfg_motion_workspace_size) of the calls made while it is selected;
  * frames are plain device memory and may be used from any lane -- the caller orders producers and consumers:
  *   lfg_lanes(ctx, n)       1 <= n <= LFG_MAX_LANES lanes (lane 0 is the context's own stream); shrinking waits
  *                           for the lanes that go and frees what they own
@@ -198,6 +198,10 @@ int  lfg_set_motion_mode(lfg_context *ctx, int mode);
  * and the mean number of candidates recorded per pixel in the others (synchronises; reporting only). */
 int  lfg_motion_last_stats(lfg_context *ctx, uint32_t *out_tiles, uint32_t *out_fallback_tiles,
                            double *out_mean_recorded);
+/* Bytes of device memory the prefiltered lfg_motion keeps for frames of this size (allocated on the first such call, kept
+ * until the size changes or the context goes; one per lane).  No reference counterpart -- the reference's motion pass keeps
+ * nothing between its two images (src/frame_manager.cpp:262-300); a host budgets lanes with it.  Needs no GPU work. */
+int  lfg_motion_workspace_size(lfg_context *ctx, uint32_t width, uint32_t height, uint64_t *out_bytes);
 
 /* Which arithmetic lfg_motion and lfg_interpolate follow.  No reference counterpart: SURVEY.md 8(f) rank 4.
  *   LFG_SEMANTICS_REFERENCE (default, the parity contract): the shaders as written -- equal block-match costs

@@ -75,6 +75,7 @@ SIGNATURES = {
     "lfg_motion": (_i, [_vp, _FP, _FP, _FP, _i, ctypes.c_float]),
     "lfg_set_motion_mode": (_i, [_vp, _i]),
     "lfg_motion_last_stats": (_i, [_vp, ctypes.POINTER(_u32), ctypes.POINTER(_u32), ctypes.POINTER(ctypes.c_double)]),
+    "lfg_motion_workspace_size": (_i, [_vp, _u32, _u32, ctypes.POINTER(ctypes.c_uint64)]),
     "lfg_set_semantics": (_i, [_vp, _i]),
     "lfg_interpolate": (_i, [_vp, _FP, _FP, _FP, _FP, ctypes.c_float]),
     "lfg_interpolate_frames": (_i, [_vp, _FP, _FP, _FP, ctypes.c_float]),
@@ -270,6 +271,12 @@ class Context:
         t, f, m = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_double()
         self._check(self.lib.lfg_motion_last_stats(self.h, ctypes.byref(t), ctypes.byref(f), ctypes.byref(m)), "lfg_motion_last_stats")
         return t.value, f.value, m.value
+
+    def motion_workspace_size(self, width: int, height: int) -> int:
+        """Bytes the prefiltered motion path keeps for frames of this size (per lane)."""
+        n = ctypes.c_uint64()
+        self._check(self.lib.lfg_motion_workspace_size(self.h, width, height, ctypes.byref(n)), "lfg_motion_workspace_size")
+        return n.value
 
     def interpolate(self, prev: Frame, curr: Frame, mv: Frame, out: Frame, factor: float = 0.5):
         self._check(self.lib.lfg_interpolate(self.h, ctypes.byref(prev), ctypes.byref(curr), ctypes.byref(mv),

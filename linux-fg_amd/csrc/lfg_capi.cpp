@@ -641,6 +641,15 @@ LFG_EXPORT int lfg_set_motion_mode(lfg_context *ctx, int mode) {
     return LFG_OK;
 }
 
+LFG_EXPORT int lfg_motion_workspace_size(lfg_context *ctx, uint32_t width, uint32_t height, uint64_t *out_bytes) {
+    if (!ctx) return LFG_ERR_INVALID;
+    if (!out_bytes || width == 0 || height == 0 || width > 32768u || height > 32768u)
+        return fail(ctx, LFG_ERR_INVALID, "lfg_motion_workspace_size: null output or a frame size outside 1..32768");
+    if (ctx->motion_slots == 0) ctx->motion_slots = lfg::prefilter_slots();
+    *out_bytes = (uint64_t)lfg::motion_workspace_bytes(width, height, ctx->motion_slots, nullptr);
+    return LFG_OK;
+}
+
 LFG_EXPORT int lfg_motion_last_stats(lfg_context *ctx, uint32_t *out_tiles, uint32_t *out_fallback_tiles,
                                      double *out_mean_recorded) {
     if (!ctx) return LFG_ERR_INVALID;

@@ -365,6 +365,15 @@ constexpr int kRunIn = kRun + kB - 1;             // 13
 #ifndef LFG_ZERO_COMPARE
 #define LFG_ZERO_COMPARE 1
 #endif
+#ifndef LFG_LIST_MAIN
+#define LFG_LIST_MAIN 32
+#endif
+#ifndef LFG_LIST_AUX
+#define LFG_LIST_AUX 24
+#endif
+#ifndef LFG_LIST_DYN
+#define LFG_LIST_DYN 24
+#endif
 #ifndef LFG_RANK_ALWAYS
 #define LFG_RANK_ALWAYS 1
 #endif
@@ -399,9 +408,20 @@ static_assert(kSlabFloats >= 4 * kSlabP && 2 * (3 * kNarrowQ + 15) + 1 < kNarrow
 #define LFG_HINT_GRID 16
 #endif
 constexpr int kHintGrid = LFG_HINT_GRID, kHints = kHintGrid * kHintGrid;      // sample blocks of the per-call visiting order
-constexpr int kListK = 32;              // recorded candidates per pixel.  A pseudo-random visiting order makes the
-                                        // number of running minima ~Poisson(ln 1089 = 7.6) whatever the content:
-                                        // P(> 32) ~ 1e-11 per pixel, so only genuinely tied content overflows
+// Recorded candidates per pixel and list.  A pseudo-random visiting order makes the number of running minima of a pixel
+// without any match ~Poisson(ln n) over the n candidates a wave visits, whatever the content; a list that overflows flags
+// its tile for the literal kernel (exact, slow), so the depths are sized for "no tile, ever, on a frame of pure noise":
+//   kListK    image-shaped lists of whole tiles: n = 1089, Poisson(7.6): P(> 32) ~ 1e-11 per unmatched pixel.  (24 was
+//             measured: P(> 24) ~ 5e-7, two or three tiles of a 4K noise frame through the literal kernel, 4 % of its time.)
+//   kListAux  private lists of the parts of a rim tile: n <= 273, Poisson(5.6): P(> 24) ~ 1e-9;
+//   kListDyn  private lists of the eight parts of a segment handed over at run time: n = 137, and a part starts from the
+//             thresholds of the wave that handed the segment over, which has tried the call's first eight candidates at
+//             least; Poisson(ln(145 / 8) = 2.9) would allow 16 -- measured, it does not: 3 tiles of the hand-over test's
+//             4K frame (noise around intact sample points, 7.3 M pixel-parts) overflow at 16 and 25 tiles of the occluded
+//             benchmark frame at 12, as if three candidates had been seen before, not eight.  24 has the margin.
+// (32 / 32 / 32 before: 2.5 GB of workspace at 4K instead of 2.2.)
+constexpr int kListK = LFG_LIST_MAIN, kListAux = LFG_LIST_AUX, kListDyn = LFG_LIST_DYN;
+static_assert(kListK % 2 == 0 && kListK >= 4 && kListAux >= 4 && kListDyn >= 4 && kListK <= 64 && kListAux <= 64 && kListDyn <= 64, "list depths");
 constexpr float kRatio = 1.00008f;      // >= (1 + 3.6e-5) / (1 - 3.6e-5) with room for the product's rounding ("Bracket")
 static_assert((kHints & (kHints - 1)) == 0 && kHints >= 256 && kHints <= 1024, "one hint per thread of the order kernel, scrambled by an odd multiplier");
 static_assert(kPNT / 64 * kSeg == kPTH && 8 * kRun == kPTW && kPTH == kTH, "stage maps cover the tile");
@@ -682,14 +702,15 @@ __device__ __forceinline__ void prefilter_unit(
     float *const auxUminBase = fromQueue ? sp.dynUmin : sp.auxUmin;
     uint32_t *const auxCountBase = fromQueue ? sp.dynCount : sp.auxCount;
     const uint32_t rowStride = whole ? (uint32_t)W : (uint32_t)kPTW;
+    const uint32_t listK = whole ? (uint32_t)kListK : (fromQueue ? (uint32_t)kListDyn : (uint32_t)kListAux);      // this unit's list depth
     Rec *const waveList = whole
         ? list + ((size_t)(ty0 + kSeg * seg) * (size_t)kListK * (size_t)W + (size_t)tx0)
-        : auxListBase + ((size_t)auxUnit * auxRows + (size_t)(kSeg * seg - auxRow0)) * (size_t)kListK * (size_t)kPTW;
+        : auxListBase + ((size_t)auxUnit * auxRows + (size_t)(kSeg * seg - auxRow0)) * (size_t)listK * (size_t)kPTW;
     uint32_t laneOff[2];
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
         const int py = ty0 + kSeg * seg + 8 * hb + r8;
-        laneOff[hb] = (uint32_t)(8 * hb + r8) * ((uint32_t)kListK * rowStride) + (uint32_t)(kRun * q);   // < 16 K W
+        laneOff[hb] = (uint32_t)(8 * hb + r8) * (listK * rowStride) + (uint32_t)(kRun * q);   // < 16 K W
 #pragma unroll
         for (int i = 0; i < (kRun + 1) / 2; ++i) cnt2[hb][i] = 0u;
 #pragma unroll
@@ -699,13 +720,13 @@ __device__ __forceinline__ void prefilter_unit(
             if (hb) thr2[i].y = t0; else thr2[i].x = t0;
         }
     }
-    // some pixel of this lane has more than kListK records: bit 15 of a 16-bit counter biased by 0x7FFF - kListK
+    // some pixel of this lane has more than listK records: bit 15 of a 16-bit counter biased by 0x7FFF - listK
     auto listsOverflowed = [&]() -> bool {
         uint32_t any = 0u;
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
 #pragma unroll
-            for (int i = 0; i < (kRun + 1) / 2; ++i) any |= cnt2[hb][i] + (uint32_t)(0x7FFF - kListK) * 0x10001u;
+            for (int i = 0; i < (kRun + 1) / 2; ++i) any |= cnt2[hb][i] + (0x7FFFu - listK) * 0x10001u;
         }
         return (any & 0x80008000u) != 0u;
     };
@@ -782,7 +803,7 @@ __device__ __forceinline__ void prefilter_unit(
                         const uint32_t n = (cnt2[hb][i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
                         // past the end of the list the last slot is overwritten; the count keeps growing and
                         // flags the tile
-                        const uint32_t at = __umul24(min(n, (uint32_t)kListK - 1u), rowStride) + laneOff[hb] + (uint32_t)i;
+                        const uint32_t at = __umul24(min(n, listK - 1u), rowStride) + laneOff[hb] + (uint32_t)i;
                         if (s != 0.0f) waveList[at] = rec_make(s, cand);       // (a zero-cost candidate lives in the threshold word: no record, no write)
                         uint32_t inc = (s != 0.0f && countIt != 0u) ? (1u << (16 * (i & 1))) : 0u;
                         if (candMayLeave) {                            // wave-uniform: tiles away from the rim skip this
@@ -1305,7 +1326,7 @@ __device__ __forceinline__ void prefilter_unit(
             }
             // column sum i (0..10) of candidate k for this lane: slab column c = colsPer k + 4 g + i, stored at (c & 3) kNarrowQ + c / 4
             const lds_ro_f32_ptr nSlabR = (lds_ro_f32_ptr)(sSlab[wave] + (r >> 1) * kNarrowPitch + (r & 1) + 2 * (active ? g : 0));
-            const uint32_t nLaneOff = (uint32_t)r * ((uint32_t)kListK * rowStride) + (uint32_t)(nXb + 4 * g);
+            const uint32_t nLaneOff = (uint32_t)r * (listK * rowStride) + (uint32_t)(nXb + 4 * g);
             const int segY0 = ty0 + kSeg * seg;
             auto testCandidate = [&](const float (&X)[4 + kB - 1], uint32_t ord, uint32_t countIt) {
                 float h2[10], h4[8], sN[4];
@@ -1335,7 +1356,7 @@ __device__ __forceinline__ void prefilter_unit(
                         if (s <= thrN[j]) {                            // (the rules of rowSumsAndTest)
                             const float cap = __builtin_fmaxf(s * kRatio, __builtin_bit_cast(float, zeroCap));
                             thrN[j] = __builtin_fminf(thrN[j], cap);
-                            const uint32_t at = __umul24(min(cntN[j], (uint32_t)kListK - 1u), rowStride) + nLaneOff + (uint32_t)j;
+                            const uint32_t at = __umul24(min(cntN[j], listK - 1u), rowStride) + nLaneOff + (uint32_t)j;
                             if (s != 0.0f) waveList[at] = rec_make(s, cand);
                             uint32_t inc = (s != 0.0f && countIt != 0u) ? 1u : 0u;
                             if (candMayLeave) {
@@ -1359,7 +1380,7 @@ __device__ __forceinline__ void prefilter_unit(
                 if (!have && !pending) {                               // (the pipeline has drained) every 64 entries: give up?
                     if (idx0 >= iEnd) break;
                     started = 0;
-                    const bool over = cntN[0] > (uint32_t)kListK || cntN[1] > (uint32_t)kListK || cntN[2] > (uint32_t)kListK || cntN[3] > (uint32_t)kListK;
+                    const bool over = cntN[0] > listK || cntN[1] > listK || cntN[2] > listK || cntN[3] > listK;
                     if (__builtin_amdgcn_readfirstlane(__ballot(over) != 0ull)) sGiveUp = 1u;
                     if (__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)&sGiveUp) != 0) return false;
                     continue;
@@ -2235,13 +2256,14 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
     const float *thrs;
     const uint32_t *cnts;
     uint32_t listStride, recStride, thrStride;
+    const uint32_t listDepth = handedOver ? (uint32_t)kListDyn : whole ? (uint32_t)kListK : (uint32_t)kListAux;
     if (handedOver) {
         const size_t blk0 = (size_t)(sm & 0xFFFFFFu);
         const int ly = cpy % kSeg, lx = cpx % kPTW;
-        recs = sp.dynList + (blk0 * kSeg + (size_t)ly) * (size_t)kListK * kPTW + (size_t)lx;
+        recs = sp.dynList + (blk0 * kSeg + (size_t)ly) * (size_t)kListDyn * kPTW + (size_t)lx;
         thrs = sp.dynUmin + (blk0 * kSeg + (size_t)ly) * kPTW + (size_t)lx;
         cnts = sp.dynCount + (blk0 * kSeg + (size_t)ly) * kPTW + (size_t)lx;
-        listStride = (uint32_t)(kSeg * kListK * kPTW); recStride = kPTW; thrStride = (uint32_t)(kSeg * kPTW);
+        listStride = (uint32_t)(kSeg * kListDyn * kPTW); recStride = kPTW; thrStride = (uint32_t)(kSeg * kPTW);
     } else if (whole) {
         recs = list + (size_t)cpy * (size_t)kListK * (size_t)W + (size_t)cpx;
         thrs = uminIn + (size_t)cpy * (size_t)W + (size_t)cpx;
@@ -2250,10 +2272,10 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
     } else {
         const size_t unit0 = (size_t)(tm & 0xFFFFFFu);
         const int ly = cpy % kPTH, lx = cpx % kPTW;
-        recs = sp.auxList + (unit0 * kPTH + (size_t)ly) * (size_t)kListK * kPTW + (size_t)lx;
+        recs = sp.auxList + (unit0 * kPTH + (size_t)ly) * (size_t)kListAux * kPTW + (size_t)lx;
         thrs = sp.auxUmin + (unit0 * kPTH + (size_t)ly) * kPTW + (size_t)lx;
         cnts = sp.auxCount + (unit0 * kPTH + (size_t)ly) * kPTW + (size_t)lx;
-        listStride = (uint32_t)(kPTH * kListK * kPTW); recStride = kPTW; thrStride = (uint32_t)(kPTH * kPTW);
+        listStride = (uint32_t)(kPTH * kListAux * kPTW); recStride = kPTW; thrStride = (uint32_t)(kPTH * kPTW);
     }
     // A recorded candidate whose block leaves prev stands for its whole plateau (block_leaves_prev): same exact
     // cost, so the plateau's first member in tie order takes its place.
@@ -2312,7 +2334,7 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
             uint32_t nL[kMaxLists];
 #pragma unroll
             for (int c = 0; c < kMaxLists; ++c) {
-                nL[c] = min(cntL[c], (uint32_t)kListK);
+                nL[c] = min(cntL[c], listDepth);
                 count(recL[c], nL[c] > 0u);
             }
             // The rest of the lists: four lists x four records per round, all sixteen loads in flight (a pixel
@@ -2358,6 +2380,7 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
         const int qx = __shfl(px, L), qy = __shfl(py, L);
         const float qBound = __shfl(bound, L);
         const int qLists = __shfl(nLists, L);
+        const uint32_t qDepth = __shfl(listDepth, L);
         const uint32_t qListStride = __shfl(listStride, L), qRecStride = __shfl(recStride, L), qThrStride = __shfl(thrStride, L);
         const Rec *qRecs = reinterpret_cast<const Rec *>(
             ((unsigned long long)__shfl((uint32_t)((unsigned long long)recs >> 32), L) << 32) |
@@ -2374,7 +2397,7 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
         float bestV = __builtin_inff();
         uint32_t bestR = 0xFFFFFFFFu;
         for (int c = 0; c < qLists; ++c) {
-            const uint32_t n = min(qCnts[(size_t)c * qThrStride], (uint32_t)kListK);
+            const uint32_t n = min(qCnts[(size_t)c * qThrStride], qDepth);
             for (uint32_t k = 0; k < n; ++k) {
                 const Rec rec = qRecs[(size_t)c * qListStride + (size_t)k * qRecStride];    // same address in every lane
                 if (!(rec_cost_low(rec) <= qBound)) continue;
@@ -2499,13 +2522,13 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, Motion
     const size_t auxUnits = (size_t)plan.auxUnits;
     l.plan = align(l.order + (kHints + kCand + 3) * sizeof(uint32_t));
     l.auxList = align(l.plan + (size_t)(2 * plan.units + plan.tiles) * sizeof(uint32_t));
-    l.auxUmin = align(l.auxList + auxUnits * kPTH * kPTW * kListK * sizeof(Rec));
+    l.auxUmin = align(l.auxList + auxUnits * kPTH * kPTW * kListAux * sizeof(Rec));
     l.auxCount = align(l.auxUmin + auxUnits * kPTH * kPTW * sizeof(float));
     // each queue entry owns four 16-row blocks of private lists (0.92 MB)
     const size_t dynBlocks = (size_t)l.queueCap * 4;
     l.dynList = align(l.auxCount + auxUnits * kPTH * kPTW * sizeof(uint32_t));
     l.slots = slots;
-    l.dynUmin = align(l.dynList + dynBlocks * kSeg * kPTW * kListK * sizeof(Rec));
+    l.dynUmin = align(l.dynList + dynBlocks * kSeg * kPTW * kListDyn * sizeof(Rec));
     l.dynCount = align(l.dynUmin + dynBlocks * kSeg * kPTW * sizeof(float));
     l.dynInit = align(l.dynCount + dynBlocks * kSeg * kPTW * sizeof(uint32_t));
     l.total = align(l.dynInit + (size_t)l.queueCap / (LFG_DYN_PARTS / 4) * kSeg * kPTW * sizeof(uint32_t));

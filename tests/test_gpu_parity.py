@@ -950,6 +950,27 @@ def test_mv_export_is_the_reference_rgba32f_image(ctx, oracle):
         ctx.destroy_frame(f)
 
 
+def test_motion_workspace_size_and_list_depths_on_pure_noise(ctx):
+    """lfg_motion_workspace_size: what the prefiltered path keeps per lane (2.2 GB at 4K with list depths 32 / 24 / 24;
+    2.5 GB with 32 everywhere), refusals; and the depths are enough where lists are longest -- a pair of independent noise
+    frames, every pixel without a match, every list holding its ~ln(n) running minima: no tile overflows into the literal
+    kernel, and the vectors are the literal kernel's."""
+    from linux_fg_amd import capi
+    n4k = ctx.motion_workspace_size(3840, 2160)
+    assert 0.5e9 < n4k < 2.3e9
+    assert ctx.motion_workspace_size(1920, 1080) < n4k
+    for bad in ((0, 16), (16, 0), (40000, 16)):
+        with pytest.raises(capi.LfgError):
+            ctx.motion_workspace_size(*bad)
+    w, h = 1920, 1080
+    prev = synth.noise_bytes(w, h, 4242)
+    curr = synth.noise_bytes(w, h, 4243)
+    a, st = run_motion_mode(ctx, prev, curr, capi.MOTION_PREFILTERED)
+    b, _ = run_motion_mode(ctx, prev, curr, capi.MOTION_EXACT_ONLY)
+    assert (a == b).all()
+    assert st[1] == 0, f"{st[1]} of {st[0]} tiles overflowed their lists"
+
+
 def test_staging_buffers_round_trip(ctx):
     """lfg_staging_create / lfg_staging_destroy (FrameManager::CreateStagingBuffer, src/frame_manager.cpp:199-214):
     pinned host memory, asynchronous upload from it and read-back into it."""
