@@ -666,6 +666,29 @@ LFG_EXPORT int lfg_motion_last_stats(lfg_context *ctx, uint32_t *out_tiles, uint
         fprintf(stderr, "lfg: motion prefilter: %u requests to hand a segment over (room for %d), %u tiles flagged for the exact kernel\n",
                 handed[0], ctx->motion_ws_layout.queueCap, handed[1]);
     }
+    if (getenv("LFG_DEBUG_DYN")) {       // the deepest private lists of the handed-over segments: block (4 x queue slot + wave), pixel, records
+        uint32_t handed[2] = {0, 0};
+        LFG_HIP(ctx, hipMemcpy(handed, ctx->motion_ws + ctx->motion_ws_layout.queueCount, 8, hipMemcpyDeviceToHost));
+        const size_t blocks = (size_t)std::min<uint32_t>(handed[0], (uint32_t)ctx->motion_ws_layout.queueCap) * 4u, per = 16u * 56u;
+        std::vector<uint32_t> dc(blocks * per);
+        if (!dc.empty()) LFG_HIP(ctx, hipMemcpy(dc.data(), ctx->motion_ws + ctx->motion_ws_layout.dynCount, dc.size() * 4, hipMemcpyDeviceToHost));
+        size_t hist[40] = {0};
+        for (size_t i = 0; i < dc.size(); ++i) { ++hist[std::min<uint32_t>(dc[i], 39u)]; if (dc[i] > 14u) fprintf(stderr, "lfg: dyn list block %zu (part %zu of its segment) pixel %zu: %u records\n", i / per, (i / per) % 8u, i % per, dc[i]); }
+        {   // which segments under the flagged tiles were handed over
+            const uint32_t ptx = (ctx->motion_ws_w + 55u) / 56u, pty = (ctx->motion_ws_h + 63u) / 64u;
+            std::vector<uint32_t> sm((size_t)ptx * pty * 4u);
+            LFG_HIP(ctx, hipMemcpy(sm.data(), ctx->motion_ws + ctx->motion_ws_layout.segMap, sm.size() * 4, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < flags.size(); ++i) if (flags[i]) {
+                const uint32_t fx = (uint32_t)(i % tx), fy = (uint32_t)(i / tx);
+                for (uint32_t px = fx * 64u / 56u; px <= std::min(ptx - 1u, (fx * 64u + 63u) / 56u); ++px)
+                    for (uint32_t sg = 0; sg < 4u; ++sg)
+                        fprintf(stderr, "lfg: flagged tile (%u,%u) flag %#x: prefilter tile (%u,%u) segment %u segMap %#x\n", fx, fy, flags[i], px, fy, sg, sm[((size_t)fy * ptx + px) * 4u + sg]);
+            }
+        }
+        fprintf(stderr, "lfg: dyn list depths over %zu pixel-parts:", dc.size());
+        for (int k = 0; k < 40; ++k) if (hist[k]) fprintf(stderr, " %d:%zu", k, hist[k]);
+        fprintf(stderr, "\n");
+    }
     if (getenv("LFG_DEBUG"))
         for (size_t i = 0; i < flags.size(); ++i)
             if (flags[i]) fprintf(stderr, "lfg: motion fallback tile (%zu, %zu)\n", i % tx, i / tx);

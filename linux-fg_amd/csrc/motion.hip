@@ -416,12 +416,11 @@ constexpr int kHintGrid = LFG_HINT_GRID, kHints = kHintGrid * kHintGrid;      //
 //   kListAux  private lists of the parts of a rim tile: n <= 273, Poisson(5.6): P(> 24) ~ 1e-9;
 //   kListDyn  private lists of the eight parts of a segment handed over at run time: n = 137, and a part starts from the
 //             thresholds of the wave that handed the segment over, which has tried the call's first eight candidates at
-//             least; sum 1 / (8 + j) = 2.9 expected records would allow 16 (P(> 16) = 3e-9) -- measured, it does not: the
-//             same 3 tiles of the hand-over test's 4K frame overflow at 16 with and without the inherited thresholds.
-//             The visiting order is an arithmetic progression through the scan order, not a random permutation, and
-//             where prev is a smooth gradient a part's 137 consecutive visits can walk down it: costs that fall along
-//             the order, many running minima.  (12: 25 tiles of the occluded benchmark frame, as the count predicts.)
-//             24 has the margin on every frame of the test-suite and the fuzz.
+//             least; sum 1 / (8 + j) = 2.9 expected records would allow 16 (P(> 16) = 3e-9, and the parts that finish hold
+//             15 at most on the hand-over test's 4K frame: LFG_DEBUG_DYN) -- yet two segments of that frame give up at
+//             16, with and without the inherited thresholds or the narrow search.  Not understood; 24 has the margin on
+//             every frame of the test-suite and the fuzz.  (12: 25 tiles of the occluded benchmark frame, as the count
+//             predicts.)
 // (32 / 32 / 32 before: 2.5 GB of workspace at 4K instead of 2.2.)
 constexpr int kListK = LFG_LIST_MAIN, kListAux = LFG_LIST_AUX, kListDyn = LFG_LIST_DYN;
 static_assert(kListK % 2 == 0 && kListK >= 4 && kListAux >= 4 && kListDyn >= 4 && kListK <= 64 && kListAux <= 64 && kListDyn <= 64, "list depths");
