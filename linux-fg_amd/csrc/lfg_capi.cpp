@@ -685,6 +685,18 @@ LFG_EXPORT int lfg_motion_last_stats(lfg_context *ctx, uint32_t *out_tiles, uint
                         fprintf(stderr, "lfg: flagged tile (%u,%u) flag %#x: prefilter tile (%u,%u) segment %u segMap %#x\n", fx, fy, flags[i], px, fy, sg, sm[((size_t)fy * ptx + px) * 4u + sg]);
             }
         }
+        for (size_t b = 0; b < blocks; ++b) {      // blocks nobody wrote counts into: their workgroup gave up (or the segment settled)
+            bool any = false;
+            for (size_t i = 0; i < per && !any; ++i) any = dc[b * per + i] != 0u;
+            if (!any) fprintf(stderr, "lfg: dyn block %zu (part %zu) holds no counts\n", b, b % 8u);
+        }
+        {
+            double sum[8] = {0}; size_t n8[8] = {0};
+            for (size_t i = 0; i < dc.size(); ++i) { sum[(i / per) % 8u] += dc[i]; ++n8[(i / per) % 8u]; }
+            fprintf(stderr, "lfg: mean records per pixel by part:");
+            for (int k = 0; k < 8; ++k) fprintf(stderr, " %.2f", n8[k] ? sum[k] / n8[k] : 0.0);
+            fprintf(stderr, "\n");
+        }
         fprintf(stderr, "lfg: dyn list depths over %zu pixel-parts:", dc.size());
         for (int k = 0; k < 40; ++k) if (hist[k]) fprintf(stderr, " %d:%zu", k, hist[k]);
         fprintf(stderr, "\n");
