@@ -2983,6 +2983,9 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
                        reinterpret_cast<unsigned long long *>(list));
     e = hipGetLastError();
     if (e != hipSuccess) return e;
+#ifdef LFG_DIAG_NO_FALLBACK             // (timing experiment: what the three launches that usually find nothing to do cost)
+    return hipSuccess;
+#endif
     // (the flagged tiles' parts merge in record 0 of their pixels' lists, which nothing reads any more)
     return launch_motion_tiled_8_16(s, prev, curr, mv, flags, rank2scan, reinterpret_cast<unsigned long long *>(list),
                                     (size_t)kListK * (size_t)curr.width / 2u, sp.queueCount + 1);
