@@ -82,5 +82,6 @@ def test_null_arguments_are_rejected(capi):
     assert lib.lfg_lanes(None, 2) != 0 and lib.lfg_lane_select(None, 0) != 0
     assert lib.lfg_lane_mark(None) != 0 and lib.lfg_lane_wait(None, 0) != 0
     assert lib.lfg_lane_count(None) == 0 and lib.lfg_lane_current(None) == -1
+    assert lib.lfg_motion_workspace_size(None, 3840, 2160, None) != 0      # (a size query still needs a context: a device)
     lib.lfg_context_destroy(None)                   # NULL-safe, like the reference's Cleanup()
     lib.lfg_frame_destroy(None, None)
