@@ -374,6 +374,9 @@ constexpr int kRunIn = kRun + kB - 1;             // 13
 #ifndef LFG_LIST_DYN
 #define LFG_LIST_DYN 24
 #endif
+#ifndef LFG_BORDER_PER_SEGMENT
+#define LFG_BORDER_PER_SEGMENT 1
+#endif
 #ifndef LFG_RANK_ALWAYS
 #define LFG_RANK_ALWAYS 1
 #endif
@@ -616,6 +619,11 @@ __device__ __forceinline__ void prefilter_unit(
     // Interior tiles: every block position the outputs use (columns 0..62) lies inside the image.
     const int borderTile = __builtin_amdgcn_readfirstlane(
         !((bx0 >= 0) && (bx0 + kPTW + kB - 2 < W) && (by0 >= 0) && (by0 + kPTH + kB - 2 < H)));
+    // ... and what counts for a wave is its own segment's 23 position rows: the inner segments of a tile at the top or bottom
+    // border take the interior paths (24-point lattice, lookahead, no validity masks).
+    const int segRow0 = __builtin_amdgcn_readfirstlane(by0 + kSeg * seg);
+    const int borderSeg = LFG_BORDER_PER_SEGMENT
+        ? __builtin_amdgcn_readfirstlane((int)((bx0 < 0) | (bx0 + kPTW + kB - 2 >= W) | (segRow0 < 0) | (segRow0 + kSegD - 1 >= H))) : borderTile;
 
     // Some candidate's block can leave prev altogether only if the search window does.
     const int windowLeavesPrev = __builtin_amdgcn_readfirstlane(
@@ -659,7 +667,7 @@ __device__ __forceinline__ void prefilter_unit(
         float dMid = __builtin_amdgcn_sqrtf((f1of(kHalf - 1) - f2of(kHalf - 1)) + 8388608.0f);   // d_11
         // Border tiles only (one wave-uniform branch; the flag is laundered through an empty asm so the loop
         // is not unswitched into two copies, which doubles the register pressure of the function).
-        int border = borderTile;
+        int border = borderSeg;
         asm volatile("" : "+s"(border));
         if (border) {                      // position outside the image: skipped by the shader, adds 0 here
 #pragma unroll
@@ -893,7 +901,7 @@ __device__ __forceinline__ void prefilter_unit(
         // against are those at its start; the first two batches are short (zero motion and the first hint, then six
         // more) so that the long ones start with thresholds worth testing against.
         const int nEntries = nHead + eEnd - eBegin;                    // the head, then this wave's part of the order
-        int border = borderTile;
+        int border = borderSeg;
         asm volatile("" : "+s"(border));   // one copy of the loop below, not one per kind of tile
         // The SQUARED distance n (an exact integer, same arithmetic as columnSums) is enough here: the lattice test
         // compares with a squared threshold and saves the square root, the most expensive operation of a point.
