@@ -310,13 +310,15 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
 //       blocks in front (most popular first), then a fixed pseudo-random order of the rest.
 //   motion_prefilter_kernel  a wave owns a 16-row segment of a 56 x 64 tile.  Per BATCH of up to 64 candidates (one
 //       per lane) a partial-distortion test drops every candidate whose distances at a lattice of block positions
-//       already exceed all of the segment's thresholds (one point per block, then 2 x 2 sums; see run()).  The
+//       already exceed all of the segment's thresholds (one point per block, then 2 x 2 and 4 x 4 sums, over the column
+//       band of the pixels that are not settled yet; exact-texel compares once a wave is settled; see run()).  The
 //       survivors are evaluated in full: per-position distances -> 8-row column sums (registers) -> 8-column row
 //       sums = S~ per pixel; a candidate is recorded in the pixel's list when S~ <= kRatio * (min of S~ over the
-//       candidates seen so far) (it may still be the exact minimum); at most kListK per pixel, else the tile is
+//       candidates seen so far) (it may still be the exact minimum); at most kListK / kListAux / kListDyn per pixel, else the tile is
 //       flagged and left to the exact kernel.  Work units (prefilter_plan): whole tiles; rim tiles as one
 //       workgroup per segment with its four waves on quarters of the order; segments of whole tiles that find no
-//       match are handed over through a queue to a second launch.  Easy pixels are settled in the kernel itself.
+//       match are handed over through a queue that the persistent workgroups of the SAME launch drain, in eight parts
+//       that start from the thresholds of the wave that handed them over.  Easy pixels are settled in the kernel itself.
 //   motion_resolve_kernel    per remaining pixel: the recorded candidates that pass the final bound (typically
 //       one) get the literal chain of motion.comp:33-47; the smallest (cost, rank in the tie order) wins, which
 //       is the shader's first strict minimum in scan order.
