@@ -544,13 +544,19 @@ __device__ __forceinline__ void prefilter_unit(
         const int gx = bx0 + lane;
         const bool okx = gx >= 0 && gx < W;
         const uint8_t *const column = curr + (size_t)clampi(gx, 0, W - 1) * 4u;
+        // (the rows inside the image are one run jLo .. jHi - 1, the same for every lane: a scalar mask, not 23 compares,
+        //  selects and shifts per lane -- a tenth of a unit's instructions before its first batch)
+        const int gy0 = by0 + kSeg * seg;
+        const int jLo = clampi(-gy0, 0, kSegD), jHi = clampi(H - gy0, 0, kSegD);
+        const uint32_t rowMask = jHi > jLo ? (((1u << jHi) - 1u) & ~((1u << jLo) - 1u)) : 0u;
+        valid = okx ? rowMask : 0u;
+        const uint32_t keepLane = okx ? 0xFFFFFFFFu : 0u;
 #pragma unroll
         for (int j = 0; j < kSegD; ++j) {
-            const int gy = by0 + kSeg * seg + j;
-            const bool ok = okx && gy >= 0 && gy < H;
+            const int gy = gy0 + j;
             const uint32_t t = *reinterpret_cast<const uint32_t *>(column + (size_t)clampi(gy, 0, H - 1) * (size_t)currPitch);
-            c[j] = ok ? t : 0u;
-            valid |= (ok ? 1u : 0u) << j;
+            const uint32_t keepRow = 0u - ((rowMask >> j) & 1u);        // scalar: all ones or zero
+            c[j] = t & keepLane & keepRow;
         }
     }
     // ---- search window: prev(bx0 - R + wx, by0 - R + wy), zero outside the image (texelFetch semantics); a segment
