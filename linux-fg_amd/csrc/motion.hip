@@ -725,17 +725,28 @@ __device__ __forceinline__ void prefilter_unit(
         ? list + ((size_t)(ty0 + kSeg * seg) * (size_t)kListK * (size_t)W + (size_t)tx0)
         : auxListBase + ((size_t)auxUnit * auxRows + (size_t)(kSeg * seg - auxRow0)) * (size_t)listK * (size_t)kPTW;
     uint32_t laneOff[2];
+    // (a segment whose 16 x 56 pixels all lie inside the image -- all but the last column and row of tiles -- skips the
+    //  fourteen per-pixel tests: their lane masks were kept in scalar registers, spilled, across the whole unit)
+    const int allInside = __builtin_amdgcn_readfirstlane((int)((tx0 + kPTW <= W) & (ty0 + kSeg * seg + kSeg <= H)));
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
-        const int py = ty0 + kSeg * seg + 8 * hb + r8;
         laneOff[hb] = (uint32_t)(8 * hb + r8) * (listK * rowStride) + (uint32_t)(kRun * q);   // < 16 K W
 #pragma unroll
         for (int i = 0; i < (kRun + 1) / 2; ++i) cnt2[hb][i] = 0u;
+    }
+    if (allInside) {
 #pragma unroll
-        for (int i = 0; i < kRun; ++i)    // pixels outside the image never pass the test (S~ >= 0 > -inf)
-        {
-            const float t0 = (py < H && px0 + i < W) ? __builtin_inff() : -__builtin_inff();
-            if (hb) thr2[i].y = t0; else thr2[i].x = t0;
+        for (int i = 0; i < kRun; ++i) thr2[i] = f32x2{__builtin_inff(), __builtin_inff()};
+    } else {
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            const int py = ty0 + kSeg * seg + 8 * hb + r8;
+#pragma unroll
+            for (int i = 0; i < kRun; ++i)    // pixels outside the image never pass the test (S~ >= 0 > -inf)
+            {
+                const float t0 = (py < H && px0 + i < W) ? __builtin_inff() : -__builtin_inff();
+                if (hb) thr2[i].y = t0; else thr2[i].x = t0;
+            }
         }
     }
     // some pixel of this lane has more than listK records: bit 15 of a 16-bit counter biased by 0x7FFF - listK
