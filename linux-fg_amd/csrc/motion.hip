@@ -533,6 +533,15 @@ __device__ __forceinline__ void prefilter_unit(
     //  which had tried every hint -- instead: see the push and `run` below)
     const int nHead = (chunk > 0 && !(fromQueue && LFG_QUEUE_INIT)) ? kHead : 0;
 
+    // Interior tiles: every block position the outputs use (columns 0..62) lies inside the image.
+    const int borderTile = __builtin_amdgcn_readfirstlane(
+        !((bx0 >= 0) && (bx0 + kPTW + kB - 2 < W) && (by0 >= 0) && (by0 + kPTH + kB - 2 < H)));
+    // ... and what counts for a wave is its own segment's 23 position rows: the inner segments of a tile at the top or bottom
+    // border take the interior paths (24-point lattice, lookahead, no validity masks).
+    const int segRow0 = __builtin_amdgcn_readfirstlane(by0 + kSeg * seg);
+    const int borderSeg = LFG_BORDER_PER_SEGMENT
+        ? __builtin_amdgcn_readfirstlane((int)((bx0 < 0) | (bx0 + kPTW + kB - 2 >= W) | (segRow0 < 0) | (segRow0 + kSegD - 1 >= H))) : borderTile;
+
     // ---- this thread's 23 block positions (column bx0 + lane, rows by0 + 16 seg + j).  Loaded BEFORE the window is staged
     // (their squares are taken after it): the two sets of loads are in flight together, and a unit pays one memory
     // latency before its barrier, not two.
@@ -554,9 +563,14 @@ __device__ __forceinline__ void prefilter_unit(
 #pragma unroll
         for (int j = 0; j < kSegD; ++j) {
             const int gy = gy0 + j;
-            const uint32_t t = *reinterpret_cast<const uint32_t *>(column + (size_t)clampi(gy, 0, H - 1) * (size_t)currPitch);
-            const uint32_t keepRow = 0u - ((rowMask >> j) & 1u);        // scalar: all ones or zero
-            c[j] = t & keepLane & keepRow;
+            c[j] = *reinterpret_cast<const uint32_t *>(column + (size_t)clampi(gy, 0, H - 1) * (size_t)currPitch);
+        }
+        if (borderSeg) {                   // (wave-uniform; a segment inside the image keeps every texel)
+#pragma unroll
+            for (int j = 0; j < kSegD; ++j) {
+                const uint32_t keepRow = 0u - ((rowMask >> j) & 1u);    // scalar: all ones or zero
+                c[j] = c[j] & keepLane & keepRow;
+            }
         }
     }
     // ---- search window: prev(bx0 - R + wx, by0 - R + wy), zero outside the image (texelFetch semantics); a segment
@@ -624,15 +638,6 @@ __device__ __forceinline__ void prefilter_unit(
 
 #pragma unroll
     for (int j = 0; j < kSegD; ++j) cc[j] = __builtin_amdgcn_udot4(c[j], c[j], 0x4B000000u, false);   // 2^23 + |c|^2 as float bits
-    // Interior tiles: every block position the outputs use (columns 0..62) lies inside the image.
-    const int borderTile = __builtin_amdgcn_readfirstlane(
-        !((bx0 >= 0) && (bx0 + kPTW + kB - 2 < W) && (by0 >= 0) && (by0 + kPTH + kB - 2 < H)));
-    // ... and what counts for a wave is its own segment's 23 position rows: the inner segments of a tile at the top or bottom
-    // border take the interior paths (24-point lattice, lookahead, no validity masks).
-    const int segRow0 = __builtin_amdgcn_readfirstlane(by0 + kSeg * seg);
-    const int borderSeg = LFG_BORDER_PER_SEGMENT
-        ? __builtin_amdgcn_readfirstlane((int)((bx0 < 0) | (bx0 + kPTW + kB - 2 >= W) | (segRow0 < 0) | (segRow0 + kSegD - 1 >= H))) : borderTile;
-
     // Some candidate's block can leave prev altogether only if the search window does.
     const int windowLeavesPrev = __builtin_amdgcn_readfirstlane(
         !((bx0 - kR >= 0) && (bx0 + kPTW + kB - 2 + kR < W) && (by0 - kR >= 0) && (by0 + kPTH + kB - 2 + kR < H)));
@@ -1328,11 +1333,15 @@ __device__ __forceinline__ void prefilter_unit(
                 const int gx = bx0 + pcol;
                 const bool okx = gx >= 0 && gx < W;
                 const uint8_t *const column = curr + (size_t)clampi(gx, 0, W - 1) * 4u;
+                // (the pitch through an empty asm: sharing the 23 row offsets with the loads at the unit's start keeps 46
+                //  scalars alive -- spilled -- from there to here in every unit, narrow or not)
+                int pitchN = currPitch;
+                asm volatile("" : "+s"(pitchN));
 #pragma unroll
                 for (int j = 0; j < kSegD; ++j) {
                     const int gy = by0 + kSeg * seg + j;
                     const bool ok = okx && gy >= 0 && gy < H;
-                    const uint32_t t = *reinterpret_cast<const uint32_t *>(column + (size_t)clampi(gy, 0, H - 1) * (size_t)currPitch);
+                    const uint32_t t = *reinterpret_cast<const uint32_t *>(column + (size_t)clampi(gy, 0, H - 1) * (size_t)pitchN);
                     cN[j] = ok ? t : 0u;
                     nValid |= (ok ? 1u : 0u) << j;
                 }
