@@ -892,6 +892,7 @@ __device__ __forceinline__ void prefilter_unit(
         wave_lds_sync();
     };
 
+    bool settledAtZero = false;            // set by run(): the wave's largest threshold stands for a zero cost
     auto run = [&]() -> int {              // 0: done, 1: lists overflowed (tile flagged), 2: segment handed over
 #ifdef LFG_STAMP_LATTICE4
         unsigned long long stampU[4] = {0ull, 0ull, 0ull, 0ull};
@@ -1835,6 +1836,7 @@ __device__ __forceinline__ void prefilter_unit(
             else { i0 += count; count = i0 == LFG_FIRST_BATCH ? hintsEnd - LFG_FIRST_BATCH : 64; }
         }
         if (narrow && !narrowPhase(hintsEnd)) return 1;
+        if (!narrow) settledAtZero = waveThr < 0.5f;                   // (every pixel of the wave owns a zero-cost candidate)
         return __builtin_amdgcn_readfirstlane(__ballot(listsOverflowed()) != 0ull) ? 1 : 0;
     };
     const int outcome = run();
@@ -1914,19 +1916,36 @@ __device__ __forceinline__ void prefilter_unit(
     // A segment whose pixels were all settled says so, and the resolve kernel skips the blocks it covers.
     if (whole && !windowLeavesPrev) {
         // the first two records of the pixels that have any (a zero-cost pixel has none: most of a frame under a pan)
+        const bool fastSettle = __builtin_amdgcn_readfirstlane((int)(allInside && settledAtZero)) != 0;
         Rec ra[2][kRun], rb[2][kRun];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+            for (int i = 0; i < kRun; ++i) { ra[hb][i] = 0u; rb[hb][i] = 0u; }
+        }
+        if (!fastSettle) {
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
 #pragma unroll
             for (int i = 0; i < kRun; ++i) {
                 const uint32_t cnt = (cnt2[hb][i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
-                ra[hb][i] = 0u; rb[hb][i] = 0u;
                 if (cnt >= 1u) ra[hb][i] = waveList[laneOff[hb] + (uint32_t)i];
                 if (cnt >= 2u) rb[hb][i] = waveList[rowStride + laneOff[hb] + (uint32_t)i];
             }
         }
+        }
         uint32_t best[2][kRun];
         bool allSettled = true;
+        if (fastSettle) {
+            // the common case under a pan or where nothing moves: every threshold word IS the answer (rank + 0x00800000);
+            // no records to look at, no pixel outside the image -- a dozen instructions instead of 250
+#pragma unroll
+            for (int i = 0; i < kRun; ++i) {
+                const float fx = thr2[i].x, fy = thr2[i].y;            // (named floats: see refreshZeroBound)
+                best[0][i] = __builtin_bit_cast(uint32_t, fx) - 0x00800000u;
+                best[1][i] = __builtin_bit_cast(uint32_t, fy) - 0x00800000u;
+            }
+        } else
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
             const int py = ty0 + kSeg * seg + 8 * hb + r8;
