@@ -22,6 +22,7 @@ echo "kernel stats done"
 python3 $R/bench.py > $OUT/${TAG}_pipeline_bench.json 2> /tmp/bench.err
 python3 $R/bench.py --workload scale > $OUT/${TAG}_scale_bench.json 2>> /tmp/bench.err
 python3 $R/bench.py --in-flight 1 --no-extras --no-cpu-baseline > $OUT/${TAG}_pipeline_one_lane_bench.json 2>> /tmp/bench.err   # one frame at a time
+python3 $R/bench.py --workload pipeline_input_res --no-extras --no-cpu-baseline > $OUT/${TAG}_pipeline_input_res_bench.json 2>> /tmp/bench.err   # labelled variant: motion + interpolate at input resolution, then scale
 echo "bench done"
 N=10
 for c in FETCH_SIZE WRITE_SIZE; do
