@@ -167,14 +167,25 @@ int ensure_motion_tables(lfg_context *ctx) {
 
 // ---- scratch of the prefiltered motion path (per frame size; kept between calls)
 
+// Parts of the candidate order per rim segment (motion.hip: prefilter_plan): four.  LFG_MOTION_RIM_SPLIT=8 halves the longest
+// unit of a frame under a pan -- the strip it exposes -- and with it the launch where one frame runs at a time (4K pan:
+// motion 0.49 -> 0.44 ms, 1,860 -> 2,050 frames/s; the input-resolution variant 2,370 -> 3,380), but costs every other content
+// 5 - 10 % (twice the staging and the lists for every rim segment: noisy 889 -> 843, moving objects 976 -> 919, stills
+// 3,880 -> 3,500 frames/s one frame at a time) and 9 % with three frames in flight: a knob for pan-heavy, latency-bound use.
+int motion_rim_split(const lfg_context *) {
+    if (const char *e = getenv("LFG_MOTION_RIM_SPLIT")) { const int v = atoi(e); if (v == 4 || v == 8) return v; }
+    return 4;
+}
+
 int ensure_motion_workspace(lfg_context *ctx, uint32_t width, uint32_t height) {
-    if (ctx->motion_ws && ctx->motion_ws_w == width && ctx->motion_ws_h == height) return LFG_OK;
+    const int rimSplit = motion_rim_split(ctx);
+    if (ctx->motion_ws && ctx->motion_ws_w == width && ctx->motion_ws_h == height && ctx->motion_ws_layout.rimSplit == rimSplit) return LFG_OK;
     lfg::MotionWorkspaceLayout layout;
     if (ctx->motion_slots == 0) {
         ctx->motion_slots = lfg::prefilter_slots();
         if (getenv("LFG_DEBUG")) fprintf(stderr, "lfg: motion prefilter: %d workgroups resident at once\n", ctx->motion_slots);
     }
-    const size_t bytes = lfg::motion_workspace_bytes(width, height, ctx->motion_slots, &layout);
+    const size_t bytes = lfg::motion_workspace_bytes(width, height, ctx->motion_slots, rimSplit, &layout);
     if (bytes > ctx->motion_ws_bytes) {
         LFG_HIP(ctx, hipStreamSynchronize(ctx->stream));          // a queued kernel may still use the old one
         if (ctx->motion_ws) (void)hipFree(ctx->motion_ws);
@@ -185,7 +196,7 @@ int ensure_motion_workspace(lfg_context *ctx, uint32_t width, uint32_t height) {
         LFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     // work-unit tables of this frame size: unitMap | unitAux | tileMap
-    const lfg::PrefilterPlanHost plan = lfg::prefilter_plan(width, height, ctx->motion_slots);
+    const lfg::PrefilterPlanHost plan = lfg::prefilter_plan(width, height, ctx->motion_slots, rimSplit);
     std::vector<uint32_t> tables;
     tables.insert(tables.end(), plan.unitMap.begin(), plan.unitMap.end());
     tables.insert(tables.end(), plan.unitAux.begin(), plan.unitAux.end());
@@ -646,7 +657,7 @@ LFG_EXPORT int lfg_motion_workspace_size(lfg_context *ctx, uint32_t width, uint3
     if (!out_bytes || width == 0 || height == 0 || width > 32768u || height > 32768u)
         return fail(ctx, LFG_ERR_INVALID, "lfg_motion_workspace_size: null output or a frame size outside 1..32768");
     if (ctx->motion_slots == 0) ctx->motion_slots = lfg::prefilter_slots();
-    *out_bytes = (uint64_t)lfg::motion_workspace_bytes(width, height, ctx->motion_slots, nullptr);
+    *out_bytes = (uint64_t)lfg::motion_workspace_bytes(width, height, ctx->motion_slots, motion_rim_split(ctx), nullptr);
     return LFG_OK;
 }
 
@@ -711,7 +722,7 @@ LFG_EXPORT int lfg_motion_last_stats(lfg_context *ctx, uint32_t *out_tiles, uint
         std::vector<uint32_t> cnt(px);
         LFG_HIP(ctx, hipMemcpy(cnt.data(), ctx->motion_ws + ctx->motion_ws_layout.count, px * 4, hipMemcpyDeviceToHost));
         // (tiles whose candidates were shared between several workgroups keep their counts elsewhere: left out)
-        const lfg::PrefilterPlanHost plan = lfg::prefilter_plan(ctx->motion_ws_w, ctx->motion_ws_h, ctx->motion_slots);
+        const lfg::PrefilterPlanHost plan = lfg::prefilter_plan(ctx->motion_ws_w, ctx->motion_ws_h, ctx->motion_slots, ctx->motion_ws_layout.rimSplit);
         // (a segment that settled all of its pixels in the prefilter wrote no counts: its pixels hold at most two records,
         //  counted as none here)
         std::vector<uint32_t> segDone((size_t)plan.tiles * 4u);

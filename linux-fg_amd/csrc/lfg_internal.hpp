@@ -35,7 +35,7 @@ struct AxisTable {
 };
 
 struct MotionWorkspaceLayout { size_t list, umin, count, tileFlags, segDone, segMap, queueCount, ctrl, order, plan, auxList, auxUmin, auxCount,
-                               queue, dynList, dynUmin, dynCount, dynInit, total; int queueCap, slots; };
+                               queue, dynList, dynUmin, dynCount, dynInit, total; int queueCap, slots, rimSplit; };
 // Work units of the motion prefilter (motion.hip: prefilter_plan).  A unit is a 56 x 64 tile, or one of nChunks
 // contiguous parts of a tile's candidate order, or one 16-row segment of a tile with its four waves on four parts of
 // the order; parts have private lists in the aux arrays (merged by the resolve kernel).
@@ -144,8 +144,8 @@ hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const 
 constexpr int kMotionTableWords = 1092;     // 33 * 33 candidates + the sentinel, padded to a multiple of 4
 void motion_tables(bool intended, uint32_t *rank2scan, uint32_t *order32, uint32_t *entryOfScan, uint32_t *baseScan);
 // Prefiltered motion path (motion.hip): MotionWorkspaceLayout = byte offsets of its scratch arrays.
-size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, MotionWorkspaceLayout *layout);
-PrefilterPlanHost prefilter_plan(uint32_t width, uint32_t height, int slots);
+size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, int rimSplit, MotionWorkspaceLayout *layout);
+PrefilterPlanHost prefilter_plan(uint32_t width, uint32_t height, int slots, int rimSplit);   // rimSplit: 4 or 8 parts of the order per rim segment
 int prefilter_slots();      // workgroups of the prefilter kernel the current device holds at once
 hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                           const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &layout, int units,

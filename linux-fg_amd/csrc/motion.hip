@@ -2564,7 +2564,7 @@ hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const 
     return hipGetLastError();
 }
 
-size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, MotionWorkspaceLayout *layout) {
+size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, int rimSplit, MotionWorkspaceLayout *layout) {
     const size_t px = (size_t)width * height;
     const size_t tiles = (size_t)((width + kTW - 1) / kTW) * ((height + kTH - 1) / kTH);
     auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -2589,7 +2589,7 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, Motion
     l.queue = l.ctrl + 4 * sizeof(uint32_t);
     l.order = align(l.queue + (size_t)l.queueCap * sizeof(uint32_t));           // this call's hints and visiting order
     // work-unit tables and the auxiliary arrays of the shared tiles (see prefilter_plan): one 56 x 64 block per unit
-    const PrefilterPlanHost plan = prefilter_plan(width, height, slots);
+    const PrefilterPlanHost plan = prefilter_plan(width, height, slots, rimSplit);
     const size_t auxUnits = (size_t)plan.auxUnits;
     l.plan = align(l.order + (kHints + kCand + 3) * sizeof(uint32_t));
     l.auxList = align(l.plan + (size_t)(2 * plan.units + plan.tiles) * sizeof(uint32_t));
@@ -2599,6 +2599,7 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, Motion
     const size_t dynBlocks = (size_t)l.queueCap * 4;
     l.dynList = align(l.auxCount + auxUnits * kPTH * kPTW * sizeof(uint32_t));
     l.slots = slots;
+    l.rimSplit = rimSplit;
     l.dynUmin = align(l.dynList + dynBlocks * kSeg * kPTW * kListDyn * sizeof(Rec));
     l.dynCount = align(l.dynUmin + dynBlocks * kSeg * kPTW * sizeof(float));
     l.dynInit = align(l.dynCount + dynBlocks * kSeg * kPTW * sizeof(uint32_t));
@@ -2618,12 +2619,10 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, Motion
 //     ones start at once and the short ones fill in behind them.
 //   * A frame with fewer tiles than half the slots has every tile shared by up to 8 units (contiguous parts of the
 //     candidate order, private lists), to fill the chip.
-#ifndef LFG_RIM_SPLIT
-#define LFG_RIM_SPLIT 4
-#endif
-PrefilterPlanHost prefilter_plan(uint32_t width, uint32_t height, int slots) {
-    constexpr int kRimSplit = LFG_RIM_SPLIT;          // 4 or 8 parts of the order per rim segment; 1: rim tiles whole
-    static_assert(kRimSplit == 1 || kRimSplit == 4 || kRimSplit == 8, "a segment unit's four waves take one part each");
+//   * The parts of a rim segment, 4 or 8 (rimSplit: lfg_capi.cpp, motion_rim_split -- four unless LFG_MOTION_RIM_SPLIT=8 asks;
+//     the measurements are there).
+PrefilterPlanHost prefilter_plan(uint32_t width, uint32_t height, int slots, int rimSplit) {
+    const int kRimSplit = rimSplit == 8 ? 8 : rimSplit == 1 ? 1 : 4;  // 4 or 8 parts of the order per rim segment; 1: rim tiles whole
     PrefilterPlanHost p;
     const int W = (int)width, H = (int)height;
     p.tilesX = (W + kPTW - 1) / kPTW;

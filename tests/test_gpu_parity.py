@@ -952,7 +952,7 @@ def test_mv_export_is_the_reference_rgba32f_image(ctx, oracle):
 
 def test_motion_workspace_size_and_list_depths_on_pure_noise(ctx):
     """lfg_motion_workspace_size: what the prefiltered path keeps per lane (2.2 GB at 4K with list depths 32 / 24 / 24;
-    2.5 GB with 32 everywhere), refusals; and the depths are enough where lists are longest -- a pair of independent noise
+    2.5 GB with 32 everywhere or with LFG_MOTION_RIM_SPLIT=8), refusals; and the depths are enough where lists are longest -- a pair of independent noise
     frames, every pixel without a match, every list holding its ~ln(n) running minima: no tile overflows into the literal
     kernel, and the vectors are the literal kernel's."""
     from linux_fg_amd import capi
@@ -969,6 +969,29 @@ def test_motion_workspace_size_and_list_depths_on_pure_noise(ctx):
     b, _ = run_motion_mode(ctx, prev, curr, capi.MOTION_EXACT_ONLY)
     assert (a == b).all()
     assert st[1] == 0, f"{st[1]} of {st[0]} tiles overflowed their lists"
+
+
+def test_rim_segments_in_eight_parts_agree_with_the_literal_kernel(monkeypatch):
+    """LFG_MOTION_RIM_SPLIT=8 (a knob for pan-heavy, latency-bound use: the strip a pan exposes is searched by two workgroups
+    per segment instead of one): the plan, the private lists and the resolve kernel's eight-list merge against the literal
+    kernel on a frame with rim, interior, occlusions and noise; and the workspace the query reports grows with it."""
+    from linux_fg_amd import capi
+    base = capi.Context(0)
+    try:
+        n4 = base.motion_workspace_size(1940, 1090)
+    finally:
+        base.close()
+    monkeypatch.setenv("LFG_MOTION_RIM_SPLIT", "8")
+    c8 = capi.Context(0)
+    try:
+        assert c8.motion_workspace_size(1940, 1090) > n4       # (a frame with more tiles than half the resident workgroups: rim tiles go by segment)
+        for seed in (31, 32):
+            prev, curr = _mixed_pair(1940, 1090, 9700 + seed)
+            a, _ = run_motion_mode(c8, prev, curr, capi.MOTION_PREFILTERED)
+            b, _ = run_motion_mode(c8, prev, curr, capi.MOTION_EXACT_ONLY)
+            assert (a == b).all()
+    finally:
+        c8.close()
 
 
 def test_staging_buffers_round_trip(ctx):
