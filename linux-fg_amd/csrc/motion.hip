@@ -359,6 +359,13 @@ constexpr int kWinH = kPTH + kB - 1 + 2 * kR;     // 103 rows; the window is sto
 constexpr int kSlabP = 136;                       // slab pitch of a ROW PAIR (floats): rows 2a, 2a+1 interleaved per column,
                                                   // so a thread writes two rows with one ds_write_b64; 136 keeps the
                                                   // transposed reads on 32 distinct banks
+// The one-point lattice of interior segments: block positions (kLatC0 + 8 i, kLatR0 + 8 j).  A pixel's block is the 8 x 8
+// positions that start at its own column and row, so rows 7 | 15 put exactly one lattice row into the block of each of a
+// segment's 16 pixel rows, and columns 7, 15 .. 55 one lattice column into the block of each of its 56 pixel columns:
+// 2 x 7 = 14 points.  (Rows 3 | 11 | 19 and columns 3 .. 59 did the same with 3 x 8 = 24 until late in round 2.)
+constexpr int kLatC0 = 7, kLatCols = 7, kLatR0 = 7, kLatRows = 2;
+static_assert(kLatC0 + 8 * (kLatCols - 1) == kPTW - 1 && kLatR0 + 8 * (kLatRows - 1) == kSeg - 1 && kLatC0 == kB - 1 && kLatR0 == kB - 1,
+              "one lattice point in every pixel's block: the first at the far end of pixel 0's, the last at the near end of the last pixel's");
 constexpr int kRun = 7;                           // pixels per row-sum run: 8 runs x 7 = 56
 constexpr int kRunIn = kRun + kB - 1;             // 13
 #ifndef LFG_SIXTEEN
@@ -928,7 +935,7 @@ __device__ __forceinline__ void prefilter_unit(
         // of positions that puts a point into every pixel's 8 x 8 block therefore certifies the whole wave: if the
         // candidate's distance exceeds waveThr at all of them, no pixel can pass its own (smaller) threshold and the
         // candidate is dropped after a handful of its 23 x 63 distances.
-        //   interior tiles: rows 3|11|19, columns = 3 mod 8 -- exactly one point per block, 3 x 8 in all;
+        //   interior tiles: rows 7|15, columns = 7 mod 8 -- exactly one point per block, 2 x 7 in all (kLatC0 ...);
         //   border tiles:   rows 4|8|12|16, columns = 0 mod 4 in 4..56 -- the point (4*floor(x/4), 4*floor(y/4)) of
         //                   pixel (x, y) lies in its block and inside the image whenever the pixel does, so
         //                   positions outside the image are simply left out; 4 x 14 points.
@@ -985,17 +992,17 @@ __device__ __forceinline__ void prefilter_unit(
                     }
                 }
             } else {
-                uint32_t tex[8][3];
+                uint32_t tex[kLatCols][kLatRows];
 #pragma unroll
-                for (int ci = 0; ci < 8; ++ci) {
+                for (int ci = 0; ci < kLatCols; ++ci) {
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) tex[ci][t] = w[(3 + 8 * ci) * kWinH + 3 + 8 * t];
+                    for (int t = 0; t < kLatRows; ++t) tex[ci][t] = w[(kLatC0 + 8 * ci) * kWinH + kLatR0 + 8 * t];
                 }
 #pragma unroll
-                for (int ci = 0; ci < 8; ++ci) {
+                for (int ci = 0; ci < kLatCols; ++ci) {
 #pragma unroll
-                    for (int t = 0; t < 3; ++t)
-                        acc = min(acc, tex[ci][t] ^ (uint32_t)__builtin_amdgcn_readlane((int)c[3 + 8 * t], 3 + 8 * ci));
+                    for (int t = 0; t < kLatRows; ++t)
+                        acc = min(acc, tex[ci][t] ^ (uint32_t)__builtin_amdgcn_readlane((int)c[kLatR0 + 8 * t], kLatC0 + 8 * ci));
                 }
             }
             const bool same = acc == 0u;
@@ -1050,11 +1057,11 @@ __device__ __forceinline__ void prefilter_unit(
                         }
                     }
                 } else {
-                    uint32_t tex[8][3];    // all 24 texel reads in flight at once: one LDS round trip, not 24
+                    uint32_t tex[kLatCols][kLatRows];    // all 14 texel reads in flight at once: one LDS round trip, not 14
 #pragma unroll
-                    for (int ci = 0; ci < 8; ++ci) {
+                    for (int ci = 0; ci < kLatCols; ++ci) {
 #pragma unroll
-                        for (int t = 0; t < 3; ++t) tex[ci][t] = w[(3 + 8 * ci) * kWinH + 3 + 8 * t];
+                        for (int t = 0; t < kLatRows; ++t) tex[ci][t] = w[(kLatC0 + 8 * ci) * kWinH + kLatR0 + 8 * t];
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (LFG_ZERO_COMPARE && waveThr < 0.5f) {
@@ -1064,18 +1071,18 @@ __device__ __forceinline__ void prefilter_unit(
                         // most of a frame under a pan or where nothing moves, seventeen batches per wave.
                         uint32_t acc = 0xFFFFFFFFu;                     // (smallest XOR: see the lookahead below)
 #pragma unroll
-                        for (int ci = 0; ci < 8; ++ci) {
+                        for (int ci = 0; ci < kLatCols; ++ci) {
 #pragma unroll
-                            for (int t = 0; t < 3; ++t)
-                                acc = min(acc, tex[ci][t] ^ (uint32_t)__builtin_amdgcn_readlane((int)c[3 + 8 * t], 3 + 8 * ci));
+                            for (int t = 0; t < kLatRows; ++t)
+                                acc = min(acc, tex[ci][t] ^ (uint32_t)__builtin_amdgcn_readlane((int)c[kLatR0 + 8 * t], kLatC0 + 8 * ci));
                         }
                         dMin = acc == 0u ? 0u : 0x7F800000u;
                     } else {
 #pragma unroll
-                        for (int ci = 0; ci < 8; ++ci) {
+                        for (int ci = 0; ci < kLatCols; ++ci) {
 #pragma unroll
-                            for (int t = 0; t < 3; ++t)
-                                dMin = min(dMin, bitsOf(distanceOf((uint32_t)__builtin_amdgcn_readlane((int)c[3 + 8 * t], 3 + 8 * ci), tex[ci][t])));
+                            for (int t = 0; t < kLatRows; ++t)
+                                dMin = min(dMin, bitsOf(distanceOf((uint32_t)__builtin_amdgcn_readlane((int)c[kLatR0 + 8 * t], kLatC0 + 8 * ci), tex[ci][t])));
                         }
                     }
                 }
@@ -1659,16 +1666,16 @@ __device__ __forceinline__ void prefilter_unit(
                     constexpr int kA = kAhead > 1 ? kAhead : 1;
                     uint32_t ordA[kA];
                     bool needA[kA];
-                    uint32_t tex[kA][8][3];
+                    uint32_t tex[kA][kLatCols][kLatRows];
 #pragma unroll
                     for (int a = 0; a < kA; ++a) needA[a] = candidateAt(a == 0 ? 0 : (byRank ? 64 : count) + 64 * (a - 1), ordA[a]);
 #pragma unroll
                     for (int a = 0; a < kA; ++a) {
                         const lds_ro_u32_ptr w = (lds_ro_u32_ptr)(sWin + kSeg * seg) + ((ordA[a] & 0x7FFFFFFFu) >> 16);
 #pragma unroll
-                        for (int ci = 0; ci < 8; ++ci) {
+                        for (int ci = 0; ci < kLatCols; ++ci) {
 #pragma unroll
-                            for (int t = 0; t < 3; ++t) tex[a][ci][t] = w[(3 + 8 * ci) * kWinH + 3 + 8 * t];
+                            for (int t = 0; t < kLatRows; ++t) tex[a][ci][t] = w[(kLatC0 + 8 * ci) * kWinH + kLatR0 + 8 * t];
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -1681,10 +1688,10 @@ __device__ __forceinline__ void prefilter_unit(
 #pragma unroll
                         for (int a = 0; a < kA; ++a) accA[a] = 0xFFFFFFFFu;
 #pragma unroll
-                        for (int ci = 0; ci < 8; ++ci) {
+                        for (int ci = 0; ci < kLatCols; ++ci) {
 #pragma unroll
-                            for (int t = 0; t < 3; ++t) {
-                                const uint32_t cT = (uint32_t)__builtin_amdgcn_readlane((int)c[3 + 8 * t], 3 + 8 * ci);
+                            for (int t = 0; t < kLatRows; ++t) {
+                                const uint32_t cT = (uint32_t)__builtin_amdgcn_readlane((int)c[kLatR0 + 8 * t], kLatC0 + 8 * ci);
 #pragma unroll
                                 for (int a = 0; a < kA; ++a) accA[a] = min(accA[a], tex[a][ci][t] ^ cT);
                             }
@@ -1696,10 +1703,10 @@ __device__ __forceinline__ void prefilter_unit(
 #pragma unroll
                         for (int a = 0; a < kA; ++a) dMinA[a] = 0x7F800000u;
 #pragma unroll
-                        for (int ci = 0; ci < 8; ++ci) {
+                        for (int ci = 0; ci < kLatCols; ++ci) {
 #pragma unroll
-                            for (int t = 0; t < 3; ++t) {
-                                const uint32_t cT = (uint32_t)__builtin_amdgcn_readlane((int)c[3 + 8 * t], 3 + 8 * ci);
+                            for (int t = 0; t < kLatRows; ++t) {
+                                const uint32_t cT = (uint32_t)__builtin_amdgcn_readlane((int)c[kLatR0 + 8 * t], kLatC0 + 8 * ci);
 #pragma unroll
                                 for (int a = 0; a < kA; ++a) dMinA[a] = min(dMinA[a], __builtin_bit_cast(uint32_t, distanceOf(cT, tex[a][ci][t])));
                             }
