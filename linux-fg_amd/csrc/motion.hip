@@ -1100,59 +1100,61 @@ __device__ __forceinline__ void prefilter_unit(
             //  a full batch came out of it three quarters intact: segments that search in full anyway stop paying for it)
             if (useFourPoint && !(waveThr < kOnePointMax) && waveThr < LFG_FOURPOINT_MAX && __builtin_popcountll(__ballot(need)) > 8) {
                 // FOUR-point test, for thresholds a single distance rarely exceeds (a match under sensor noise costs a
-                // few hundred).  Block positions = 0 mod 4 form a lattice of 6 x 16 points of which every pixel's
-                // 8 x 8 block holds exactly a 2 x 2 group (columns 4a, 4a + 4 with a = ceil(i / 4) for pixel column
-                // i, rows likewise), and S~ >= (the sum of those four distances) (1 - 8.1 u): S~ adds the same
-                // rounded distances in a depth-6 tree (factor (1-u)^6 at worst), the group sum in two levels
-                // ((1+u)^2 at most).  If every group's sum exceeds waveThr (1 + 2^-19), no pixel passes.
-                // Positions outside the image add nothing to S~ and nothing here; groups that no pixel inside the
-                // image maps to are left out.  Walks the lattice column by column: six distances, five vertical
-                // pair sums, five group sums with the previous column's.
-                lds_ro_u32_ptr w = (lds_ro_u32_ptr)(sWin + kSeg * seg) + (ordL >> 16);
+                // few hundred).  Block positions = 3 mod 4 form a lattice of 5 x 15 points of which every pixel's
+                // 8 x 8 block holds exactly a 2 x 2 group (columns 3 + 4 g, 7 + 4 g with g = i / 4 for pixel column i,
+                // rows likewise: the block starts at the pixel's own position), and S~ >= (the sum of those four
+                // distances) (1 - 8.1 u): S~ adds the same rounded distances in a depth-6 tree (factor (1-u)^6 at
+                // worst), the group sum in two levels ((1+u)^2 at most).  If every group's sum exceeds
+                // waveThr (1 + 2^-19), no pixel passes.  Positions outside the image add nothing to S~ and nothing
+                // here; groups that no pixel inside the image maps to are left out.  Walks the lattice column by
+                // column: five distances, four vertical pair sums, four group sums with the previous column's.
+                // (Positions = 0 mod 4 did the same with 6 x 16 points until late in round 2.)
+                lds_ro_u32_ptr w = (lds_ro_u32_ptr)(sWin + kSeg * seg) + (ordL >> 16) + (3 * kWinH + 3);
                 auto bitsOf = [](float d) { return __builtin_bit_cast(uint32_t, d); };
                 uint32_t pMin = 0x7F800000u;
-                float vPrev[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                float vPrev[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                 int tx0L = tx0, rowsL = ty0 + kSeg * seg;
                 asm volatile("" : "+s"(tx0L), "+s"(rowsL));
-                uint32_t rowRelevant = 0u;                              // bit b: some pixel row inside the image maps to vertical group b
+                uint32_t rowRelevant = 0u;                              // bit h: some pixel row inside the image maps to vertical group h (rows 4 h .. 4 h + 3)
 #pragma unroll
-                for (int b = 0; b < 5; ++b) rowRelevant |= (!border || rowsL + max(0, 4 * b - 3) < H) ? (1u << b) : 0u;
-                // (a rolled loop, two columns per trip: sixteen unrolled columns were 2,000 instructions and 7 % slower where
-                //  this test dominates -- not for instruction-cache misses, SQC_ICACHE_MISSES stays at 0.01 %)
-                const int gLo = (bandLo + 3) >> 2, gHi = (bandHi + 3) >> 2;   // groups ceil(i / 4) of the band's pixel columns i
+                for (int h = 0; h < 4; ++h) rowRelevant |= (!border || rowsL + 4 * h < H) ? (1u << h) : 0u;
+                // (a rolled loop, three columns per trip -- fifteen columns: two per trip leave a remainder whose extra copy cost
+                //  11 spilled VGPRs; all of them unrolled were 2,000 instructions and 7 % slower where this test dominates, not
+                //  for instruction-cache misses, SQC_ICACHE_MISSES stays at 0.01 %)
+                const int gLo = bandLo >> 2, gHi = bandHi >> 2;         // groups i / 4 of the band's pixel columns i
                 const bool restricted = LFG_BAND && (bandLo > 0 || bandHi < kPTW - 1);
                 // (two copies of the walk, with and without the band's bounds: the bounds' tests in the one walk cost the
                 //  segments whose band is the whole width -- noise everywhere -- 6 %)
                 auto walk = [&](auto banded) {
                 constexpr bool kBanded = decltype(banded)::value;
-#pragma unroll 2
-                for (int a = 0; a < 16; ++a, w += 4 * kWinH) {
+#pragma unroll 3
+                for (int a = 0; a < kPTW / 4 + 1; ++a, w += 4 * kWinH) {   // lattice column 3 + 4 a closes group a - 1
                     if (kBanded && (a < gLo || a > gHi + 1)) continue;  // (wave-uniform)
                     // (the lane select goes through an empty asm: the current-frame texels are the same in every batch,
-                    //  and hoisted out of the batch loop their 96 scalar registers are spilled)
-                    int colL = 4 * a;
+                    //  and hoisted out of the batch loop their scalar registers are spilled)
+                    int colL = 3 + 4 * a;
                     asm volatile("" : "+s"(colL));
-                    uint32_t tex[6];
+                    uint32_t tex[5];
 #pragma unroll
-                    for (int b = 0; b < 6; ++b) tex[b] = w[4 * b];
+                    for (int b = 0; b < 5; ++b) tex[b] = w[4 * b];
                     const uint32_t inImage = border ? (uint32_t)__builtin_amdgcn_readlane((int)valid, colL) : 0xFFFFFFFFu;
-                    float d[6];
-#pragma unroll
-                    for (int b = 0; b < 6; ++b) {
-                        const float dd = __builtin_amdgcn_sqrtf(distanceOf((uint32_t)__builtin_amdgcn_readlane((int)c[4 * b], colL), tex[b]));
-                        const uint32_t keep = 0u - ((inImage >> (4 * b)) & 1u);        // scalar: all ones or zero
-                        d[b] = border ? __builtin_bit_cast(float, bitsOf(dd) & keep) : dd;
-                    }
-                    float v[5];
-#pragma unroll
-                    for (int b = 0; b < 5; ++b) v[b] = d[b] + d[b + 1];
-                    // group (a - 1, b): its first pixel is (max(0, 4 (a-1) - 3), max(0, 4 b - 3))
-                    const bool colRelevant = a > (kBanded ? gLo : 0) && (!border || tx0L + max(0, 4 * (a - 1) - 3) < W);
+                    float d[5];
 #pragma unroll
                     for (int b = 0; b < 5; ++b) {
-                        const uint32_t g = bitsOf(vPrev[b] + v[b]);
-                        pMin = min(pMin, (colRelevant && ((rowRelevant >> b) & 1u)) ? g : 0x7F800000u);
-                        vPrev[b] = v[b];
+                        const float dd = __builtin_amdgcn_sqrtf(distanceOf((uint32_t)__builtin_amdgcn_readlane((int)c[3 + 4 * b], colL), tex[b]));
+                        const uint32_t keep = 0u - ((inImage >> (3 + 4 * b)) & 1u);    // scalar: all ones or zero
+                        d[b] = border ? __builtin_bit_cast(float, bitsOf(dd) & keep) : dd;
+                    }
+                    float v[4];
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) v[h] = d[h] + d[h + 1];
+                    // group (a - 1, h): its pixels are columns 4 (a - 1) .. + 3, rows 4 h .. + 3
+                    const bool colRelevant = a > (kBanded ? gLo : 0) && (!border || tx0L + 4 * (a - 1) < W);
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        const uint32_t g = bitsOf(vPrev[h] + v[h]);
+                        pMin = min(pMin, (colRelevant && ((rowRelevant >> h) & 1u)) ? g : 0x7F800000u);
+                        vPrev[h] = v[h];
                     }
                 }
                 };
