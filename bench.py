@@ -552,7 +552,7 @@ def main():
                            "pixel.  work_disposed_tflops = the shader's algorithmic flops (W*H*1089*(64 adds + 12 per distance)) / "
                            "the duration of the lfg_motion call: the rate at which that work is DISPOSED OF, not executed -- an exact "
                            "bracket on the cost rules out all but ~1 candidate per pixel and a partial-distortion test drops most "
-                           "candidates of a segment after 24 of their 1449 distances (DESIGN.md, motion) -- so it may exceed the "
+                           "candidates of a segment after 14 of their 1449 distances (DESIGN.md, motion) -- so it may exceed the "
                            "157.3 TFLOP/s fp32 peak and is NOT a utilisation; `executed` (when a counter profile of this very "
                            "library is committed) is.  LFG_MOTION_MODE=1 runs the literal kernel alone.")}
             if not exact_only and args.input == "1080p" and not in_res:

@@ -544,7 +544,7 @@ __device__ __forceinline__ void prefilter_unit(
     const int borderTile = __builtin_amdgcn_readfirstlane(
         !((bx0 >= 0) && (bx0 + kPTW + kB - 2 < W) && (by0 >= 0) && (by0 + kPTH + kB - 2 < H)));
     // ... and what counts for a wave is its own segment's 23 position rows: the inner segments of a tile at the top or bottom
-    // border take the interior paths (24-point lattice, lookahead, no validity masks).
+    // border take the interior paths (14-point lattice, lookahead, no validity masks).
     const int segRow0 = __builtin_amdgcn_readfirstlane(by0 + kSeg * seg);
     const int borderSeg = LFG_BORDER_PER_SEGMENT
         ? __builtin_amdgcn_readfirstlane((int)((bx0 < 0) | (bx0 + kPTW + kB - 2 >= W) | (segRow0 < 0) | (segRow0 + kSegD - 1 >= H))) : borderTile;
