@@ -56,5 +56,8 @@ path = os.path.join(ROOT, "README.md")
 r = open(path).read()
 r = re.sub(r"\*\*≈[\d,]+ interpolated frames/s\*\*", f"**≈{round(d['value'], -1):,.0f} interpolated frames/s**", r)
 r = re.sub(r"[\d,]+ strictly one frame at a time", f"{d1['value']:,.0f} strictly one frame at a time", r)
+lo = min(sw[k][0] for k in ("occluded", "objects", "noisy"))
+hi = max(sw[k][0] for k in ("occluded", "objects", "noisy"))
+r = re.sub(r"[\d,]+–[\d,]+ with occlusions, moving objects or sensor noise added", f"{round(lo, -1):,.0f}–{round(hi, -1):,.0f} with occlusions, moving objects or sensor noise added", r)
 open(path, "w").write(r)
 print(f"DESIGN.md / README.md: {d['value']:.0f} frames/s, one frame at a time {d1['value']:.0f}, library {d.get('library_sha16')}")
