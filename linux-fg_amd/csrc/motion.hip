@@ -1258,7 +1258,8 @@ __device__ __forceinline__ void prefilter_unit(
             const lds_ro_u32_ptr wb = (lds_ro_u32_ptr)(sWin + kSeg * seg);
             const uint32_t ref = wb[0];
             const int colA = lane, colB = lane + (kWinW - 64);         // 0..63 and 31..94: all 95 window columns
-            bool flat = true;
+            // (one row first: textured content -- nearly every segment -- leaves after two reads, not twenty-two)
+            bool flat = __builtin_amdgcn_readfirstlane(__ballot(wb[colA * kWinH] != ref || wb[colB * kWinH] != ref) == 0ull);
             constexpr int kRows = kSegD + 2 * kR;                      // 55 window rows serve this segment
             for (int r0 = 0; r0 < kRows && flat; r0 += kRows / 5) {
                 // (all 22 reads of a chunk in flight, then one OR of XORs: `&&` made each read wait for the one before)
