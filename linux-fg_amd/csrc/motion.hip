@@ -601,12 +601,17 @@ __device__ __forceinline__ void prefilter_unit(
         const int stageInside = __builtin_amdgcn_readfirstlane((int)((bx0 - kR >= 0) & (bx0 - kR + 4 * kGroups <= W) &
                                                                       (by0 - kR + stageRow0 >= 0) & (by0 - kR + stageRow0 + stageRows <= H)));
         if (stageInside) {
+            // (row and group of round k from those of round k - 1: 256 threads are ten rows of 24 groups and 16 groups more --
+            //  one division per unit instead of ten)
+            static_assert(kPNT == 10 * kGroups + 16, "a round advances a thread by ten rows and sixteen groups");
+            int wyK = tidL / kGroups, gK = tidL - wyK * kGroups;
 #pragma unroll
             for (int k = 0; k < kRounds; ++k) {
-                const int i = k * kPNT + tidL;
-                const int wy = min(stageRow0 + i / kGroups, stageRow0 + stageRows - 1), g = i % kGroups;   // (the last round's spare threads re-read the last row)
-                const int gx = bx0 - kR + 4 * g, gy = by0 - kR + wy;
+                const int wy = min(stageRow0 + wyK, stageRow0 + stageRows - 1);   // (the last round's spare threads re-read the last row)
+                const int gx = bx0 - kR + 4 * gK, gy = by0 - kR + wy;
                 v[k] = *reinterpret_cast<const uint4 *>(prev + (size_t)gy * (size_t)prevPitch + (size_t)gx * 4u);
+                gK += 16; wyK += 10;
+                if (gK >= kGroups) { gK -= kGroups; wyK += 1; }
             }
         } else {
 #pragma unroll
@@ -624,11 +629,14 @@ __device__ __forceinline__ void prefilter_unit(
         }
         }
         asm volatile("" : "+v"(tidL));
+        int wyS = tidL / kGroups, gS = tidL - wyS * kGroups;
 #pragma unroll
         for (int k = 0; k < kRounds; ++k) {
-            const int i = k * kPNT + tidL;
-            const int wy = stageRow0 + i / kGroups, g = i % kGroups;
-            if (i < stageRows * kGroups) {
+            const int wy = stageRow0 + wyS, g = gS;
+            const bool staged = wyS < stageRows;                       // (i < stageRows * kGroups)
+            gS += 16; wyS += 10;
+            if (gS >= kGroups) { gS -= kGroups; wyS += 1; }
+            if (staged) {
                 uint32_t *dst = sWin + (4 * g) * kWinH + wy;
                 dst[0] = v[k].x; dst[kWinH] = v[k].y; dst[2 * kWinH] = v[k].z;
                 if (4 * g + 3 < kWinW) dst[3 * kWinH] = v[k].w;
