@@ -167,14 +167,19 @@ int ensure_motion_tables(lfg_context *ctx) {
 
 // ---- scratch of the prefiltered motion path (per frame size; kept between calls)
 
-// Parts of the candidate order per rim segment (motion.hip: prefilter_plan): four.  LFG_MOTION_RIM_SPLIT=8 halves the longest
-// unit of a frame under a pan -- the strip it exposes -- and with it the launch where one frame runs at a time (4K pan:
-// motion 0.49 -> 0.44 ms, 1,860 -> 2,050 frames/s; the input-resolution variant 2,370 -> 3,380), but costs every other content
-// 5 - 10 % (twice the staging and the lists for every rim segment: noisy 889 -> 843, moving objects 976 -> 919, stills
-// 3,880 -> 3,500 frames/s one frame at a time) and 9 % with three frames in flight: a knob for pan-heavy, latency-bound use.
-int motion_rim_split(const lfg_context *) {
-    if (const char *e = getenv("LFG_MOTION_RIM_SPLIT")) { const int v = atoi(e); if (v == 4 || v == 8) return v; }
-    return 4;
+// Parts of the candidate order per rim segment (motion.hip: prefilter_plan), measured at 4K (frames/s):
+//   4   the default with frames in flight (lfg_lanes >= 2), where the sum of all units' times is what counts: pan 2,838;
+//   48  four, and eight for the segments whose position rows leave the image at its top or bottom -- the strip a vertical pan
+//       exposes is the longest unit of a frame, and the launch is as long as its longest unit when ONE frame runs at a time:
+//       the default there.  One frame at a time: pan 1,868 -> 2,307 (motion 0.49 -> 0.38 ms), noisy 889 -> 981, stills
+//       3,880 -> 3,976, occluded 815 -> 810, moving objects 976 -> 971; with three frames in flight it costs 1 - 2 %
+//       (134 more workgroups that stage a window each), which is why it is not used there;
+//   8   every rim segment in eight parts: one frame at a time the pan gains less (2,050) and everything else loses 5 - 10 %;
+//       9 % slower with three frames in flight.
+// LFG_MOTION_RIM_SPLIT=4|8|48 overrides.
+int motion_rim_split(const lfg_context *ctx) {
+    if (const char *e = getenv("LFG_MOTION_RIM_SPLIT")) { const int v = atoi(e); if (v == 4 || v == 8 || v == 48) return v; }
+    return ctx->lanes.size() >= 2 ? 4 : 48;
 }
 
 int ensure_motion_workspace(lfg_context *ctx, uint32_t width, uint32_t height) {

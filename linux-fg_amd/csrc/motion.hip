@@ -2340,7 +2340,9 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
     // of a segment's 16 rows for a segment handed over at run time.  Record k of list c: recs[c * listStride + k * recStride].
     const bool handedOver = tm == 0xFFFFFFFFu && sm != 0u;
     const bool whole = tm == 0xFFFFFFFFu && sm == 0u;
-    const int nLists = whole ? 1 : (int)(((handedOver ? sm : tm) >> 24) & 0xFu);
+    // (a tile of the plan: its parts, twice as many for the segments marked in the top four bits)
+    const int nLists = whole ? 1 : handedOver ? (int)((sm >> 24) & 0xFu)
+                                              : (int)((tm >> 24) & 0xFu) << ((tm >> (28 + (cpy % kPTH) / kSeg)) & 1u);
     const Rec *recs;
     const float *thrs;
     const uint32_t *cnts;
@@ -2640,7 +2642,11 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, int ri
 //   * The parts of a rim segment, 4 or 8 (rimSplit: lfg_capi.cpp, motion_rim_split -- four unless LFG_MOTION_RIM_SPLIT=8 asks;
 //     the measurements are there).
 PrefilterPlanHost prefilter_plan(uint32_t width, uint32_t height, int slots, int rimSplit) {
-    const int kRimSplit = rimSplit == 8 ? 8 : rimSplit == 1 ? 1 : 4;  // 4 or 8 parts of the order per rim segment; 1: rim tiles whole
+    // 4 or 8 parts of the order per rim segment; 1: rim tiles whole; 48: four, and eight for the segments whose position rows
+    // leave the image at its top or bottom -- the strip a vertical pan exposes is searched in full there, the longest units
+    // of a frame, and two workgroups halve them without doubling every other rim segment
+    const int kRimSplit = rimSplit == 8 ? 8 : rimSplit == 1 ? 1 : 4;
+    const bool rowBorderEight = rimSplit == 48;
     PrefilterPlanHost p;
     const int W = (int)width, H = (int)height;
     p.tilesX = (W + kPTW - 1) / kPTW;
@@ -2658,12 +2664,21 @@ PrefilterPlanHost prefilter_plan(uint32_t width, uint32_t height, int slots, int
             const int n = bySegment ? kRimSplit : everywhere;
             if (n == 1) { p.unitMap.push_back((uint32_t)t | (1u << 24)); p.unitAux.push_back(0xFFFFFFFFu); continue; }
             const uint32_t aux0 = (uint32_t)p.auxUnits;
-            p.tileMap[(size_t)t] = aux0 | ((uint32_t)n << 24);
-            p.auxUnits += n;
+            // (tileMap: first private block | parts << 24 | mask of the segments that have twice as many << 28)
+            uint32_t doubled = 0u;
+            if (bySegment && rowBorderEight && n == 4) {
+                for (int seg = 0; seg < kPTH / kSeg && ty * kPTH + seg * kSeg < H; ++seg) {
+                    const int r0 = by0 + kSeg * seg;
+                    if (r0 < 0 || r0 + kSegD - 1 >= H) doubled |= 1u << seg;
+                }
+            }
+            p.tileMap[(size_t)t] = aux0 | ((uint32_t)n << 24) | (doubled << 28);
+            p.auxUnits += doubled ? 2 * n : n;
             if (bySegment) {
                 for (int seg = 0; seg < kPTH / kSeg && ty * kPTH + seg * kSeg < H; ++seg) {
-                    for (int c0 = 0; c0 < n; c0 += 4) {
-                        p.unitMap.push_back((uint32_t)t | ((uint32_t)c0 << 20) | ((uint32_t)n << 24) | (1u << 28) | ((uint32_t)seg << 29));
+                    const int nSeg = ((doubled >> seg) & 1u) ? 2 * n : n;
+                    for (int c0 = 0; c0 < nSeg; c0 += 4) {
+                        p.unitMap.push_back((uint32_t)t | ((uint32_t)c0 << 20) | ((uint32_t)nSeg << 24) | (1u << 28) | ((uint32_t)seg << 29));
                         p.unitAux.push_back(aux0);
                     }
                 }

@@ -951,13 +951,20 @@ def test_mv_export_is_the_reference_rgba32f_image(ctx, oracle):
 
 
 def test_motion_workspace_size_and_list_depths_on_pure_noise(ctx):
-    """lfg_motion_workspace_size: what the prefiltered path keeps per lane (2.2 GB at 4K with list depths 32 / 24 / 24;
-    2.5 GB with 32 everywhere or with LFG_MOTION_RIM_SPLIT=8), refusals; and the depths are enough where lists are longest -- a pair of independent noise
+    """lfg_motion_workspace_size: what the prefiltered path keeps per lane (at 4K 2.2 GB with frames in flight, 2.4 GB for a
+    context that runs one frame at a time and searches the top and bottom strips in eight parts; list depths 32 / 24 / 24),
+    refusals; and the depths are enough where lists are longest -- a pair of independent noise
     frames, every pixel without a match, every list holding its ~ln(n) running minima: no tile overflows into the literal
     kernel, and the vectors are the literal kernel's."""
     from linux_fg_amd import capi
     n4k = ctx.motion_workspace_size(3840, 2160)
-    assert 0.5e9 < n4k < 2.3e9
+    assert 0.5e9 < n4k < 2.5e9
+    other = capi.Context(0)
+    try:
+        other.lanes(2)
+        assert other.motion_workspace_size(3840, 2160) < min(n4k, 2.3e9)       # every rim segment in four parts
+    finally:
+        other.close()
     assert ctx.motion_workspace_size(1920, 1080) < n4k
     for bad in ((0, 16), (16, 0), (40000, 16)):
         with pytest.raises(capi.LfgError):
