@@ -201,7 +201,7 @@ def pmc_executed(prefix="lfg::motion_"):
     if us <= 0:
         return None
     slots = us * 1e-6 * 2.4e9 * 1024
-    return {"source": src, "kernels": prefix + "*", "kernel_us_per_step_in_that_pass": round(us, 2),
+    return {"source": src, "kernels": prefix + ("*" if prefix.endswith("_") else ""), "kernel_us_per_step_in_that_pass": round(us, 2),
             "valu_wave_instructions": valu, "lds_wave_instructions": lds, "salu_wave_instructions": salu,
             "valu_issue_utilisation": round(valu * 4.0 / slots, 3),
             "how": "VALU wave-instructions x 4 cycles / (kernel time x 2.4 GHz x 1024 SIMDs): the share of the VALU issue "
@@ -260,8 +260,114 @@ def cpu_baseline(w_in, h_in, w, h, factors, workload):
                        f"{t_scale:.3f}/{t_motion:.1f}/{t_interp:.3f}")}
 
 
+def visible_devices() -> int:
+    """HIP devices the library sees (lfg_device_count), asked in a CHILD process: the process that starts the ranks must
+    never initialise the GPU itself."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); from linux_fg_amd import capi; print(capi.load().lfg_device_count())" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    if out.returncode != 0:
+        raise SystemExit("bench.py: cannot count the HIP devices: " + out.stderr.strip()[-400:])
+    return int(out.stdout.strip().splitlines()[-1])
+
+
+def launch_command(n: int, argv, port: int):
+    """`python bench.py --gpus N ...` started by hand (or by a driver that does not wrap it): the command that runs the same
+    arguments as N ranks, one per GPU, on this node."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(args, argv) -> int:
+    """--gpus N > 1 without a launcher around us: start N ranks as a fresh child (torch.distributed.run), pass its output
+    through and return its exit code.  This process never touches the GPU and never exec()s."""
+    import subprocess
+    share_gpu = os.environ.get("LFG_BENCH_SHARE_GPU") == "1"          # (rehearsal: several ranks on one card, no RCCL)
+    if not share_gpu:
+        have = visible_devices()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} needs {args.gpus} HIP devices, found {have} (lfg_device_count); "
+                  "one rank per GPU, RCCL wants a device per rank", file=sys.stderr, flush=True)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(launch_command(args.gpus, argv, free_port()), env=env).returncode
+
+
+def measure_config5(torch, capi, dev, dev_index, n_lanes, steps=24):
+    """BASELINE config 5 on this GPU, short: 4K -> 8K, t = 1/4, 1/2, 3/4 (three generated 8K frames per pair: scale, motion ONCE,
+    one pass of lfg_interpolate_multi), the benchmark's pan.  A context of its own; frames in flight as the headline run."""
+    w_in, h_in = SIZES["4k"]
+    w, h = 2 * w_in, 2 * h_in
+    factors = [0.25, 0.5, 0.75]
+    prev_in, curr_in = make_content("translated", w_in, h_in, 0, 0)
+    ctx = capi.Context(dev_index)
+    if n_lanes > 1:
+        ctx.lanes(n_lanes)
+    def frame(width, height, fmt=capi.FORMAT_RGBA8):
+        t = torch.empty((height, width, 4 if fmt == capi.FORMAT_RGBA8 else 2), dtype=torch.uint8, device=dev)
+        return t, capi.Context.wrap(t.data_ptr(), width, height, fmt)
+    t_pin = torch.from_numpy(prev_in).to(dev); f_pin = capi.Context.wrap(t_pin.data_ptr(), w_in, h_in, capi.FORMAT_RGBA8)
+    t_cin = torch.from_numpy(curr_in).to(dev); f_cin = capi.Context.wrap(t_cin.data_ptr(), w_in, h_in, capi.FORMAT_RGBA8)
+    t_p8, f_p8 = frame(w, h)
+    lanes = [(frame(w, h), frame(w, h, capi.FORMAT_MV_S8X2), [frame(w, h) for _ in factors]) for _ in range(n_lanes)]
+    ctx.scale(f_pin, f_p8)
+    ctx.sync()
+    def step(k, n):
+        j = k % n
+        (tc, fc), (tm, fm), outs = lanes[j]
+        if n > 1:
+            ctx.lane_select(j)
+            ctx.lane_wait((k - 1) % n)
+        ctx.scale(f_cin, fc)
+        if n > 1:
+            ctx.lane_mark()
+        ctx.motion(f_p8, fc, fm, 8, 16.0)
+        ctx.interpolate_multi(f_p8, fc, fm, [f for _, f in outs], factors)
+    def timed(n_steps, n):
+        ctx.sync(); torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for k in range(n_steps):
+            step(k, n)
+        ctx.sync(); torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0
+    timed(2 * n_lanes, n_lanes)
+    t = timed(steps, n_lanes)
+    if n_lanes > 1:
+        ctx.lane_select(0)
+    ctx.profile_reset(); ctx.profile_enable(True)
+    timed(max(4, steps // 3), 1)
+    per = {}
+    for name, sid in (("scale", capi.STAGE_SCALE), ("motion", capi.STAGE_MOTION), ("interpolate", capi.STAGE_INTERPOLATE)):
+        ms, n = ctx.profile_get(sid)
+        per[name] = round(ms / max(n, 1), 4)
+    ctx.profile_enable(False)
+    st = ctx.motion_last_stats()
+    ws = ctx.motion_workspace_size(w, h)
+    rim, groups = ctx.motion_plan()
+    algo = algorithmic_bytes("scale", w_in, h_in, w, h) + algorithmic_bytes("motion", w_in, h_in, w, h) + \
+        algorithmic_bytes("interpolate", w_in, h_in, w, h) + 4 * w * h * (len(factors) - 1)
+    out = {"workload": "BASELINE config 5 on one GPU: 4K->8K, scale + motion(8,16) once + interpolate at t = 0.25, 0.5, 0.75 (one pass)",
+           "steps": steps, "frames_in_flight": n_lanes, "pairs_per_s": round(steps / t, 2),
+           "interpolated_frames_per_s": round(steps * len(factors) / t, 1), "ms_per_pair": round(t / steps * 1e3, 4),
+           "stage_ms_one_call_at_a_time": per, "motion_workspace_bytes_per_lane": ws, "motion_plan_rim_split": rim,
+           "prefilter_workgroups": groups, "fallback_tiles": st[1], "algorithmic_bytes_per_pair": algo,
+           "hbm_frac": round(algo * steps / t / 1e9 / HBM_PEAK_GBS, 5)}
+    ctx.close()
+    return out
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
     import torch
     import torch.distributed as dist
 
@@ -269,9 +375,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-        args.gpus = world
+        args.gpus = world                  # (launched by torch.distributed.run: its world size is the number of GPUs)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # One rank per GPU.  torch.distributed (gloo, CPU tensors) is the CONTROL plane only: it carries the 128-byte
@@ -280,6 +384,10 @@ def main():
     # (rehearsal only) lets several ranks share one card with torch carrying the frame too: RCCL itself needs one
     # device per rank.
     share_gpu = os.environ.get("LFG_BENCH_SHARE_GPU") == "1"
+    from linux_fg_amd import capi as _capi
+    n_dev = _capi.load().lfg_device_count()
+    if world > 1 and not share_gpu and n_dev < world:
+        raise SystemExit(f"bench.py: --gpus {world} needs {world} HIP devices, found {n_dev} (lfg_device_count): one rank per GPU")
     dev_index = local_rank % torch.cuda.device_count() if share_gpu else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -415,12 +523,29 @@ def main():
         step(k)
     ctx.profile_reset()
     ctx.profile_enable(args.workload != "scale" and n_lanes == 1)     # events around every stage launch (ms-scale kernels)
-    barrier_sync()
-    t0 = time.perf_counter()
-    for k in range(warmup, warmup + steps):
-        step(k)
-    barrier_sync()
-    elapsed = time.perf_counter() - t0
+
+    def timed_region(first):
+        """EXACTLY `steps` steps between two barrier + device-synchronisation pairs; seconds, max over ranks."""
+        barrier_sync()
+        t0 = time.perf_counter()
+        for k in range(first, first + steps):
+            step(k)
+        barrier_sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    # A short region (the driver asks for 20 steps: 7 ms) is mostly ramp-up of the frames in flight and timer noise, so it is
+    # REPEATED -- every region is exactly `steps` steps between its own barriers -- until a quarter of a second has been
+    # timed (25 regions at most) and the MEDIAN region gives `value`; `repeats` reports the spread and the first region.
+    regions = [timed_region(warmup)]
+    n_regions = 1 if regions[0] >= 0.25 else int(min(25, max(3, np.ceil(0.25 / max(regions[0], 1e-6)))))
+    for r in range(1, n_regions):
+        regions.append(timed_region(warmup + r * steps))
+    elapsed = float(np.median(regions))
     shared_prev.drain()
     torch.cuda.synchronize(dev)
 
@@ -443,6 +568,14 @@ def main():
     exact_only = os.environ.get("LFG_MOTION_MODE", "0") == "1"
     if args.workload != "scale" and not exact_only:
         motion_stats = ctx.motion_last_stats()        # after the timed region: it synchronises and copies counters
+    rim_split, prefilter_groups = ctx.motion_plan()
+    stage_pass = {"plan_rim_split": rim_split, "prefilter_workgroups": prefilter_groups, "lanes_of_the_context": n_lanes,
+                  "how": ("events around every stage call inside the timed regions (one frame at a time: nothing overlaps)" if n_lanes == 1 and args.workload != "scale" else
+                          "a second pass, one call at a time on lane 0 of the SAME context as the timed regions, event-bracketed: the same "
+                          f"work-unit plan (rim segments in {'4 parts' if rim_split == 4 else '4 parts, 8 at the top and bottom border' if rim_split == 48 else '8 parts'}) "
+                          "as the step that `value` times, where the stages of neighbouring steps overlap and an event pair would time both; a context that runs "
+                          "one frame at a time (--in-flight 1) plans for the longest unit instead (rim split 48) and its motion call is shorter: "
+                          "profiles/r03_pipeline_one_lane_bench.json")}
     stage_ms = {}
     for name, sid in (("scale", capi.STAGE_SCALE), ("motion", capi.STAGE_MOTION), ("interpolate", capi.STAGE_INTERPOLATE)):
         ms, n = ctx.profile_get(sid)
@@ -450,10 +583,14 @@ def main():
             stage_ms[name] = ms / n
     ctx.profile_enable(False)
 
+    # what RCCL saw, and which card every rank drove (the driver checks its N against these)
+    rccl_ranks = ctx.comm_ranks()
+    devices = [dev_index]
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (dev_index, rccl_ranks, ctx.comm_rank()))
+        devices = [g[0] for g in gathered]
+        rccl_ranks = min(g[1] for g in gathered)                  # (every rank must report the same communicator size)
 
     units_per_step = 1 if args.workload == "scale" else len(factors)
     in_res = args.workload == "pipeline_input_res"
@@ -480,6 +617,53 @@ def main():
                                        "us_per_step": round(t_si / n2 * 1e6, 3), "algorithmic_bytes": b_scale + b_interp,
                                        "hbm_gbs": round((b_scale + b_interp) * n2 / t_si / 1e9, 1),
                                        "hbm_frac": round((b_scale + b_interp) * n2 / t_si / 1e9 / HBM_PEAK_GBS, 4)}
+        # ---- the same two configurations on TWO lanes of a second context (launch k + 1's dispatch and first-row wait overlap
+        # launch k's tail: a throughput figure, labelled) and cache-COLD (every buffer of a step was last touched more than a
+        # gigabyte of traffic ago, far beyond the 256 MiB Infinity Cache -- except the upscaled frame interpolate reads, which
+        # the step's own scale has just written: that locality is the pipeline's, not the benchmark's)
+        ctx2 = capi.Context(dev_index)
+        ctx2.lanes(2)
+        two = [empty_frame(w, h) for _ in range(2)]
+        def scale_two(k):
+            ctx2.lane_select(k & 1)
+            ctx2.scale(f_curr_in, two[k & 1][1])
+        timed(scale_two, 200)
+        t_s2 = timed(scale_two, n2)
+        extras["scale_only"]["two_lanes"] = {"frames_per_s": round(n2 / t_s2, 1), "us_per_step": round(t_s2 / n2 * 1e6, 3),
+                                             "hbm_frac": round(b_scale * n2 / t_s2 / 1e9 / HBM_PEAK_GBS, 4),
+                                             "how": "independent frames alternate between two streams of one context (lfg_lanes 2): throughput of "
+                                                    "overlapping launches, not the duration of one"}
+        n_sets = 12
+        sets = []
+        for i in range(n_sets):
+            tin = t_curr_in.clone()
+            sets.append((tin, capi.Context.wrap(tin.data_ptr(), w_in, h_in, capi.FORMAT_RGBA8), empty_frame(w, h), empty_frame(w, h),
+                         empty_frame(w, h, capi.FORMAT_MV_S8X2), [empty_frame(w, h) for _ in factors]))
+            sets[-1][3][0].copy_(t_prev4); sets[-1][4][0].copy_(t_mv)
+        set_bytes = w_in * h_in * 4 + (2 + len(factors)) * w * h * 4 + w * h * 2
+        def scale_cold(k):
+            st = sets[k % n_sets]
+            ctx.scale(st[1], st[2][1])
+        def scale_interp_cold(k):
+            st = sets[k % n_sets]
+            ctx.scale(st[1], st[2][1])
+            interpolate_all(st[3][1], st[2][1], st[4][1], [f for _, f in st[5]])
+        timed(scale_cold, 2 * n_sets)
+        t_sc = timed(scale_cold, n2)
+        timed(scale_interp_cold, 2 * n_sets)
+        t_sic = timed(scale_interp_cold, n2)
+        extras["scale_only"]["cache_cold"] = {"frames_per_s": round(n2 / t_sc, 1), "us_per_step": round(t_sc / n2 * 1e6, 3),
+                                              "hbm_frac": round(b_scale * n2 / t_sc / 1e9 / HBM_PEAK_GBS, 4),
+                                              "how": f"{n_sets} distinct input and output frames in rotation ({n_sets * (w_in * h_in + w * h) * 4 >> 20} MiB between two uses of a buffer)"}
+        extras["scale_only"]["cache"] = "warm: one input frame, resident in the Infinity Cache between launches (cache_cold beside it)"
+        extras["scale_interpolate"]["cache_cold"] = {"frames_per_s": round(n2 / t_sic, 1), "us_per_step": round(t_sic / n2 * 1e6, 3),
+                                                     "hbm_frac": round((b_scale + b_interp) * n2 / t_sic / 1e9 / HBM_PEAK_GBS, 4),
+                                                     "how": f"{n_sets} distinct sets of input / upscaled / previous / vector / output frames in rotation "
+                                                            f"({n_sets * set_bytes >> 20} MiB between two uses of a buffer); the upscaled frame interpolate "
+                                                            "reads was written by the step's own scale"}
+        extras["scale_interpolate"]["cache"] = "warm: the same buffers every step (cache_cold beside it)"
+        del sets, two
+        ctx2.close()
         sweep = {args.content: {"frames_per_s": round(value, 1), "motion_ms": round(stage_ms.get("motion", 0.0), 4)}}
         def sweep_case(label, content, mode):
             p_in, c_in = make_content(content, w_in, h_in, 0, 0)
@@ -509,6 +693,7 @@ def main():
             ctx.set_motion_mode(capi.MOTION_PREFILTERED)
             ctx.scale(f_prev_in, f_prev4)
         worst = min((v["frames_per_s"] for k, v in sweep.items() if not k.startswith("literal")), default=None)
+        extras["config5"] = measure_config5(torch, capi, dev, dev_index, n_lanes)
         extras["content_sweep"] = {"frames_per_s_by_content": sweep, "worst_case_frames_per_s": worst,
                                    "note": "same kernels, same results discipline (bit-exact vectors on every content); the motion "
                                            "stage's run time depends on how much of the frame has an exact or near match inside the "
@@ -556,9 +741,12 @@ def main():
                            "157.3 TFLOP/s fp32 peak and is NOT a utilisation; `executed` (when a counter profile of this very "
                            "library is committed) is.  LFG_MOTION_MODE=1 runs the literal kernel alone.")}
             if not exact_only and args.input == "1080p" and not in_res:
-                ex = pmc_executed("lfg::motion_")
+                ex = pmc_executed("lfg::motion_prefilter_kernel")           # the dominant KERNEL of the dominant stage
                 if ex is not None:
                     md["executed"] = ex
+                    ex_all = pmc_executed("lfg::motion_")
+                    if ex_all is not None:
+                        md["executed_all_motion_kernels"] = {k: ex_all[k] for k in ("kernels", "kernel_us_per_step_in_that_pass", "valu_issue_utilisation")}
             if motion_stats is not None:
                 md["motion_mode"] = "prefiltered"
                 md["fallback_tiles"] = {"of": motion_stats[0], "exact_kernel": motion_stats[1]}
@@ -591,10 +779,19 @@ def main():
                                                                     else "scale only")),
                        "input": [w_in, h_in], "output": [w, h], "factors": factors if args.workload != "scale" else [],
                        "frames_in_flight": n_lanes,       # lanes of the C-ABI; 1 = strictly one frame at a time
+                       "devices": devices,                # HIP device ordinal of every rank, in rank order
                        "content": args.content + (" (the motion stage's best case but `static`; see content_sweep)" if args.content == "translated" and args.workload != "scale" else ""),
                        "parallelism": f"one frame pair per GPU x{world}" + (", lfg_broadcast_frame (RCCL) of the shared previous input frame per step, upscaled on every rank" if world > 1 else "")},
+            "rccl_ranks": rccl_ranks,              # lfg_comm_ranks(): the size of the RCCL communicator every rank joined (0: one GPU, none)
+            "repeats": {"regions": len(regions), "steps_per_region": steps, "median_ms_per_step": round(elapsed / steps * 1e3, 5),
+                        "min_ms_per_step": round(min(regions) / steps * 1e3, 5), "max_ms_per_step": round(max(regions) / steps * 1e3, 5),
+                        "first_region_ms_per_step": round(regions[0] / steps * 1e3, 5),
+                        "how": "every region is exactly `steps` steps between its own barrier + device-synchronisation pairs (max over ranks); "
+                               "a region shorter than 0.25 s is repeated until 0.25 s have been timed (25 regions at most) and `value` / "
+                               "`ms_per_step` are the MEDIAN region's"},
             "roofline": roofline,
             "stages": stages,
+            "stages_how": stage_pass,
             "library_sha16": library_sha16(),
         }
         line.update(extras)

@@ -200,8 +200,17 @@ int  lfg_motion_last_stats(lfg_context *ctx, uint32_t *out_tiles, uint32_t *out_
                            double *out_mean_recorded);
 /* Bytes of device memory the prefiltered lfg_motion keeps for frames of this size (allocated on the first such call, kept
  * until the size changes or the context goes; one per lane).  No reference counterpart -- the reference's motion pass keeps
- * nothing between its two images (src/frame_manager.cpp:262-300); a host budgets lanes with it.  Needs no GPU work. */
+ * nothing between its two images (src/frame_manager.cpp:262-300); a host budgets lanes with it.  Needs no GPU work.
+ * The figure is for the context's CURRENT lane count (the work-unit plan of a context with frames in flight differs from
+ * that of a context without, see lfg_motion_plan): call it after lfg_lanes(). */
 int  lfg_motion_workspace_size(lfg_context *ctx, uint32_t width, uint32_t height, uint64_t *out_bytes);
+/* The work-unit plan the prefiltered lfg_motion uses on this context: *out_rim_split = parts of the candidate order a
+ * segment on the image's rim is searched in -- 4 with frames in flight (lfg_lanes >= 2: the sum of the units' times counts),
+ * 48 = four, and eight for the segments at the top and bottom border, when one frame runs at a time (the longest unit counts);
+ * LFG_MOTION_RIM_SPLIT=4|8|48 in the environment at context creation overrides -- and *out_workgroups = the persistent
+ * workgroups of its prefilter launch (0 before the first call).  The plan changes only inside lfg_lanes(); the first lfg_motion
+ * after such a change re-plans (it waits for the lane's stream once).  Reporting only; either pointer may be NULL. */
+int  lfg_motion_plan(const lfg_context *ctx, int *out_rim_split, int *out_workgroups);
 
 /* Which arithmetic lfg_motion and lfg_interpolate follow.  No reference counterpart: SURVEY.md 8(f) rank 4.
  *   LFG_SEMANTICS_REFERENCE (default, the parity contract): the shaders as written -- equal block-match costs
@@ -279,11 +288,16 @@ int  lfg_comm_init(lfg_context *ctx, int nranks, int rank, const lfg_comm_id *id
 int  lfg_comm_rank(const lfg_context *ctx);       /* -1 without a communicator */
 int  lfg_comm_ranks(const lfg_context *ctx);      /*  0 without a communicator */
 /* Broadcast a tightly packed frame (every rank passes its own frame of the same size and format) from `root`,
- * asynchronously on the context's communication stream: it starts once everything enqueued so far on the compute
- * stream has finished (the kernels still reading the frame on a receiver, the kernels producing it on the root) and
- * runs next to whatever is enqueued afterwards.  Nothing enqueued later may touch the frame before lfg_comm_wait(). */
+ * asynchronously on the context's communication stream: it starts once everything enqueued so far on EVERY lane of
+ * the context has finished (the kernels still reading the frame on a receiver, the kernels producing it on the root,
+ * whichever lane they were given to) and runs next to whatever is enqueued afterwards.  Nothing enqueued later, on any
+ * lane, may touch the frame before that lane has passed an lfg_comm_wait() (or waits, lfg_lane_wait, for a lane that has). */
 int  lfg_broadcast_frame(lfg_context *ctx, lfg_frame *frame, int root);
-/* Make everything enqueued on the compute stream from now on wait (on the device) for the broadcasts issued so far. */
+/* Make everything enqueued on the SELECTED lane from now on wait (on the device) for ALL broadcasts issued so far.
+ * Contract: the communication stream is in order and one event, re-recorded behind each broadcast, stands for every
+ * broadcast before it -- so with two broadcasts in flight this waits for both, never for the older one alone (a caller
+ * that double-buffers, like linux-fg_amd/sharding.py, waits for slot k before it issues k + 1 and loses nothing).  Other
+ * lanes are not gated: they call lfg_comm_wait themselves or order behind this lane with lfg_lane_mark / lfg_lane_wait. */
 int  lfg_comm_wait(lfg_context *ctx);
 /* Collective teardown (also done by lfg_context_destroy).  Idempotent. */
 int  lfg_comm_destroy(lfg_context *ctx);

@@ -76,6 +76,7 @@ SIGNATURES = {
     "lfg_set_motion_mode": (_i, [_vp, _i]),
     "lfg_motion_last_stats": (_i, [_vp, ctypes.POINTER(_u32), ctypes.POINTER(_u32), ctypes.POINTER(ctypes.c_double)]),
     "lfg_motion_workspace_size": (_i, [_vp, _u32, _u32, ctypes.POINTER(ctypes.c_uint64)]),
+    "lfg_motion_plan": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "lfg_set_semantics": (_i, [_vp, _i]),
     "lfg_interpolate": (_i, [_vp, _FP, _FP, _FP, _FP, ctypes.c_float]),
     "lfg_interpolate_frames": (_i, [_vp, _FP, _FP, _FP, ctypes.c_float]),
@@ -278,6 +279,12 @@ class Context:
         self._check(self.lib.lfg_motion_workspace_size(self.h, width, height, ctypes.byref(n)), "lfg_motion_workspace_size")
         return n.value
 
+    def motion_plan(self):
+        """(rim split, persistent workgroups) of the prefiltered motion path on this context (lfg_motion_plan)."""
+        a, b = ctypes.c_int(), ctypes.c_int()
+        self._check(self.lib.lfg_motion_plan(self.h, ctypes.byref(a), ctypes.byref(b)), "lfg_motion_plan")
+        return a.value, b.value
+
     def interpolate(self, prev: Frame, curr: Frame, mv: Frame, out: Frame, factor: float = 0.5):
         self._check(self.lib.lfg_interpolate(self.h, ctypes.byref(prev), ctypes.byref(curr), ctypes.byref(mv),
                                              ctypes.byref(out), factor), "lfg_interpolate")
@@ -332,6 +339,13 @@ class Context:
             raise ValueError(f"communicator id must be {COMM_ID_BYTES} bytes")
         buf = ctypes.create_string_buffer(comm_id, COMM_ID_BYTES)
         self._check(self.lib.lfg_comm_init(self.h, nranks, rank, buf), "lfg_comm_init")
+
+    def comm_ranks(self) -> int:
+        """Ranks of this context's communicator (0 without one)."""
+        return int(self.lib.lfg_comm_ranks(self.h))
+
+    def comm_rank(self) -> int:
+        return int(self.lib.lfg_comm_rank(self.h))
 
     def broadcast_frame(self, f: Frame, root: int = 0):
         self._check(self.lib.lfg_broadcast_frame(self.h, ctypes.byref(f), root), "lfg_broadcast_frame")

@@ -21,7 +21,28 @@ import subprocess
 import sys
 import tempfile
 
-OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def find_objdump():
+    """llvm-objdump of the ROCm toolchain that built the library: $LLVM_OBJDUMP, next to the clang that hipcc drives
+    ($HIPCC --print-prog-name where it answers), under $ROCM_PATH, on PATH.  None if there is none."""
+    cand = [os.environ.get("LLVM_OBJDUMP")]
+    hipcc = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    try:
+        out = subprocess.run([hipcc, "--print-prog-name=llvm-objdump"], capture_output=True, text=True, timeout=60).stdout.strip()
+        cand.append(out if os.path.isabs(out) else None)
+    except (OSError, subprocess.SubprocessError):
+        pass
+    rocm = os.environ.get("ROCM_PATH") or "/opt/rocm"
+    cand += [os.path.join(rocm, "lib", "llvm", "bin", "llvm-objdump"), os.path.join(rocm, "llvm", "bin", "llvm-objdump"),
+             shutil.which("llvm-objdump")]
+    for c in cand:
+        if c and os.path.isfile(c) and os.access(c, os.X_OK):
+            return c
+    return None
+
+
+OBJDUMP = find_objdump()
 BUFFER_WINDOW = 6                 # instructions after a buffer store that must leave its data registers alone
 OTHER_WINDOW = 1                  # documented: one wait state
 STORE = re.compile(r"\b(buffer|global|flat|scratch)_store_dwordx[34]\b")
@@ -57,8 +78,11 @@ def check(disasm_lines, name):
             # (VALU writers only: data an LDS or memory read returns arrives long after any store has read its operands,
             #  and the compiler waits for the counters where registers are reused)
             if later.startswith("v_") and not later.startswith("v_cmp"):
-                dst = later.split(None, 1)[1].split(",")[0].strip()
-                if reg_range(dst) & data:
+                operands = [t.strip() for t in later.split(None, 1)[1].split(",")] if " " in later else []
+                # the first operand is the destination; v_swap_b32 writes its second as well, and the instructions with a
+                # scalar carry / mask output (v_add_co, v_div_scale, v_mad_u64_u32 ...) keep their vector result first
+                dsts = operands[:2] if later.startswith("v_swap") else operands[:1]
+                if any(reg_range(d) & data for d in dsts):
                     bad.append((name, ins, later))
                     break
     return bad
@@ -66,6 +90,10 @@ def check(disasm_lines, name):
 
 def main():
     lib = sys.argv[1]
+    if OBJDUMP is None:
+        print("check_store_hazard: no llvm-objdump (looked at $LLVM_OBJDUMP, `hipcc --print-prog-name`, $ROCM_PATH/lib/llvm/bin and PATH): "
+              "the wide-store guard of " + lib + " cannot be checked, so the library is not installed")
+        return 1
     tmp = tempfile.mkdtemp(prefix="lfg_hazard_")
     try:
         local = os.path.join(tmp, os.path.basename(lib))

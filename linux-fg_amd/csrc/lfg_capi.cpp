@@ -176,9 +176,10 @@ int ensure_motion_tables(lfg_context *ctx) {
 //       (134 more workgroups that stage a window each), which is why it is not used there;
 //   8   every rim segment in eight parts: one frame at a time the pan gains less (2,050) and everything else loses 5 - 10 %;
 //       9 % slower with three frames in flight.
-// LFG_MOTION_RIM_SPLIT=4|8|48 overrides.
+// LFG_MOTION_RIM_SPLIT=4|8|48 overrides (read ONCE, when the context is created).  The plan therefore changes only where the lane
+// count does -- inside lfg_lanes(), never silently between two lfg_motion calls -- and lfg_motion_plan() reports it.
 int motion_rim_split(const lfg_context *ctx) {
-    if (const char *e = getenv("LFG_MOTION_RIM_SPLIT")) { const int v = atoi(e); if (v == 4 || v == 8 || v == 48) return v; }
+    if (ctx->rim_split_env) return ctx->rim_split_env;
     return ctx->lanes.size() >= 2 ? 4 : 48;
 }
 
@@ -288,6 +289,7 @@ LFG_EXPORT int lfg_context_create(int device_ordinal, lfg_context **out_ctx) {
     ctx->stream = ctx->own_stream;
     ctx->tables.reserve(17);                 // AxisTable pointers handed out stay valid
     if (const char *m = getenv("LFG_MOTION_HINTS")) ctx->motion_hints = atoi(m) != 0;
+    if (const char *m = getenv("LFG_MOTION_RIM_SPLIT")) { const int v = atoi(m); if (v == 4 || v == 8 || v == 48) ctx->rim_split_env = v; }
     if (const char *m = getenv("LFG_FUSED_INTERPOLATE_SCALE")) ctx->fuse_interpolate_scale = atoi(m) != 0;
     if (const char *m = getenv("LFG_MOTION_MODE")) ctx->motion_mode = atoi(m) == 1 ? LFG_MOTION_EXACT_ONLY : LFG_MOTION_PREFILTERED;
     *out_ctx = ctx;
@@ -663,6 +665,13 @@ LFG_EXPORT int lfg_motion_workspace_size(lfg_context *ctx, uint32_t width, uint3
         return fail(ctx, LFG_ERR_INVALID, "lfg_motion_workspace_size: null output or a frame size outside 1..32768");
     if (ctx->motion_slots == 0) ctx->motion_slots = lfg::prefilter_slots();
     *out_bytes = (uint64_t)lfg::motion_workspace_bytes(width, height, ctx->motion_slots, motion_rim_split(ctx), nullptr);
+    return LFG_OK;
+}
+
+LFG_EXPORT int lfg_motion_plan(const lfg_context *ctx, int *out_rim_split, int *out_workgroups) {
+    if (!ctx) return LFG_ERR_INVALID;
+    if (out_rim_split) *out_rim_split = motion_rim_split(ctx);
+    if (out_workgroups) *out_workgroups = ctx->motion_slots;
     return LFG_OK;
 }
 

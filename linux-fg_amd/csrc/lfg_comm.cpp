@@ -5,13 +5,16 @@
 // RCCL is opened at run time (dlopen("librccl.so")) the first time a communicator is asked for: a single-GPU user of
 // the library never loads it, and the library has no link-time dependency on it.  The broadcast runs on the context's
 // own communication stream, ordered against the compute stream with events:
-//     lfg_broadcast_frame   comm stream waits for what the compute stream has been given so far (the kernels that still
+//     lfg_broadcast_frame   comm stream waits for what EVERY lane's stream has been given so far (the kernels that still
 //                           read the frame on a receiver, the kernels that produce it on the root), broadcasts, records;
-//     lfg_comm_wait         the compute stream waits (on the device) for every broadcast issued so far.
+//     lfg_comm_wait         the SELECTED lane's stream waits (on the device) for every broadcast issued so far -- the
+//                           communication stream is in order, so the one event, re-recorded behind each broadcast,
+//                           stands for all of them; a caller that wants the older of two broadcasts waits for both.
 // Between the two calls the caller enqueues the kernels of the step before: that is the overlap.
 #include <dlfcn.h>
 
 #include <cstring>
+#include <mutex>
 
 #include <rccl/rccl.h>
 
@@ -31,20 +34,23 @@ struct Rccl {
     std::string error;
 };
 
+// (std::call_once: the header allows one thread per GPU, and two of them may ask for their first communicator together)
 Rccl &rccl() {
     static Rccl r;
-    if (r.handle || !r.error.empty()) return r;
-    for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-        r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-        if (r.handle) break;
-    }
-    if (!r.handle) { r.error = std::string("cannot load librccl.so: ") + dlerror(); return r; }
-    auto sym = [&](const char *n) { void *p = dlsym(r.handle, n); if (!p && r.error.empty()) r.error = std::string("librccl.so lacks ") + n; return p; };
-    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
-    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
-    r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
-    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
-    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.handle) break;
+        }
+        if (!r.handle) { r.error = std::string("cannot load librccl.so: ") + dlerror(); return; }
+        auto sym = [&](const char *n) { void *p = dlsym(r.handle, n); if (!p && r.error.empty()) r.error = std::string("librccl.so lacks ") + n; return p; };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    });
     return r;
 }
 
@@ -112,9 +118,17 @@ LFG_EXPORT int lfg_broadcast_frame(lfg_context *ctx, lfg_frame *frame, int root)
     if (frame->pitch != frame->width * bpp)                     // one contiguous message per frame, as every rank allocates it
         return fail(ctx, LFG_ERR_UNSUPPORTED, "lfg_broadcast_frame: the frame must be tightly packed (pitch == width * bytes per pixel)");
     const size_t bytes = (size_t)frame->pitch * frame->height;
+    // The broadcast starts once EVERY lane has finished what it has been given so far: the kernels that still read the
+    // frame on a receiver (or produce it on the root) may sit on any of them.  One event, recorded and waited for lane by
+    // lane (a wait refers to the record that precedes it).
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess) e = hipEventRecord(ctx->comm_ready, ctx->stream);
     if (e == hipSuccess) e = hipStreamWaitEvent(ctx->comm_stream, ctx->comm_ready, 0);
+    for (size_t j = 0; j < ctx->lanes.size() && e == hipSuccess; ++j) {
+        if ((int)j == ctx->lane || !ctx->lanes[j].stream) continue;       // (the selected lane's stream is ctx->stream, above)
+        e = hipEventRecord(ctx->comm_ready, ctx->lanes[j].stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->comm_stream, ctx->comm_ready, 0);
+    }
     if (e != hipSuccess) return fail(ctx, LFG_ERR_DEVICE, std::string("lfg_broadcast_frame: ") + hipGetErrorString(e));
     const ncclResult_t rc = rccl().Broadcast(frame->data, frame->data, bytes, ncclUint8, root, (ncclComm_t)ctx->comm, ctx->comm_stream);
     if (rc != ncclSuccess) return fail_nccl(ctx, rc, "ncclBroadcast");
@@ -127,10 +141,10 @@ LFG_EXPORT int lfg_broadcast_frame(lfg_context *ctx, lfg_frame *frame, int root)
 LFG_EXPORT int lfg_comm_wait(lfg_context *ctx) {
     if (!ctx) return LFG_ERR_INVALID;
     if (!ctx->comm) return fail(ctx, LFG_ERR_INVALID, "lfg_comm_wait: no communicator (lfg_comm_init)");
-    if (ctx->comm_pending) {
+    if (ctx->comm_pending) {               // (never cleared: another lane may still have to wait for the same broadcast,
+                                           //  and waiting for an event that has fired costs nothing on the device)
         const hipError_t e = hipStreamWaitEvent(ctx->stream, ctx->comm_done, 0);
         if (e != hipSuccess) return fail(ctx, LFG_ERR_DEVICE, std::string("lfg_comm_wait: ") + hipGetErrorString(e));
-        ctx->comm_pending = false;
     }
     return LFG_OK;
 }

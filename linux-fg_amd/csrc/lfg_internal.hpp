@@ -104,6 +104,7 @@ struct lfg_context {
     lfg::MotionWorkspaceLayout motion_ws_layout{};
     int motion_units = 0;                      // work units of the prefilter for the current workspace size
     int motion_slots = 0;                      // prefilter workgroups resident at once on this device (0 = not queried yet)
+    int rim_split_env = 0;                     // LFG_MOTION_RIM_SPLIT at context creation (0: unset -- the plan follows the lane count)
     int motion_mode = 0;                       // 0: prefilter + exact fallback, 1: exact kernel only
     int semantics = 0;                         // 0: the shaders as written, 1: "intended" (lfg_set_semantics)
     uint32_t *motion_tables = nullptr;         // device: [semantics][rank2scan | order32 | entryOfScan], then baseScan
@@ -114,7 +115,7 @@ struct lfg_context {
     int comm_ranks = 0, comm_rank = 0;
     hipStream_t comm_stream = nullptr;
     hipEvent_t comm_ready = nullptr, comm_done = nullptr;
-    bool comm_pending = false;                 // a broadcast has been issued that the compute stream has not been told to wait for
+    bool comm_pending = false;                 // some broadcast has been issued on this communicator (comm_done has been recorded)
     // profiling
     bool profile = false;
     std::vector<lfg::ProfileSlot> prof_pending;

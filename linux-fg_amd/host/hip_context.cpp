@@ -1,7 +1,12 @@
 #include "hip_context.hpp"
 
+#include <unistd.h>
+
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
+#include <cstring>
+#include <mutex>
 #include <thread>
 
 bool HipContext::Initialize(int device) {
@@ -35,20 +40,35 @@ bool HipContext::WaitIdle() {
     return true;
 }
 
-bool HipContext::InitComm(int ranks, int rank, const std::string& idFile) {
+// The id file: 8 bytes of magic, the launcher's 8-byte run nonce, then the 128-byte id.  A file left behind by an earlier run
+// (same name, rank 0 of THIS run not there yet) must not be taken for this run's: rank 0 removes the name before it makes
+// the id and again once every rank has joined, and a receiver only accepts a file that carries its own nonce
+// (--comm-nonce / LFG_COMM_NONCE: the launcher gives every rank of one run the same number).  A rank that joined with
+// a wrong id would sit in ncclCommInitRank for ever, holding its GPU: a watchdog ends the process instead.
+namespace {
+constexpr char kIdMagic[8] = {'L', 'F', 'G', 'C', 'O', 'M', 'M', '1'};
+struct IdFile { char magic[8]; uint64_t nonce; char id[LFG_COMM_ID_BYTES]; };
+}  // namespace
+
+bool HipContext::InitComm(int ranks, int rank, const std::string& idFile, uint64_t nonce, int joinTimeoutSeconds) {
     if (!m_ctx) {
         LOG_ERROR("HipContext::InitComm: context not initialized");
         return false;
     }
     lfg_comm_id id{};
     if (rank == 0) {
+        (void)remove(idFile.c_str());                                  // a stale id of an earlier run
         if (lfg_comm_unique_id(&id) != LFG_OK) {
             LOG_ERROR("Failed to create a communicator id (is librccl.so available?)");
             return false;
         }
+        IdFile rec{};
+        memcpy(rec.magic, kIdMagic, sizeof rec.magic);
+        rec.nonce = nonce;
+        memcpy(rec.id, id.bytes, sizeof rec.id);
         const std::string tmp = idFile + ".tmp";
         FILE* f = fopen(tmp.c_str(), "wb");
-        if (!f || fwrite(id.bytes, 1, sizeof id.bytes, f) != sizeof id.bytes) {
+        if (!f || fwrite(&rec, 1, sizeof rec, f) != sizeof rec) {
             LOG_ERROR("Cannot write communicator id to ", tmp);
             if (f) fclose(f);
             return false;
@@ -59,20 +79,42 @@ bool HipContext::InitComm(int ranks, int rank, const std::string& idFile) {
             return false;
         }
     } else {
-        bool got = false;
+        bool got = false, foreign = false;
         for (int attempt = 0; attempt < 6000 && !got; ++attempt) {      // up to a minute
             if (FILE* f = fopen(idFile.c_str(), "rb")) {
-                got = fread(id.bytes, 1, sizeof id.bytes, f) == sizeof id.bytes;
+                IdFile rec{};
+                if (fread(&rec, 1, sizeof rec, f) == sizeof rec && memcmp(rec.magic, kIdMagic, sizeof rec.magic) == 0) {
+                    if (rec.nonce == nonce) { memcpy(id.bytes, rec.id, sizeof rec.id); got = true; }
+                    else foreign = true;                               // another run's file: rank 0 of this run will replace it
+                }
                 fclose(f);
             }
             if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(10));
         }
         if (!got) {
-            LOG_ERROR("Timed out waiting for the communicator id in ", idFile);
+            LOG_ERROR(foreign ? "The communicator id file belongs to another run (nonce mismatch): " : "Timed out waiting for the communicator id in ", idFile);
             return false;
         }
     }
-    if (lfg_comm_init(m_ctx, ranks, rank, &id) != LFG_OK) {
+    // ncclCommInitRank has no timeout of its own
+    std::mutex mu;
+    std::condition_variable cv;
+    bool joined = false;
+    std::thread watchdog([&] {
+        std::unique_lock<std::mutex> lock(mu);
+        if (!cv.wait_for(lock, std::chrono::seconds(joinTimeoutSeconds), [&] { return joined; })) {
+            fprintf(stderr, "lfg: rank %d of %d still waits for the other ranks after %d s (stale or foreign communicator id in %s?): giving up\n",
+                    rank, ranks, joinTimeoutSeconds, idFile.c_str());
+            fflush(stderr);
+            _exit(3);
+        }
+    });
+    const int rc = lfg_comm_init(m_ctx, ranks, rank, &id);
+    { std::lock_guard<std::mutex> lock(mu); joined = true; }
+    cv.notify_one();
+    watchdog.join();
+    if (rank == 0) (void)remove(idFile.c_str());                       // every rank has read it: nothing to go stale
+    if (rc != LFG_OK) {
         LOG_ERROR("Failed to join the communicator: ", lfg_last_error(m_ctx));
         return false;
     }

@@ -27,9 +27,12 @@ public:
     bool WaitIdle();                                          // vkQueueWaitIdle
 
     // Several GPUs, one process each (no reference counterpart: one queue, no communication,
-    // src/vulkan_context.cpp:130-151).  Rank 0 makes the communicator id and leaves it in `idFile` (written under a
-    // temporary name, then renamed); the other ranks wait for the file.  Collective: returns when all ranks have joined.
-    bool InitComm(int ranks, int rank, const std::string& idFile);
+    // src/vulkan_context.cpp:130-151).  Rank 0 removes `idFile`, makes the communicator id and leaves it there (magic,
+    // `nonce`, id; written under a temporary name, then renamed); the other ranks wait for a file that carries the same
+    // nonce -- the launcher hands every rank of one run the same number, so an id left by an earlier run is never joined.
+    // Collective: returns when all ranks have joined, and rank 0 then removes the file.  A join that does not complete
+    // within `joinTimeoutSeconds` ends the process with exit code 3 (ncclCommInitRank itself never gives up).
+    bool InitComm(int ranks, int rank, const std::string& idFile, uint64_t nonce = 0, int joinTimeoutSeconds = 120);
     int GetRank() const { return m_ctx ? lfg_comm_rank(m_ctx) : -1; }
     int GetRanks() const { return m_ctx ? lfg_comm_ranks(m_ctx) : 0; }
 

@@ -29,6 +29,8 @@ static void PrintUsage() {
               << "                           One process per GPU (BASELINE config 4): the batch shares its previous frame\n"
               << "                           (synthetic stream 0, captured on rank 0, broadcast over RCCL per frame); each\n"
               << "                           rank's current frames are its own stream.  FILE carries the communicator id.\n"
+              << "  --comm-nonce N           A number the launcher gives every rank of ONE run (default: LFG_COMM_NONCE, else 0): an\n"
+              << "                           id file left behind by another run is then never joined\n"
               << "  --frames N               Number of input frames to process (default: 10)\n"
               << "  --device N               HIP device ordinal (default: 0)\n"
               << "  --dump-dir DIR           Write every presented frame to DIR as raw RGBA8\n"
@@ -47,6 +49,7 @@ int main(int argc, char* argv[]) {
     int frames = 10, device = 0;
     std::string dumpDir, inputRaw, outputRaw, commFile;
     int ranks = 0, rank = 0, inFlight = 2;
+    unsigned long long commNonce = getenv("LFG_COMM_NONCE") ? strtoull(getenv("LFG_COMM_NONCE"), nullptr, 0) : 0ull;
     std::vector<float> factors;
     bool syncPresent = false;
 
@@ -72,6 +75,7 @@ int main(int argc, char* argv[]) {
         else if (strcmp(argv[i], "--ranks") == 0 && i + 1 < argc) ranks = std::atoi(argv[++i]);
         else if (strcmp(argv[i], "--rank") == 0 && i + 1 < argc) rank = std::atoi(argv[++i]);
         else if (strcmp(argv[i], "--comm-file") == 0 && i + 1 < argc) commFile = argv[++i];
+        else if (strcmp(argv[i], "--comm-nonce") == 0 && i + 1 < argc) commNonce = strtoull(argv[++i], nullptr, 0);
         else if (strcmp(argv[i], "--frames") == 0 && i + 1 < argc) frames = std::atoi(argv[++i]);
         else if (strcmp(argv[i], "--device") == 0 && i + 1 < argc) device = std::atoi(argv[++i]);
         else if (strcmp(argv[i], "--dump-dir") == 0 && i + 1 < argc) dumpDir = argv[++i];
@@ -109,7 +113,7 @@ int main(int argc, char* argv[]) {
     }
     if (ranks > 0) {
         if (commFile.empty() || rank < 0 || rank >= ranks) { LOG_ERROR("--ranks needs --rank in range and --comm-file"); return 1; }
-        if (!HipContext::Get().InitComm(ranks, rank, commFile)) { HipContext::Get().Cleanup(); return 1; }
+        if (!HipContext::Get().InitComm(ranks, rank, commFile, (uint64_t)commNonce)) { HipContext::Get().Cleanup(); return 1; }
         Scaler::Get().SetSharedPreviousSource(std::make_unique<SyntheticCapture>(0));   // the batch's previous frames: stream 0
         if (stream == 0) stream = (uint32_t)rank + 1;                                   // a rank's own current frames
     }

@@ -74,3 +74,54 @@ def test_contents_are_deterministic_and_distinct():
     assert (frames["static"][0] == frames["static"][1]).all()
     cur = [frames[c][1].tobytes() for c in b.CONTENTS]
     assert len(set(cur)) == len(cur)
+
+
+def test_gpus_n_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` run bare (the driver's command shape) starts N ranks itself: a fresh child under
+    torch.distributed.run with the same arguments, rendezvous on 127.0.0.1 -- never an exec, never a GPU call in the parent --
+    and fewer devices than ranks is refused with a clear message before anything is launched."""
+    import sys
+    import types
+    b = _bench()
+    cmd = b.launch_command(4, ["--gpus", "4", "--steps", "5", "--warmup", "2"], 29511)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    script = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[script + 1:] == ["--gpus", "4", "--steps", "5", "--warmup", "2"]
+
+    calls = []
+    def fake_run(argv, **kw):
+        calls.append((argv, kw))
+        return types.SimpleNamespace(returncode=7)
+    import subprocess
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("LFG_BENCH_SHARE_GPU", raising=False)
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    args = types.SimpleNamespace(gpus=4)
+    monkeypatch.setattr(b, "visible_devices", lambda: 8)           # an 8-GPU node: four ranks are started, their exit code comes back
+    assert b.spawn_ranks(args, ["--gpus", "4", "--steps", "5"]) == 7
+    assert len(calls) == 1 and calls[0][0][:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert calls[0][0][-4:] == ["--gpus", "4", "--steps", "5"]
+    assert calls[0][1]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"      # dmabuf IPC: RCCL needs it on this pool
+    calls.clear()
+    monkeypatch.setattr(b, "visible_devices", lambda: 1)           # the one-GPU box: refused, nothing launched
+    assert b.spawn_ranks(args, ["--gpus", "4"]) == 2
+    assert calls == []
+
+
+def test_main_spawns_before_it_imports_torch(monkeypatch):
+    """main() hands over to the launcher before `import torch` (the parent must never initialise the GPU)."""
+    import sys
+    b = _bench()
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
+    seen = {}
+    def fake_spawn(args, argv):
+        seen["gpus"], seen["argv"] = args.gpus, list(argv)
+        return 5
+    monkeypatch.setattr(b, "spawn_ranks", fake_spawn)
+    import pytest
+    with pytest.raises(SystemExit) as e:
+        b.main()
+    assert e.value.code == 5 and seen == {"gpus": 2, "argv": ["--gpus", "2", "--steps", "3"]}

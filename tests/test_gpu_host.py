@@ -87,11 +87,14 @@ def test_shared_previous_batch_mode_one_rank(host_binary, oracle, tmp_path):
     w, h, n = 64, 36, 3
     d = tmp_path / "shared"
     d.mkdir()
+    # a file left behind by an earlier run under the same name (another run's nonce, garbage for an id): rank 0 replaces it,
+    # nobody joins it
+    (tmp_path / "comm.id").write_bytes(b"LFGCOMM1" + (12345).to_bytes(8, "little") + bytes(128))
     stats = run_host(["--input-width", str(w), "--input-height", str(h), "--output-width", str(2 * w), "--output-height", str(2 * h),
                       "--frames", str(n), "--dump-dir", str(d), "--quiet", "--ranks", "1", "--rank", "0",
-                      "--comm-file", str(tmp_path / "comm.id")])
+                      "--comm-file", str(tmp_path / "comm.id"), "--comm-nonce", "777"])
     assert stats["presented"] == 2 * n and stats["interpolated"] == n
-    assert os.path.getsize(tmp_path / "comm.id") == 128
+    assert not os.path.exists(tmp_path / "comm.id")          # every rank has joined: rank 0 removed the id, nothing to go stale
     files = sorted(os.listdir(d))
     assert [f.split("_")[2] for f in files] == ["interp", "real"] * n
     frames = [np.fromfile(d / f, np.uint8).reshape(2 * h, 2 * w, 4) for f in files]

@@ -16,12 +16,3 @@ for r in csv.DictReader(open(sys.argv[2])):
 PY
 done; done
 cat $OUT
-exit 0
-# SQ counters of the shipped library's scale kernel (own pass, counters only)
-rm -rf /tmp/pmc_scale
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d /tmp/pmc_scale -- python3 $R/tools/run_stage.py scale 20 > /dev/null 2>&1
-python3 $R/tools/pmc_summary.py /tmp/pmc_scale | sed "s#/tmp/##" > $R/gpurun_out/scale_sq_counters.txt
-rm -rf /tmp/pmc_scale2
-rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_scale2 -- python3 $R/tools/run_stage.py scale 20 > /dev/null 2>&1
-python3 $R/tools/pmc_summary.py /tmp/pmc_scale2 | sed "s#/tmp/##" >> $R/gpurun_out/scale_sq_counters.txt
-cat $R/gpurun_out/scale_sq_counters.txt
