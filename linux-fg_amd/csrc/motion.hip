@@ -337,12 +337,12 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
 //     window, n = |c|^2 + |p|^2 - 2 c.p by two v_dot4_u32_u8 whose accumulators are float bit patterns (so n
 //     comes out as a float without conversions), v_sqrt_f32, then the 16 column sums
 //     V8(r) = D(r) + ... + D(r+7) as a shared pairwise tree (58 adds);
-//   * transposition through a wave-private LDS slab, eight rows at a time, rows interleaved in pairs (writes:
-//     lane = column, one ds_write_b64 per row pair; reads: lane = (row lane&7, 7-pixel run lane>>3), one
-//     ds_read2_b32 per input pair, all 32 banks distinct);
+//   * transposition through a wave-private LDS slab, all sixteen rows in one round trip, rows r and r + 8 interleaved
+//     (writes: lane = column, one ds_write_b64 per row pair; reads: lane = (row lane&7, 7-pixel run lane>>3), one
+//     ds_read_b64 per input column: both of the lane's rows at once);
 //   * row sums, per lane two runs of 7 pixels (rows r and r+8) packed side by side: 14 input pairs -> shared
 //     pairwise tree (31 packed adds) -> 7 + 7 S~, threshold test, list append.
-//   LDS: 38.2 KB window + 4 x 5.1 KB slabs (the wide passes use 2.1 KB of each) + 4.3 KB visiting order + 2.2 KB its
+//   LDS: 38.2 KB window + 4 x 5.1 KB slabs (the wide passes use 4.3 KB of each) + 4.3 KB visiting order + 2.2 KB its
 //   inverse + 8 KB narrow-search state + 2 KB waiting candidates = 75 KB; 256 VGPRs -> two workgroups (8 waves) per CU.
 //   DS operations of one wave execute in order, so a slab needs neither double buffering nor barriers.  Loop order
 //   per surviving candidate e: window reads(e+1) issued | row sums + test(e) | column sums(e+1) | slab
@@ -356,9 +356,15 @@ constexpr int kWinW = 95;                         // window columns: 63 position
 constexpr int kWinH = kPTH + kB - 1 + 2 * kR;     // 103 rows; the window is stored COLUMN-major (pitch kWinH, odd), so
                                                   // a thread's 23 texels are consecutive words (ds_read2_b32 pairs) and
                                                   // the 64 lanes of a read still fall into distinct banks
-constexpr int kSlabP = 136;                       // slab pitch of a ROW PAIR (floats): rows 2a, 2a+1 interleaved per column,
-                                                  // so a thread writes two rows with one ds_write_b64; 136 keeps the
-                                                  // transposed reads on 32 distinct banks
+constexpr int kSlabP = 132;                       // slab pitch of a ROW PAIR (floats): rows r, r + 8 interleaved per column,
+                                                  // so a thread writes two rows with one ds_write_b64 and the row sums read
+                                                  // both with one ds_read_b64.  8-byte accesses are served sixteen lanes at a
+                                                  // time over the sixteen 8-byte slots of the 32 banks: with 66 slots per row
+                                                  // the sixteen lanes (r8 = 0..7, q = 2k, 2k + 1) of a transposed read fall
+                                                  // into slots 2 r8 + 7 q + i mod 16 -- the even ones for one q, the odd ones
+                                                  // for the other.  (136 put rows r and r + 4 on the same slots: 5.7e8
+                                                  // conflict cycles per launch on a frame that searches in full, measured.)
+static_assert((kSlabP / 2) % 16 == 2 && kSlabP / 2 >= 64, "conflict-free transposed 8-byte reads");
 // The one-point lattice of interior segments: block positions (kLatC0 + 8 i, kLatR0 + 8 j).  A pixel's block is the 8 x 8
 // positions that start at its own column and row, so rows 7 | 15 put exactly one lattice row into the block of each of a
 // segment's 16 pixel rows, and columns 7, 15 .. 55 one lattice column into the block of each of its 56 pixel columns:
@@ -398,6 +404,9 @@ constexpr int kRunIn = kRun + kB - 1;             // 13
 #ifndef LFG_LOOKAHEAD
 #define LFG_LOOKAHEAD 2                 // candidates per lane of the lookahead (0 or 1: off)
 #endif
+#ifndef LFG_EXACT_MATCH
+#define LFG_EXACT_MATCH 1                // a hint whose every block position is the same bytes in both frames skips its evaluation
+#endif
 #ifndef LFG_FIRST_BATCH
 #define LFG_FIRST_BATCH 1                // entries of the first batch: the top hint alone (2: with zero motion, as in round 1)
 #endif
@@ -414,8 +423,8 @@ constexpr int kNarrowMax = 16;                    // pixel columns of the band a
 constexpr int kNarrowPitch = 164;                 // slab pitch of a row pair in the narrow passes (floats): = 4 mod 32, so the
                                                   // transposed reads of 16 rows x 2 column groups fall into 32 distinct banks
 constexpr int kNarrowQ = 20;                      // ... whose columns are stored four-way interleaved (column c at (c & 3) * 20 + c / 4)
-constexpr int kSlabFloats = 8 * kNarrowPitch;     // a wave's slab: 4 row pairs x kSlabP (wide), 8 row pairs x kNarrowPitch (narrow)
-static_assert(kSlabFloats >= 4 * kSlabP && 2 * (3 * kNarrowQ + 15) + 1 < kNarrowPitch, "both layouts fit");
+constexpr int kSlabFloats = 8 * kNarrowPitch;     // a wave's slab: 8 row pairs x kSlabP (wide), 8 row pairs x kNarrowPitch (narrow)
+static_assert(kSlabFloats >= 8 * kSlabP && 2 * (3 * kNarrowQ + 15) + 1 < kNarrowPitch, "both layouts fit");
 #ifndef LFG_HINT_GRID
 #define LFG_HINT_GRID 16
 #endif
@@ -685,12 +694,14 @@ __device__ __forceinline__ void prefilter_unit(
         for (int j = 0; j < kSegD; ++j) p[j] = w[j];
     };
     // Packed fp32 throughout (v_pk_add_f32: two adds per issue slot; a wave issues one VALU op per four
-    // cycles whatever its width): position j is paired with position j + 12, so every level of the sliding
-    // tree is "pair j + pair j+k" with a few scalar adds where the two halves meet.
-    constexpr int kHalf = 12;
-    static_assert(kSegD == 2 * kHalf - 1, "pairing (j, j+12) covers 23 positions with position 11 alone");
+    // cycles whatever its width): position j is paired with position j + 8 -- A[j] = (d_j, d_{j+8}), j = 0 .. 14, the
+    // distances of positions 8 .. 14 sitting in two pairs -- so every level of the sliding tree is "pair j + pair j+k",
+    // nothing is left over for scalar adds, and the tree ends in C8[r] = (V8 of row r, V8 of row r + 8): the very pairs
+    // the slab takes (one ds_write_b64 each) and the row sums want (transpose).  (Round 2 paired j with j + 12: its
+    // outputs came as (0,12) .. (3,15) plus eight scalars and were shuffled into row pairs with 27 moves per candidate.)
+    constexpr int kPairs = kSegD - 8;                                  // 15
     auto columnSums = [&](const uint32_t (&p)[kSegD], const uint32_t (&c)[kSegD], const uint32_t (&cc)[kSegD], const uint32_t valid,
-                          float (&v8)[kSeg]) {
+                          f32x2 (&C8)[8]) {
         // n = |c|^2 + |p|^2 - 2 c.p without integer->float conversions or shifts (half-rate ops on gfx950):
         // the dot products accumulate onto float bit patterns, 0x4B000000 + k = 2^23 + k and
         // 0x4B800000 + k = 2^24 + 2k (k < 2^23), so two exact fp32 operations give n as a float.
@@ -699,46 +710,54 @@ __device__ __forceinline__ void prefilter_unit(
         auto f1of = [&](int j) { return __builtin_bit_cast(float, __builtin_amdgcn_udot4(p[j], p[j], cc[j], false)); };        // 2^23 + |c|^2 + |p|^2
         auto f2of = [&](int j) { return __builtin_bit_cast(float, __builtin_amdgcn_udot4(c[j], p[j], 0x4B800000u, false)); };  // 2^24 + 2 c.p
         const f32x2 kBias = {8388608.0f, 8388608.0f};
-        f32x2 A[kHalf - 1];                                            // (d_j, d_{j+12}), j = 0..10
+        f32x2 A[kPairs];
 #pragma unroll
-        for (int j = 0; j < kHalf - 1; ++j) {
-            const f32x2 F1 = {f1of(j), f1of(j + kHalf)}, F2 = {f2of(j), f2of(j + kHalf)};
+        for (int j = 0; j < 8; ++j) {                                  // positions 0 .. 15
+            const f32x2 F1 = {f1of(j), f1of(j + 8)}, F2 = {f2of(j), f2of(j + 8)};
             const f32x2 N = (F1 - F2) + kBias;
             A[j] = f32x2{__builtin_amdgcn_sqrtf(N.x), __builtin_amdgcn_sqrtf(N.y)};
         }
-        float dMid = __builtin_amdgcn_sqrtf((f1of(kHalf - 1) - f2of(kHalf - 1)) + 8388608.0f);   // d_11
-        // Border tiles only (one wave-uniform branch; the flag is laundered through an empty asm so the loop
-        // is not unswitched into two copies, which doubles the register pressure of the function).
+        float dHi[kSegD - 16];                                         // positions 16 .. 22
+#pragma unroll
+        for (int k = 0; k + 1 < kSegD - 16; k += 2) {
+            const f32x2 F1 = {f1of(16 + k), f1of(17 + k)}, F2 = {f2of(16 + k), f2of(17 + k)};
+            const f32x2 N = (F1 - F2) + kBias;
+            dHi[k] = __builtin_amdgcn_sqrtf(N.x); dHi[k + 1] = __builtin_amdgcn_sqrtf(N.y);
+        }
+        dHi[kSegD - 17] = __builtin_amdgcn_sqrtf((f1of(kSegD - 1) - f2of(kSegD - 1)) + 8388608.0f);
+        // Border segments only: a REAL wave-uniform branch (the flag is laundered through an empty asm so the loop is
+        // not unswitched into two copies, which doubles the register pressure of the function, and the asm inside the
+        // body keeps the compiler from turning the branch into 23 selects -- with their 23 lane masks, half of them
+        // reloaded from spilled scalars -- that every evaluation of every interior segment then executes).
         int border = borderSeg;
         asm volatile("" : "+s"(border));
         if (border) {                      // position outside the image: skipped by the shader, adds 0 here
+            asm volatile("; positions outside the image");
 #pragma unroll
-            for (int j = 0; j < kHalf - 1; ++j) {
+            for (int j = 0; j < 8; ++j) {
                 A[j].x = ((valid >> j) & 1u) ? A[j].x : 0.0f;
-                A[j].y = ((valid >> (j + kHalf)) & 1u) ? A[j].y : 0.0f;
+                A[j].y = ((valid >> (j + 8)) & 1u) ? A[j].y : 0.0f;
             }
-            dMid = ((valid >> (kHalf - 1)) & 1u) ? dMid : 0.0f;
+#pragma unroll
+            for (int k = 0; k < kSegD - 16; ++k) dHi[k] = ((valid >> (16 + k)) & 1u) ? dHi[k] : 0.0f;
         }
-        f32x2 B[kHalf - 2], G[kHalf - 4], C[kHalf - 8];
 #pragma unroll
-        for (int j = 0; j < kHalf - 2; ++j) B[j] = A[j] + A[j + 1];    // (v2_j, v2_{j+12}), j = 0..9
-        const float v2_10 = A[10].x + dMid, v2_11 = dMid + A[0].y;
+        for (int j = 8; j < kPairs; ++j) A[j] = f32x2{A[j - 8].y, dHi[j - 8]};
+        f32x2 B[kPairs - 1], G[kPairs - 3];
 #pragma unroll
-        for (int j = 0; j < kHalf - 4; ++j) G[j] = B[j] + B[j + 2];    // (v4_j, v4_{j+12}), j = 0..7
-        const float v4_8 = B[8].x + v2_10, v4_9 = B[9].x + v2_11, v4_10 = v2_10 + B[0].y, v4_11 = v2_11 + B[1].y;
+        for (int j = 0; j < kPairs - 1; ++j) B[j] = A[j] + A[j + 1];   // (v2_j, v2_{j+8}), j = 0..13
 #pragma unroll
-        for (int j = 0; j < kHalf - 8; ++j) C[j] = G[j] + G[j + 4];    // (v8_j, v8_{j+12}), j = 0..3
+        for (int j = 0; j < kPairs - 3; ++j) G[j] = B[j] + B[j + 2];   // (v4_j, v4_{j+8}), j = 0..11
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { v8[j] = C[j].x; v8[j + kHalf] = C[j].y; }
-        v8[4] = G[4].x + v4_8;  v8[5] = G[5].x + v4_9;  v8[6] = G[6].x + v4_10;  v8[7] = G[7].x + v4_11;
-        v8[8] = v4_8 + G[0].y;  v8[9] = v4_9 + G[1].y;  v8[10] = v4_10 + G[2].y; v8[11] = v4_11 + G[3].y;
+        for (int j = 0; j < 8; ++j) C8[j] = G[j] + G[j + 4];           // (v8_j, v8_{j+8}), j = 0..7
     };
 
     // ---- row sums: rows r8 and r8 + 8 of the wave's 16, pixels tx0 + 7 q .. + 6
     const int r8 = lane & 7, q = lane >> 3;
     const int px0 = tx0 + kRun * q;
-    f32x2 *const slabW = reinterpret_cast<f32x2 *>(sSlab[wave]) + lane;               // write: rows (2a, 2a+1), column lane
-    const lds_ro_f32_ptr slabR = (lds_ro_f32_ptr)(sSlab[wave] + (r8 >> 1) * kSlabP + 2 * kRun * q + (r8 & 1));
+    typedef const __attribute__((address_space(3))) f32x2 *lds_ro_f32x2_ptr;
+    f32x2 *const slabW = reinterpret_cast<f32x2 *>(sSlab[wave]) + lane;               // write: rows (r, r + 8), column lane
+    const lds_ro_f32x2_ptr slabR = (lds_ro_f32x2_ptr)(sSlab[wave]) + r8 * (kSlabP / 2) + kRun * q;     // read: rows (r8, r8 + 8), input column 7 q + i
     f32x2 thr2[kRun];                     // (row r8, row r8 + 8): kRatio * (smallest S~ so far); a candidate survives
                                           // while S~ <= thr
     uint32_t cnt2[2][(kRun + 1) / 2];                                  // 16-bit counters (1089 events at most)
@@ -887,23 +906,18 @@ __device__ __forceinline__ void prefilter_unit(
             }
         }
     };
-    // slab traffic of one candidate: rows 0-7 out, their transposed runs in, rows 8-15 out, runs in
-    // (The wave-scope fences are for the compiler only: writes go through an f32x2 pointer, reads through a float
-    //  LDS pointer, and nothing else tells it that the reads of a pass must stay between that pass's writes and
-    //  the next pass's.  The hardware executes one wave's DS operations in order.)
-    auto transpose = [&](const float (&v8)[kSeg], f32x2 (&X)[kRunIn], const lds_ro_f32_ptr slabR) {
+    // slab traffic of one candidate: the sixteen rows out as eight (row r, row r + 8) pairs per column, the transposed runs in as
+    // thirteen pairs per lane -- ONE round trip (round 2: rows 0-7 out and in, then rows 8-15; 26 reads).  Conflict-free by the
+    // pitch (kSlabP); the writes are consecutive.
+    // (The wave-scope fences are for the compiler only: nothing else tells it that the reads of a pass must stay between
+    //  that pass's writes and the next pass's.  The hardware executes one wave's DS operations in order.)
+    auto transpose = [&](const f32x2 (&C8)[8], f32x2 (&X)[kRunIn], const lds_ro_f32x2_ptr from) {
         wave_lds_sync();
 #pragma unroll
-        for (int a = 0; a < 4; ++a) slabW[a * (kSlabP / 2)] = f32x2{v8[2 * a], v8[2 * a + 1]};
+        for (int r = 0; r < 8; ++r) slabW[r * (kSlabP / 2)] = C8[r];
         wave_lds_sync();
 #pragma unroll
-        for (int i = 0; i < kRunIn; ++i) X[i].x = slabR[2 * i];
-        wave_lds_sync();
-#pragma unroll
-        for (int a = 0; a < 4; ++a) slabW[a * (kSlabP / 2)] = f32x2{v8[8 + 2 * a], v8[9 + 2 * a]};
-        wave_lds_sync();
-#pragma unroll
-        for (int i = 0; i < kRunIn; ++i) X[i].y = slabR[2 * i];
+        for (int i = 0; i < kRunIn; ++i) X[i] = from[i];
         wave_lds_sync();
     };
 
@@ -914,7 +928,7 @@ __device__ __forceinline__ void prefilter_unit(
         stampU[0] = __builtin_amdgcn_s_memrealtime();
 #endif
         uint32_t p[kSegD];
-        float v8[kSeg];
+        f32x2 v8[8];                       // (V8 of row r, of row r + 8)
         f32x2 x[kRunIn];
         // Once EVERY pixel of this wave owns a zero-cost candidate, a candidate can only still matter if it comes
         // earlier in the tie order than the latest of those: zeroBound = that rank (none: 0xFFFFFFFF).  Later-ranked
@@ -969,7 +983,6 @@ __device__ __forceinline__ void prefilter_unit(
 #define LFG_ONEPOINT_MAX 32.0f
 #endif
         constexpr float kOnePointMax = LFG_ONEPOINT_MAX;   // below: the one-point test alone (cheap, and strong while thresholds are small)
-        bool useFourPoint = true, useSixteen = LFG_SIXTEEN != 0;
         // "Some lattice point of the candidate is the same four bytes in both frames": what a pixel that already owns a
         // zero-cost candidate needs before another candidate can matter to it (its S~ would have to be 0: every distance
         // of its block exactly 0, the lattice point inside the block among them).  One compare per point.
@@ -1038,75 +1051,13 @@ __device__ __forceinline__ void prefilter_unit(
             stampBand = 0x10000u | (unsigned)bandLo | ((unsigned)bandHi << 8);
 #endif
         };
-        // bit k of the result: candidate i0 + k of the staged order has to be evaluated in full
-        // (ordL: this lane's candidate, an entry of the order; need: it has to be looked at; fullBatch: 64 candidates)
-        auto latticeBatch = [&](const uint32_t ordL, bool need, const bool fullBatch) -> unsigned long long {
-#ifndef LFG_ONEPOINT_OFF
-#define LFG_ONEPOINT_OFF 96.0f
-#endif
-            if (waveThr < LFG_ONEPOINT_OFF) {                          // (a distance is at most 510, but few exceed a threshold of a hundred)
-                const lds_ro_u32_ptr w = (lds_ro_u32_ptr)(sWin + kSeg * seg) + (ordL >> 16);
-                // the candidate's smallest squared lattice distance, as bits: non-negative floats, whose order is
-                // the order of their bit patterns (one v_min_u32 per point, no NaN handling)
-                uint32_t dMin = 0x7F800000u;
-                auto bitsOf = [](float d) { return __builtin_bit_cast(uint32_t, d); };
-                if (border && LFG_ZERO_COMPARE && waveThr < 0.5f) {
-                    dMin = zeroHit(ordL) ? 0u : 0x7F800000u;           // (see the interior case below)
-                } else if (border) {
-#pragma unroll
-                    for (int col = 4; col <= kPTW; col += 4) {
-                        const uint32_t inImage = (uint32_t)__builtin_amdgcn_readlane((int)valid, col);
-#pragma unroll
-                        for (int row = 4; row <= 16; row += 4) {
-                            // a point outside the image is no point: its distance becomes "at least infinity"
-                            // (scalar mask, no branch)
-                            const uint32_t drop = (((inImage >> row) & 1u) - 1u) & 0x7F800000u;
-                            dMin = min(dMin, bitsOf(distanceOf((uint32_t)__builtin_amdgcn_readlane((int)c[row], col), w[col * kWinH + row])) | drop);
-                        }
-                    }
-                } else {
-                    uint32_t tex[kLatCols][kLatRows];    // all 14 texel reads in flight at once: one LDS round trip, not 14
-#pragma unroll
-                    for (int ci = 0; ci < kLatCols; ++ci) {
-#pragma unroll
-                        for (int t = 0; t < kLatRows; ++t) tex[ci][t] = w[(kLatC0 + 8 * ci) * kWinH + kLatR0 + 8 * t];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (LFG_ZERO_COMPARE && waveThr < 0.5f) {
-                        // Every pixel of the wave owns a zero-cost candidate (the threshold words stand for ranks): the test
-                        // reads "some lattice distance is exactly 0", and a squared distance is 0 iff the two texels are
-                        // the same four bytes -- one compare per point instead of three dot products.  This is the state of
-                        // most of a frame under a pan or where nothing moves, seventeen batches per wave.
-                        uint32_t acc = 0xFFFFFFFFu;                     // (smallest XOR: see the lookahead below)
-#pragma unroll
-                        for (int ci = 0; ci < kLatCols; ++ci) {
-#pragma unroll
-                            for (int t = 0; t < kLatRows; ++t)
-                                acc = min(acc, tex[ci][t] ^ (uint32_t)__builtin_amdgcn_readlane((int)c[kLatR0 + 8 * t], kLatC0 + 8 * ci));
-                        }
-                        dMin = acc == 0u ? 0u : 0x7F800000u;
-                    } else {
-#pragma unroll
-                        for (int ci = 0; ci < kLatCols; ++ci) {
-#pragma unroll
-                            for (int t = 0; t < kLatRows; ++t)
-                                dMin = min(dMin, bitsOf(distanceOf((uint32_t)__builtin_amdgcn_readlane((int)c[kLatR0 + 8 * t], kLatC0 + 8 * ci), tex[ci][t])));
-                        }
-                    }
-                }
-                // n > waveThr^2 (1 + 2^-21) => sqrt(n) > waveThr (1 + 2^-22), which v_sqrt_f32's 1 ulp cannot bring
-                // back to waveThr: every distance S~ would add exceeds the threshold.  (Both factors below round,
-                // 2^-24 each, against a margin of 2^-20; a threshold that stands for a zero cost squares to 0 and
-                // the test reads n > 0.)
-                const float thrSq = (waveThr * waveThr) * 1.000001f;
-                need = need & !(dMin > __builtin_bit_cast(uint32_t, thrSq));
-            }
 #ifndef LFG_FOURPOINT_MAX
 #define LFG_FOURPOINT_MAX (4.0f * 510.0f)
 #endif
-            // (only where the one-point test has just let more than an eighth of the batch through, and not any more once
-            //  a full batch came out of it three quarters intact: segments that search in full anyway stop paying for it)
-            if (useFourPoint && !(waveThr < kOnePointMax) && waveThr < LFG_FOURPOINT_MAX && __builtin_popcountll(__ballot(need)) > 8) {
+        bool useFourPoint = true, useSixteen = LFG_SIXTEEN != 0;
+        auto fourPointApplies = [&]() { return useFourPoint && !(waveThr < kOnePointMax) && waveThr < LFG_FOURPOINT_MAX; };
+        // (per lane: the candidate `ordL` still has to be evaluated in full)
+        auto fourPointBatch = [&](const uint32_t ordL, bool need, const bool fullBatch) -> bool {
                 // FOUR-point test, for thresholds a single distance rarely exceeds (a match under sensor noise costs a
                 // few hundred).  Block positions = 3 mod 4 form a lattice of 5 x 15 points of which every pixel's
                 // 8 x 8 block holds exactly a 2 x 2 group (columns 3 + 4 g, 7 + 4 g with g = i / 4 for pixel column i,
@@ -1171,7 +1122,74 @@ __device__ __forceinline__ void prefilter_unit(
                 if (restricted) pass = zeroHit(ordL) || pass;          // (the settled pixels outside the band)
                 need = need && pass;
                 if (fullBatch && __builtin_popcountll(__ballot(need)) >= 48) useFourPoint = false;
+                return need;
+        };
+        // bit k of the result: candidate i0 + k of the staged order has to be evaluated in full
+        // (ordL: this lane's candidate, an entry of the order; need: it has to be looked at; fullBatch: 64 candidates)
+        auto latticeBatch = [&](const uint32_t ordL, bool need, const bool fullBatch) -> unsigned long long {
+#ifndef LFG_ONEPOINT_OFF
+#define LFG_ONEPOINT_OFF 96.0f
+#endif
+            if (waveThr < LFG_ONEPOINT_OFF) {                          // (a distance is at most 510, but few exceed a threshold of a hundred)
+                const lds_ro_u32_ptr w = (lds_ro_u32_ptr)(sWin + kSeg * seg) + (ordL >> 16);
+                // the candidate's smallest squared lattice distance, as bits: non-negative floats, whose order is
+                // the order of their bit patterns (one v_min_u32 per point, no NaN handling)
+                uint32_t dMin = 0x7F800000u;
+                auto bitsOf = [](float d) { return __builtin_bit_cast(uint32_t, d); };
+                if (border && LFG_ZERO_COMPARE && waveThr < 0.5f) {
+                    dMin = zeroHit(ordL) ? 0u : 0x7F800000u;           // (see the interior case below)
+                } else if (border) {
+#pragma unroll
+                    for (int col = 4; col <= kPTW; col += 4) {
+                        const uint32_t inImage = (uint32_t)__builtin_amdgcn_readlane((int)valid, col);
+#pragma unroll
+                        for (int row = 4; row <= 16; row += 4) {
+                            // a point outside the image is no point: its distance becomes "at least infinity"
+                            // (scalar mask, no branch)
+                            const uint32_t drop = (((inImage >> row) & 1u) - 1u) & 0x7F800000u;
+                            dMin = min(dMin, bitsOf(distanceOf((uint32_t)__builtin_amdgcn_readlane((int)c[row], col), w[col * kWinH + row])) | drop);
+                        }
+                    }
+                } else {
+                    uint32_t tex[kLatCols][kLatRows];    // all 14 texel reads in flight at once: one LDS round trip, not 14
+#pragma unroll
+                    for (int ci = 0; ci < kLatCols; ++ci) {
+#pragma unroll
+                        for (int t = 0; t < kLatRows; ++t) tex[ci][t] = w[(kLatC0 + 8 * ci) * kWinH + kLatR0 + 8 * t];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (LFG_ZERO_COMPARE && waveThr < 0.5f) {
+                        // Every pixel of the wave owns a zero-cost candidate (the threshold words stand for ranks): the test
+                        // reads "some lattice distance is exactly 0", and a squared distance is 0 iff the two texels are
+                        // the same four bytes -- one compare per point instead of three dot products.  This is the state of
+                        // most of a frame under a pan or where nothing moves, seventeen batches per wave.
+                        uint32_t acc = 0xFFFFFFFFu;                     // (smallest XOR: see the lookahead below)
+#pragma unroll
+                        for (int ci = 0; ci < kLatCols; ++ci) {
+#pragma unroll
+                            for (int t = 0; t < kLatRows; ++t)
+                                acc = min(acc, tex[ci][t] ^ (uint32_t)__builtin_amdgcn_readlane((int)c[kLatR0 + 8 * t], kLatC0 + 8 * ci));
+                        }
+                        dMin = acc == 0u ? 0u : 0x7F800000u;
+                    } else {
+#pragma unroll
+                        for (int ci = 0; ci < kLatCols; ++ci) {
+#pragma unroll
+                            for (int t = 0; t < kLatRows; ++t)
+                                dMin = min(dMin, bitsOf(distanceOf((uint32_t)__builtin_amdgcn_readlane((int)c[kLatR0 + 8 * t], kLatC0 + 8 * ci), tex[ci][t])));
+                        }
+                    }
+                }
+                // n > waveThr^2 (1 + 2^-21) => sqrt(n) > waveThr (1 + 2^-22), which v_sqrt_f32's 1 ulp cannot bring
+                // back to waveThr: every distance S~ would add exceeds the threshold.  (Both factors below round,
+                // 2^-24 each, against a margin of 2^-20; a threshold that stands for a zero cost squares to 0 and
+                // the test reads n > 0.)
+                const float thrSq = (waveThr * waveThr) * 1.000001f;
+                need = need & !(dMin > __builtin_bit_cast(uint32_t, thrSq));
             }
+            // (only where the one-point test has just let more than an eighth of the batch through, and not any more once
+            //  a full batch came out of it three quarters intact: segments that search in full anyway stop paying for it)
+            if (fourPointApplies() && __builtin_popcountll(__ballot(need)) > 8) need = fourPointBatch(ordL, need, fullBatch);
             return __ballot(need);
         };
 #ifndef LFG_SIXTEEN_MAX
@@ -1443,6 +1461,7 @@ __device__ __forceinline__ void prefilter_unit(
                 }
             };
             uint32_t p[kSegD];
+            f32x2 c8[8];
             float v8[kSeg];
             bool pending = false;
             int idx0 = iBegin, idxP = 0, started = 0;
@@ -1477,7 +1496,9 @@ __device__ __forceinline__ void prefilter_unit(
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (have) {
-                    columnSums(p, cN, ccN, nValid, v8);
+                    columnSums(p, cN, ccN, nValid, c8);
+#pragma unroll
+                    for (int a = 0; a < 8; ++a) { v8[a] = c8[a].x; v8[a + 8] = c8[a].y; }
                     wave_lds_sync();
 #pragma unroll
                     for (int a = 0; a < 8; ++a) nSlabW[a * (kNarrowPitch / 2)] = f32x2{v8[2 * a], v8[2 * a + 1]};
@@ -1828,11 +1849,42 @@ __device__ __forceinline__ void prefilter_unit(
                     }
                     if (pending) rowSumsAndTest(x, ordP, cntP);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (have) {
+                    bool evaluate = have;
+                    if (LFG_EXACT_MATCH && have && !byRank && i0 < hintsEnd) {
+                        // EXACT MATCH.  A hint that IS the motion of this segment -- a pan's top hint, zero motion where nothing
+                        // moves, an object's own vector -- reads the very bytes of the current frame at every block position:
+                        // all 23 x 63 distances are exactly 0, so S~ = 0 for each of the 16 x 56 pixels and the evaluation
+                        // could only find that out the long way (46 dot products, 23 square roots, two trees, two slab round
+                        // trips).  23 XORs and a ballot do: then every pixel takes the candidate as a zero-cost one -- the
+                        // update of rowSumsAndTest for s == 0: rank into the threshold word, no record, no count.  (Positions
+                        // outside the image add nothing to S~ and are left out here; lane 63 owns no position column.)  Tried
+                        // for the call's hints only: elsewhere it would cost every evaluation 7 % for nothing.
+                        uint32_t diff = 0u;
+#pragma unroll
+                        for (int j = 0; j < kSegD; ++j) diff |= p[j] ^ c[j];
+                        if (border) {
+                            diff = 0u;
+#pragma unroll
+                            for (int j = 0; j < kSegD; ++j) diff |= (p[j] ^ c[j]) & (0u - ((valid >> j) & 1u));
+                        }
+                        if (__builtin_amdgcn_readfirstlane((int)((__ballot(diff != 0u) & 0x7FFFFFFFFFFFFFFFull) == 0ull))) {
+                            const float zc = __builtin_bit_cast(float, 0x00800000u + (ord & 0xFFFFu));
+#pragma unroll
+                            for (int i = 0; i < kRun; ++i) {       // (-inf, a pixel outside the image, stays)
+                                thr2[i].x = __builtin_fminf(thr2[i].x, zc);
+                                thr2[i].y = __builtin_fminf(thr2[i].y, zc);
+                            }
+                            evaluate = false;
+#ifdef LFG_MOTION_STAMPS
+                            stampEvals += 0x10000u;
+#endif
+                        }
+                    }
+                    if (evaluate) {
                         columnSums(p, c, cc, valid, v8);
                         transpose(v8, x, slabR);
                     }
-                    ordP = ord; cntP = cntIt; pending = have;
+                    ordP = ord; cntP = cntIt; pending = evaluate;
                 }
                 // lists full somewhere in the tile: stop early
                 if (__builtin_amdgcn_readfirstlane(__ballot(listsOverflowed()) != 0ull)) sGiveUp = 1u;
@@ -3000,6 +3052,18 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
                     const unsigned long long *o = &h[(u * 4 + w) * 8]; if (!o[1] || !((o[6] >> 9) & 1)) continue;
                     qa = std::min(qa, o[0]); qlast = std::max(qlast, o[0]); qb = std::max(qb, o[1]); qsum += (double)(o[1] - o[0]) / 100.0; qev += (double)o[2]; ++qn;
                     t1 = std::max(t1, o[1]);
+                }
+                {   // handed-over segments (two consecutive queue units = eight parts) in which some part ended with every pixel at
+                    // a zero-cost candidate: one evaluation of the right candidate would have settled the whole segment
+                    int segs = 0, zero = 0, narrowSegs = 0, bandSegs = 0;
+                    for (int u = n; u + 1 < 8192; u += 2) {
+                        bool any = false, z = false, nar = false, bnd = false;
+                        for (int k = 0; k < 8; ++k) { const unsigned long long *o = &h[((u + k / 4) * 4 + k % 4) * 8]; if (!o[1]) continue; any = true;
+                            const uint32_t tb = (uint32_t)(o[7] >> 32); float fb; memcpy(&fb, &tb, 4); if (fb < 0.5f) z = true;
+                            const int kk = (int)(o[6] & 7u); if (kk == 7) bnd = true; else if (kk) nar = true; }
+                        if (any) { ++segs; zero += z; narrowSegs += nar; bandSegs += bnd; }
+                    }
+                    fprintf(stderr, "handed-over segments %d: %d end with a zero-cost candidate for every pixel (a hint would have settled them), %d searched narrow, %d as a row band\n", segs, zero, narrowSegs, bandSegs);
                 }
                 if (qn) fprintf(stderr, "queue units: %d waves, first start %.1f, last start %.1f, last end %.1f us, mean duration %.1f us, evaluations per wave %.1f\n", qn,
                                 (double)(qa - t0) / 100.0, (double)(qlast - t0) / 100.0, (double)(qb - t0) / 100.0, qsum / qn, qev / qn);

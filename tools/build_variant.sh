@@ -6,7 +6,7 @@ name=$1; shift
 C=$R/linux-fg_amd/csrc
 mkdir -p $R/build_variants
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fvisibility=hidden -I$R/include -Wall -Wno-unused-function"
-/opt/rocm/bin/hipcc $FLAGS "$@" -c $C/motion.hip -o /tmp/motion_$name.o
+/opt/rocm/bin/hipcc $FLAGS "$@" -c ${MOTION_SRC:-$C/motion.hip} -o /tmp/motion_$name.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/build_variants/lib_$name.so $C/lfg_capi.cpp.o $C/lfg_comm.cpp.o $C/scale.hip.o $C/interpolate.hip.o /tmp/motion_$name.o -ldl
 python3 $C/check_store_hazard.py $R/build_variants/lib_$name.so     # the same machine-code check as the product build
 echo built build_variants/lib_$name.so
