@@ -208,6 +208,10 @@ int ensure_motion_workspace(lfg_context *ctx, uint32_t width, uint32_t height) {
     tables.insert(tables.end(), plan.unitAux.begin(), plan.unitAux.end());
     tables.insert(tables.end(), plan.tileMap.begin(), plan.tileMap.end());
     LFG_HIP(ctx, hipMemcpy(ctx->motion_ws + layout.plan, tables.data(), tables.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    // what the kernels expect to find between calls: a cleared control area (the hint kernel's counter of finished
+    // workgroups lies in it, and that kernel is what clears the rest per call) and the merge words of the flagged tiles all ones
+    LFG_HIP(ctx, hipMemset(ctx->motion_ws + layout.tileFlags, 0, layout.order - layout.tileFlags));
+    LFG_HIP(ctx, hipMemset(ctx->motion_ws + layout.merge, 0xFF, layout.mergeBytes));
     ctx->motion_units = plan.units;
     ctx->motion_ws_layout = layout;
     ctx->motion_ws_w = width; ctx->motion_ws_h = height;

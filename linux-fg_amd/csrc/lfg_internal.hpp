@@ -35,7 +35,7 @@ struct AxisTable {
 };
 
 struct MotionWorkspaceLayout { size_t list, umin, count, tileFlags, segDone, segMap, queueCount, ctrl, order, plan, auxList, auxUmin, auxCount,
-                               queue, dynList, dynUmin, dynCount, dynInit, total; int queueCap, slots, rimSplit; };
+                               queue, dynList, dynUmin, dynCount, dynInit, openList, merge, mergeBytes, total; int queueCap, slots, rimSplit; };
 // Work units of the motion prefilter (motion.hip: prefilter_plan).  A unit is a 56 x 64 tile, or one of nChunks
 // contiguous parts of a tile's candidate order, or one 16-row segment of a tile with its four waves on four parts of
 // the order; parts have private lists in the aux arrays (merged by the resolve kernel).
@@ -57,6 +57,7 @@ struct PrefilterPlan {               // passed by value to the kernels
     float *dynUmin;
     uint32_t *dynCount;
     uint32_t *dynInit;               // per handed-over segment: the 16 x 56 thresholds of the wave that handed it over
+    uint32_t *openList, *openCount;  // the segments left to the resolve kernel (tile * 4 + segment), appended as units end
 };
 struct PrefilterPlanHost {
     int tilesX = 0, tiles = 0, units = 0, auxUnits = 0;
@@ -139,8 +140,7 @@ int scale_2x_strips_per_xcd(int inH);
 void scale_2x_strip_host(int inH, int xcd, int index, int &first, int &steps);
 hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                     const lfg_frame &mv, const uint32_t *tileFlags, const uint32_t *rank2scan,
-                                    unsigned long long *merge = nullptr, size_t mergeRowStride = 0,
-                                    const uint32_t *flaggedTiles = nullptr);
+                                    unsigned long long *merge = nullptr, uint32_t *flaggedTiles = nullptr);
 // Candidate tables of the blockSize 8 / searchRadius 16 paths for one tie-break rule (motion.hip: motion_tables).
 constexpr int kMotionTableWords = 1092;     // 33 * 33 candidates + the sentinel, padded to a multiple of 4
 void motion_tables(bool intended, uint32_t *rank2scan, uint32_t *order32, uint32_t *entryOfScan, uint32_t *baseScan);

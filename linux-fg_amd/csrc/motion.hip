@@ -90,31 +90,47 @@ static_assert(kTW / 8 * kTH == kNT, "one thread per 8x1 pixel patch");
 static_assert(kNT / 64 * kMainRows >= kDH && kExtra <= kNT, "phase-A map covers the plane");
 
 constexpr int kShareBelow = 256;        // flagged tiles up to which the exact kernel shares each between several workgroups
-
+constexpr int kFallbackParts = 8;       // workgroups that share a flagged tile (contiguous parts of the tie order)
 __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int8_t *__restrict__ mv, int mvPitch, int W, int H, const uint32_t *__restrict__ tileFlags,
-    const uint32_t *__restrict__ rank2scan, unsigned long long *__restrict__ merge, size_t mergeRowStride,
-    const uint32_t *__restrict__ flaggedTiles, int tilesX) {
-    // As the second pass of the prefiltered path (tileFlags != nullptr) a flagged tile is shared by gridDim.z
-    // workgroups, each on a contiguous part of the tie order: one workgroup needs 4.3 ms for a tile whatever else the
-    // chip is doing, and a frame rarely has more than a few such tiles.  The parts meet in `merge` (one 64-bit word
-    // per pixel, preset to all ones): atomicMin of (cost bits << 32 | rank) is the smallest cost and, among equal
-    // costs, the first candidate in tie order; motion_merge_kernel turns the words into vectors.
+    const uint32_t *__restrict__ rank2scan, unsigned long long *__restrict__ merge,
+    uint32_t *__restrict__ flaggedTiles, int tilesX, int tiles) {
+    // Two uses.  tileFlags == nullptr: the literal kernel for the whole frame (LFG_MOTION_MODE=1), one workgroup per tile of
+    // the 2-D grid.  Otherwise the SECOND PASS of the prefiltered path, ONE launch of a 1-D grid (max(tiles, kShareBelow *
+    // kFallbackParts) workgroups) whatever the prefilter flagged -- usually nothing: every workgroup reads the count and leaves:
+    //   * up to kShareBelow flagged tiles (counted and listed on the device as they were flagged: flaggedTiles[0], [1 ..]):
+    //     a workgroup needs 4.3 ms for a tile whatever else the chip is doing, so each tile is shared by kFallbackParts
+    //     workgroups, each on a contiguous part of the tie order.  The parts meet in `merge` (one 64-bit word per pixel
+    //     of the slot's 64 x 64 tile, all ones between calls): atomicMin of (cost bits << 32 | rank) is the smallest cost
+    //     and, among equal costs, the first candidate in tie order; the part that arrives LAST (a counter per slot behind
+    //     the list) turns the words into vectors and leaves them all ones again.  (Round 2: two launches for the two
+    //     regimes, a third for the merge, and the words lived in the lists, preset by the resolve kernel.)
+    //   * more flagged tiles fill the chip by themselves: one workgroup each, vectors written directly.
     // Candidates are visited in TIE ORDER: rank2scan[r] is the scan index (dy+R)*33 + (dx+R) of the r-th candidate
     // and the first strict minimum wins, so the table decides between equal costs.  Reference semantics: the
     // identity (motion.comp's scan order).  Entry kCand is a sentinel (scan index kCand, one row below the window).
     __shared__ __attribute__((aligned(16))) float sD[2][kDH * kDS];    // 2 x 21 KB
+    __shared__ uint32_t sLast;
 
-    // Second pass of the prefiltered path: only the tiles the prefilter gave up on (flag != 0).  In the shared regime
-    // (gridDim.z > 1) the grid is the compact list of flagged tiles behind the count, not the tile grid.
     int tileX = (int)blockIdx.x, tileY = (int)blockIdx.y;
-    if (gridDim.z > 1) {
-        if (*flaggedTiles > (uint32_t)kShareBelow || blockIdx.x >= *flaggedTiles) return;
-        const int t = (int)flaggedTiles[1 + blockIdx.x];
+    int parts = 1, part = 0, slot = 0;
+    if (tileFlags) {
+        const uint32_t flagged = *flaggedTiles;
+        if (flagged == 0u) return;                                     // the usual case
+        int t;
+        if (flagged <= (uint32_t)kShareBelow) {
+            // (slot fastest: workgroups go round the XCDs in launch order, so the eight parts of a slot land on ONE XCD and
+            //  share the tile's search window in its L2 -- part fastest put them on eight and cost a quarter more, measured)
+            static_assert(kShareBelow % 8 == 0, "a slot's parts on one XCD");
+            parts = kFallbackParts; slot = (int)blockIdx.x % kShareBelow; part = (int)blockIdx.x / kShareBelow;
+            if ((uint32_t)slot >= flagged || part >= kFallbackParts) return;
+            t = (int)flaggedTiles[1 + slot];
+        } else {
+            t = (int)blockIdx.x;
+            if (t >= tiles || tileFlags[t] == 0u) return;
+        }
         tileY = t / tilesX; tileX = t - tileY * tilesX;
-    } else if (tileFlags) {
-        if ((flaggedTiles && *flaggedTiles <= (uint32_t)kShareBelow) || tileFlags[tileY * tilesX + tileX] == 0u) return;
     }
 
     constexpr int kOob = (int)0x80000000;        // a buffer offset that always fails the range check
@@ -199,11 +215,10 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
 #pragma unroll
     for (int i = 0; i < 8; ++i) { best[i] = 1e10f; bestCand[i] = 0; }   // motion.comp:23-24
 
-    // Many flagged tiles fill the chip by themselves: then each is one workgroup's again (sharing costs a fifth more
-    // in repeated set-up), and the vectors are written directly.
-    const int parts = (int)gridDim.z;      // (two launches, one per regime; the other one has returned above)
+    // (many flagged tiles fill the chip by themselves: then each is one workgroup's again -- sharing costs a fifth more in
+    //  repeated set-up -- and the vectors are written directly)
     const int perPart = (kCand + parts - 1) / parts;
-    const int candBegin = (int)blockIdx.z * perPart, candEnd = min(kCand, candBegin + perPart);
+    const int candBegin = part * perPart, candEnd = min(kCand, candBegin + perPart);
     phaseA(candBegin, candBegin & 1);
     __syncthreads();
 
@@ -254,15 +269,41 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
 
     const int py = ty0 + ry, px0 = tx0 + rxq * 8;
     if (parts > 1) {
+        // (row ry of every slot side by side: a tile's 64 rows of words lie 128 KB apart, over all memory channels -- the 4096
+        //  atomics a workgroup ends with, eight workgroups per tile, queued up on a few channels when a slot's 32 KB were contiguous)
+        unsigned long long *const words = merge + ((size_t)ry * (size_t)kShareBelow + (size_t)slot) * (size_t)kTW + (size_t)(rxq * 8);
+        // RETURNING atomics, and their results feed the barrier: a device-scope atomic has been performed where every XCD
+        // sees it by the time it returns, so "all of this workgroup's words are in" needs no fence -- __threadfence() writes
+        // back and invalidates the XCD's whole L2, and with one in every part's tail the workgroups still searching kept
+        // losing their windows (the launch 6 % longer, measured)
+        unsigned long long seen = 0ull;
         if (py < H) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 if (px0 + i < W)
-                    atomicMin(&merge[(size_t)py * mergeRowStride + (size_t)(px0 + i)],
-                              ((unsigned long long)__builtin_bit_cast(uint32_t, best[i]) << 32) | (unsigned long long)(uint32_t)bestCand[i]);
+                    seen |= atomicMin(&words[i], ((unsigned long long)__builtin_bit_cast(uint32_t, best[i]) << 32) | (unsigned long long)(uint32_t)bestCand[i]);
             }
         }
+        asm volatile("" : : "v"(seen));
+#ifdef LFG_DIAG_NO_MERGE_TAIL          // (timing experiment, wrong results: the parts leave without merging)
         return;
+#endif
+        // the part that arrives last (a counter per slot) writes the tile's vectors and leaves the slot's words all ones for
+        // the next call
+        __syncthreads();
+        if (tid == 0) sLast = atomicAdd(flaggedTiles + 1 + kShareBelow + slot, 1u) == (uint32_t)(parts - 1) ? 1u : 0u;
+        __syncthreads();
+        if (sLast == 0u) return;
+        if (py < H) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (px0 + i < W) {
+                    const unsigned long long word = __hip_atomic_load(&words[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&words[i], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    bestCand[i] = (int)(uint32_t)word;
+                }
+            }
+        }
     }
     if (py < H && px0 < W) {
         uint32_t o[4] = {0u, 0u, 0u, 0u};                             // 8 x (int8 dx, int8 dy)
@@ -306,8 +347,9 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
 // exact minimum while  S~(m) <= kRatio * min_j S~(j),  kRatio = 1 + 8e-5 >= (1+3.6e-5)/(1-3.6e-5) with room
 // for the rounding of the product.
 //
-//   motion_hint_kernel, motion_order_kernel   this call's visiting order: the SAD-best candidates of 256 sample
-//       blocks in front (most popular first), then a fixed pseudo-random order of the rest.
+//   motion_hint_kernel   this call's visiting order: the SAD-best candidates of 256 sample blocks in front (most popular
+//       first), then a fixed pseudo-random order of the rest (ordered by its last workgroup); it also clears the call's
+//       control area.
 //   motion_prefilter_kernel  a wave owns a 16-row segment of a 56 x 64 tile.  Per BATCH of up to 64 candidates (one
 //       per lane) a partial-distortion test drops every candidate whose distances at a lattice of block positions
 //       already exceed all of the segment's thresholds (one point per block, then 2 x 2 and 4 x 4 sums, over the column
@@ -1616,19 +1658,26 @@ __device__ __forceinline__ void prefilter_unit(
                         // otherwise evaluate the head of the order for its thresholds, eight evaluations in each of eight
                         // waves.  (Agent scope: the parts run on other XCDs.  Every word is some candidate's evaluated cost
                         // x kRatio, or a zero-cost word: a valid bound for its pixel in any part.)
+                        // They have to be in place before the entries that announce the segment.  Exchanges, not stores plus a
+                        // fence: an agent-scope atomic has been performed where every XCD sees it by the time it returns, and the
+                        // wave-wide test on the returned values below cannot run before all of them have -- whereas
+                        // __threadfence() writes back and invalidates this XCD's whole L2, once per handed-over segment (650 times
+                        // a launch on the moving-object frames), and every workgroup staging a window there pays for it.
                         uint32_t *const init = sp.dynInit + (size_t)(slot / kEntries) * (size_t)(kSeg * kPTW);
+                        uint32_t returned = 0u;
 #pragma unroll
                         for (int hb = 0; hb < 2; ++hb) {
 #pragma unroll
                             for (int i = 0; i < kRun; ++i) {
                                 const float fx = thr2[i].x, fy = thr2[i].y;
-                                __hip_atomic_store(init + (2 * i + hb) * 64 + lane, __builtin_bit_cast(uint32_t, hb ? fy : fx),     // (lane-major: whole lines)
-                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                returned |= atomicExch(init + (2 * i + hb) * 64 + lane, __builtin_bit_cast(uint32_t, hb ? fy : fx));     // (lane-major: whole lines)
                             }
                         }
-                        __threadfence();                               // before the entries that announce the segment
+                        asm volatile("" : "+v"(returned));
+                        if (__ballot(returned == 0x7FC12345u) == ~0ull) return 2;      // (never: a NaN pattern no threshold holds; what counts is that every lane's exchanges have returned)
                     }
                     if (lane == 0) {
+                        sp.openList[atomicAdd(sp.openCount, 1u)] = (uint32_t)(tile * (kPTH / kSeg) + seg);                 // (its parts leave it to the resolve kernel)
                         sp.segMap[tile * (kPTH / kSeg) + seg] = (4u * slot) | ((uint32_t)LFG_DYN_PARTS << 24) | (1u << 31);    // (read by the resolve kernel)
                         // the entry itself is the "slot filled" signal (never 0): an atomic, like the read that waits for it
                         for (uint32_t k = 0; k < kEntries; ++k)
@@ -2087,6 +2136,12 @@ __device__ __forceinline__ void prefilter_unit(
         }
     }
     if (thresholdsNeeded) writeThresholds();
+    // A segment that is left to the resolve kernel goes onto its list, once: by the wave that owns it (whole tiles), by the
+    // unit that holds the first part of the order (tiles shared between units), or -- segment units -- further down.
+    if (thresholdsNeeded && !gaveUp && !segUnit && chunk == 0 && lane == 0)
+        sp.openList[atomicAdd(sp.openCount, 1u)] = (uint32_t)(tile * (kPTH / kSeg) + seg);
+    if (segUnit && nChunks != 4 && !gaveUp && chunk == 0 && lane == 0)       // (eight parts, two workgroups: no pooled settling below)
+        sp.openList[atomicAdd(sp.openCount, 1u)] = (uint32_t)(tile * (kPTH / kSeg) + seg);
     // A segment unit does the same for its segment, its four waves pooling what each learnt about its part of the
     // candidate order: the tightest threshold of the four is the pixel's bound, every wave holds its own records
     // against it, and a pixel with exactly one survivor among all four (or a zero-cost candidate) is settled --
@@ -2196,7 +2251,10 @@ __device__ __forceinline__ void prefilter_unit(
         }
         if (__builtin_amdgcn_readfirstlane(__ballot(open) != 0ull) && lane == 0) *sOpen = 1u;
         __syncthreads();
-        if (tid == 0 && *sOpen == 0u) segDone[tile * (kPTH / kSeg) + seg] = 1u;
+        if (tid == 0) {
+            if (*sOpen == 0u) segDone[tile * (kPTH / kSeg) + seg] = 1u;
+            else sp.openList[atomicAdd(sp.openCount, 1u)] = (uint32_t)(tile * (kPTH / kSeg) + seg);
+        }
     }
 #ifdef LFG_MOTION_STAMPS
     if (lane == 0 && (fromQueue ? sp.units + unit : unit) < 8192)      // (the end of the unit with its epilogue)
@@ -2338,38 +2396,36 @@ __device__ float exact_cost(const uint8_t *__restrict__ prev, int prevPitch, con
     return diff;
 }
 
-#ifndef LFG_RESOLVE_WAVES
-#define LFG_RESOLVE_WAVES
-#endif
-__global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
+// The resolve kernel's launch: a fixed number of waves that share out the rows of the segments the prefilter left open -- the
+// compact list its units wrote as they ended (sp.openList, sp.openCount): item i = row i % 16 of open segment i / 16, lane =
+// pixel column of the tile (56 of 64 lanes).  Round 2 launched one workgroup
+// per 64 x 4 pixels of the frame -- 32,400 at 4K -- of which nine in ten read three flags and left: 51 us under a pan for ~550
+// segments with work.  Nothing waits for anything here: the list is complete when this launch starts.
+constexpr int kResolveGroups = 1024;
+__global__ __launch_bounds__(256) void motion_resolve_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int8_t *__restrict__ mv, int mvPitch, int W, int H, const Rec *__restrict__ list,
     const float *__restrict__ uminIn, const uint32_t *__restrict__ countIn, const uint32_t *__restrict__ tileFlags,
-    int tilesX, PrefilterPlan sp, const uint32_t *__restrict__ rank2scan, const uint32_t *__restrict__ segDone,
-    unsigned long long *__restrict__ mergeWords) {
-    // Blocks whose pixels the prefilter settled itself (see its last lines): the 64 x 4 pixels lie in one 16-row segment
-    // of one or two of its tiles.
-    {
-        const int y0 = (int)blockIdx.y * 4, x0 = (int)blockIdx.x * 64, x1 = min(x0 + 63, W - 1);
-        const int row = (y0 / kPTH) * sp.tilesX, seg = (y0 % kPTH) / kSeg;
-        // (three independent scalar loads, one wait: with `&&` they were a chain of three round trips, and nine blocks in
-        //  ten of a frame under a pan do nothing but this)
-        const uint32_t flag = tileFlags[(y0 / kTH) * tilesX + (int)blockIdx.x];  // (a flagged tile's pixels are preset below)
-        const uint32_t doneA = segDone[(row + x0 / kPTW) * (kPTH / kSeg) + seg], doneB = segDone[(row + x1 / kPTW) * (kPTH / kSeg) + seg];
-        if ((flag == 0u) & (doneA != 0u) & (doneB != 0u)) return;
-    }
+    int tilesX, PrefilterPlan sp, const uint32_t *__restrict__ rank2scan, const uint32_t *__restrict__ segDone) {
+    __shared__ float sDist[4][kB * kB];    // one block of distances per wave (cooperative exact evaluation)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // Rows are dealt out -- wave w takes items w, w + waves, ... -- not drawn with a counter: device-scope atomics on ONE address
+    // complete one every 14 ns (a draw per row and wave: 1.8 ms on a frame of noise, 56 us before the first wave of a frame
+    // with nothing to resolve has learnt that; a draw per segment and workgroup: the four rows at a time of a workgroup put
+    // four memory latencies in a row, 48 instead of 31 us under a pan -- all measured).
+    const uint32_t items = *sp.openCount * (uint32_t)kSeg;
+    for (uint32_t item = blockIdx.x * 4u + (uint32_t)wv; item < items; item += gridDim.x * 4u) {
+    const int kSegment = (int)sp.openList[item / (uint32_t)kSeg];
+    const int px = ((kSegment / (kPTH / kSeg)) % sp.tilesX) * kPTW + lane;
+    const int py = ((kSegment / (kPTH / kSeg)) / sp.tilesX) * kPTH + kSeg * (kSegment % (kPTH / kSeg)) + (int)(item % (uint32_t)kSeg);
 #ifdef LFG_MOTION_STAMPS
     const unsigned long long stampT0 = __builtin_amdgcn_s_memrealtime();
 #endif
     // Candidates are identified by their RANK in the tie order everywhere in the prefiltered path (lists, the
     // zero-cost encoding), so "smallest rank among equal costs" is the tie-break; rank2scan turns it into (dx, dy).
-    __shared__ float sDist[4][kB * kB];    // one block of distances per wave (cooperative exact evaluation)
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int px = blockIdx.x * 64 + lane;
-    const int py = blockIdx.y * 4 + wv;
     // No early exits: every lane stays for the cooperative part below.  `live` = this lane owns a pixel to resolve
     // (inside the image and not in a tile that goes through the exact kernel).
-    const bool inside = px < W && py < H;
+    const bool inside = lane < kPTW && px < W && py < H;
     const int cpx = min(px, W - 1), cpy = min(py, H - 1);
     // Everything a pixel of a whole tile usually needs -- threshold, count, first record -- is read up front, next to
     // the two table look-ups and independent of them: one memory latency for the common case instead of a chain of four.
@@ -2385,8 +2441,6 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
     // write them); this block got here because the other tile it touches has work left.
     const bool settledSeg = segDone[ptile * (kPTH / kSeg) + (cpy % kPTH) / kSeg] != 0u;
     const bool live = inside && flagged == 0u && !settledSeg;
-    // A flagged tile goes through the exact kernel in parts that meet in record 0 of the pixel's list (atomicMin).
-    if (inside && flagged != 0u) mergeWords[(size_t)cpy * ((size_t)kListK * (size_t)W / 2u) + (size_t)cpx] = ~0ull;   // (8 bytes per pixel: planes 0 and 1 of the row)
     // Where this pixel's records live: one list in the image-shaped arrays, or several lists (one per unit that
     // shared the tile's candidates) in the auxiliary arrays -- blocks of a tile's 64 rows for the units of the plan,
     // of a segment's 16 rows for a segment handed over at run time.  Record k of list c: recs[c * listStride + k * recStride].
@@ -2539,12 +2593,34 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
                              unorm8_to_float(byte2(ctex)), unorm8_to_float(byte3(ctex))};
         float bestV = __builtin_inff();
         uint32_t bestR = 0xFFFFFFFFu;
-        for (int c = 0; c < qLists; ++c) {
-            const uint32_t n = min(qCnts[(size_t)c * qThrStride], qDepth);
-            for (uint32_t k = 0; k < n; ++k) {
-                const Rec rec = qRecs[(size_t)c * qListStride + (size_t)k * qRecStride];    // same address in every lane
-                if (!(rec_cost_low(rec) <= qBound)) continue;
-                const int cscan = (int)rank2scan[rec_cand(rec)];
+        // The pixel's records, GATHERED: the lanes load the lists' counts (one per list), then 64 records per round -- lane j
+        // the j-th record of the lists laid end to end -- and the survivors' table entries; the loop below then takes the
+        // survivors out of the lanes.  (Round 2 walked list by list and record by record with the same address in every lane:
+        // a dependent memory round trip per RECORD, forty in a row for a pixel of a handed-over segment -- the rows that hold
+        // many such pixels set this kernel's duration on the occluded and unmatched frames.)
+        constexpr int kMaxLists = 8;
+        const uint32_t nMine = lane < qLists ? min(qCnts[(size_t)lane * qThrStride], qDepth) : 0u;
+        uint32_t nOf[kMaxLists], total = 0u;
+#pragma unroll
+        for (int c = 0; c < kMaxLists; ++c) { nOf[c] = (uint32_t)__builtin_amdgcn_readlane((int)nMine, c); total += nOf[c]; }
+        for (uint32_t base = 0u; base < total; base += 64u) {
+            uint32_t k = base + (uint32_t)lane, c = 0u;
+            const bool valid = k < total;
+#pragma unroll
+            for (int cc = 0; cc < kMaxLists - 1; ++cc) {
+                const bool beyond = c == (uint32_t)cc && k >= nOf[cc];
+                k -= beyond ? nOf[cc] : 0u;
+                c += beyond ? 1u : 0u;
+            }
+            const Rec recMine = valid ? qRecs[(size_t)c * qListStride + (size_t)k * qRecStride] : 0u;
+            const bool survives = valid && rec_cost_low(recMine) <= qBound;
+            const uint32_t scanMine = survives ? rank2scan[rec_cand(recMine)] : 0u;
+            unsigned long long m = __ballot(survives);
+            while (m != 0ull) {
+                const int bIdx = __builtin_ctzll(m);
+                m &= m - 1ull;
+                const Rec rec = (Rec)__builtin_amdgcn_readlane((int)recMine, bIdx);
+                const int cscan = __builtin_amdgcn_readlane((int)scanMine, bIdx);
                 const int dy = cscan / kSide - kR, dx = cscan % kSide - kR;
                 const int sx = cx + dx, sy = cy + dy;
                 uint32_t ptex = 0u;
@@ -2590,49 +2666,21 @@ __global__ __launch_bounds__(256) LFG_RESOLVE_WAVES void motion_resolve_kernel(
         atomicMin(&gResolveStats[9], stampT0); atomicMax(&gResolveStats[10], t2);
     }
 #endif
+    }   // items
 }
 
-// The vectors of the flagged tiles from the words their parts left in `merge`.
-__global__ __launch_bounds__(256) void motion_merge_kernel(
-    int8_t *__restrict__ mv, int mvPitch, int W, int H, const uint32_t *__restrict__ tileFlags,
-    const uint32_t *__restrict__ rank2scan, const unsigned long long *__restrict__ merge, size_t mergeRowStride,
-    const uint32_t *__restrict__ flaggedTiles, int tilesX) {
-    if (*flaggedTiles > (uint32_t)kShareBelow || blockIdx.x >= *flaggedTiles) return;
-    const int t = (int)flaggedTiles[1 + blockIdx.x], tileY = t / tilesX, tileX = t - tileY * tilesX;
-    const int px = tileX * kTW + (int)(threadIdx.x & 63);
-    if (px >= W) return;
-    for (int r = (int)(threadIdx.x >> 6); r < kTH; r += 4) {
-        const int py = tileY * kTH + r;
-        if (py >= H) break;
-        const int scan = (int)rank2scan[(uint32_t)merge[(size_t)py * mergeRowStride + (size_t)px]];
-        const int dyi = scan / kSide, dxi = scan - dyi * kSide;
-        int8_t *dst = mv + (size_t)py * (size_t)mvPitch + (size_t)px * 2u;
-        *reinterpret_cast<uint16_t *>(dst) = (uint16_t)(uint8_t)(int8_t)(dxi - kR) | (uint16_t)((uint16_t)(uint8_t)(int8_t)(dyi - kR) << 8);   // both components, one store
-    }
-}
-
-// merge == nullptr: every tile (tileFlags == nullptr) or the flagged ones, one workgroup each, vectors written directly.
-// Otherwise the flagged tiles in kFallbackParts parts through `merge` (preset to all ones for their pixels).
-constexpr int kFallbackParts = 8;
+// tileFlags == nullptr: the literal kernel for every tile.  Otherwise the second pass of the prefiltered path: one launch,
+// whatever was flagged (see the kernel).
 hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                     const lfg_frame &mv, const uint32_t *tileFlags, const uint32_t *rank2scan,
-                                    unsigned long long *merge, size_t mergeRowStride, const uint32_t *flaggedTiles) {
-    dim3 grid((curr.width + kTW - 1) / kTW, (curr.height + kTH - 1) / kTH, 1);
+                                    unsigned long long *merge, uint32_t *flaggedTiles) {
+    const int tilesX = ((int)curr.width + kTW - 1) / kTW, tilesY = ((int)curr.height + kTH - 1) / kTH;
+    const dim3 grid = tileFlags ? dim3((unsigned)std::max(tilesX * tilesY, kShareBelow * kFallbackParts), 1, 1)
+                                : dim3((unsigned)tilesX, (unsigned)tilesY, 1);
     hipLaunchKernelGGL(motion_tiled_8_16_kernel, grid, dim3(kNT), 0, s,
                        (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
                        (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, tileFlags, rank2scan,
-                       merge, mergeRowStride, flaggedTiles, (int)grid.x);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess || !merge) return e;
-    hipLaunchKernelGGL(motion_tiled_8_16_kernel, dim3(kShareBelow, 1, kFallbackParts), dim3(kNT), 0, s,
-                       (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
-                       (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, tileFlags, rank2scan,
-                       merge, mergeRowStride, flaggedTiles, (int)grid.x);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(motion_merge_kernel, dim3(kShareBelow), dim3(256), 0, s,
-                       (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, tileFlags, rank2scan,
-                       (const unsigned long long *)merge, mergeRowStride, flaggedTiles, (int)grid.x);
+                       merge, flaggedTiles, tilesX, tilesX * tilesY);
     return hipGetLastError();
 }
 
@@ -2651,14 +2699,15 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, int ri
     l.segDone = l.tileFlags + tiles * sizeof(uint32_t);
     l.segMap = l.segDone + ptiles * (kPTH / kSeg) * sizeof(uint32_t);
     l.queueCount = l.segMap + ptiles * (kPTH / kSeg) * sizeof(uint32_t);
-    // (+ the number of flagged tiles and the list of the first kShareBelow of them, + the prefilter's three unit counters)
-    l.ctrl = l.queueCount + (2 + kShareBelow) * sizeof(uint32_t);
+    // (+ the number of flagged tiles, the list of the first kShareBelow of them and a counter of arrived parts for each,
+    //  + the prefilter's three unit counters and the hint kernel's count of finished workgroups)
+    l.ctrl = l.queueCount + (2 + 2 * kShareBelow) * sizeof(uint32_t);
     // ... and the queue of segments handed over at run time (entries double as "slot filled" signals): up to a quarter
     // of the frame's segments, 2048 entries at most (a multiple of the entries one segment takes, so that a push either fits as
     // a whole or is refused as a whole; beyond that a segment is searched by the wave that owns it, as before).  One
     // memset clears everything from the tile flags to here.
     l.queueCap = (int)std::min<size_t>(2048, std::max<size_t>(LFG_DYN_PARTS / 4, ptiles * (kPTH / kSeg) / 4 / (LFG_DYN_PARTS / 4) * (LFG_DYN_PARTS / 4)));
-    l.queue = l.ctrl + 4 * sizeof(uint32_t);
+    l.queue = l.ctrl + 8 * sizeof(uint32_t);     // ctrl: [0..2] the prefilter's unit counters, [3] hint workgroups done, [4] open segments
     l.order = align(l.queue + (size_t)l.queueCap * sizeof(uint32_t));           // this call's hints and visiting order
     // work-unit tables and the auxiliary arrays of the shared tiles (see prefilter_plan): one 56 x 64 block per unit
     const PrefilterPlanHost plan = prefilter_plan(width, height, slots, rimSplit);
@@ -2675,7 +2724,12 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, int ri
     l.dynUmin = align(l.dynList + dynBlocks * kSeg * kPTW * kListDyn * sizeof(Rec));
     l.dynCount = align(l.dynUmin + dynBlocks * kSeg * kPTW * sizeof(float));
     l.dynInit = align(l.dynCount + dynBlocks * kSeg * kPTW * sizeof(uint32_t));
-    l.total = align(l.dynInit + (size_t)l.queueCap / (LFG_DYN_PARTS / 4) * kSeg * kPTW * sizeof(uint32_t));
+    // where the parts of a flagged tile meet (motion_tiled_8_16_kernel): kShareBelow slots of 64 x 64 words, all ones between calls
+    // the segments the prefilter leaves open, for the resolve kernel: one word per 16-row segment at most
+    l.openList = align(l.dynInit + (size_t)l.queueCap / (LFG_DYN_PARTS / 4) * kSeg * kPTW * sizeof(uint32_t));
+    l.merge = align(l.openList + ptiles * (kPTH / kSeg) * sizeof(uint32_t));
+    l.mergeBytes = (size_t)kShareBelow * kTW * kTH * sizeof(unsigned long long);
+    l.total = align(l.merge + l.mergeBytes);
     if (layout) *layout = l;
     return l.total;
 }
@@ -2819,7 +2873,7 @@ void motion_tables(bool intended, uint32_t *rank2scan, uint32_t *order32, uint32
 // The fewer running minima a pixel sees, the less the prefilter records.  Two tiny kernels put the candidates
 // that are likely to be the answer at the front of the visiting order of THIS call: motion_hint_kernel block-matches
 // 256 sample blocks (a 16 x 16 grid over the frame) with a plain SAD over all 1089 candidates and reports each
-// block's best; motion_order_kernel emits the most popular hint, zero motion, the other distinct hints, then the
+// block's best; its last workgroup (motion_order) emits the most popular hint, zero motion, the other distinct hints, then the
 // rest of the fixed pseudo-random order.  With a few dominant motions in the frame (a pan, a handful of objects) most pixels meet
 // their minimum within the first few candidates and close their thresholds at once.  The order only changes what
 // is recorded along the way: every candidate is still evaluated for every pixel and the results are identical.
@@ -2836,13 +2890,27 @@ constexpr int kHintWin = kB + 2 * kR;                // 40 x 40 texels of prev a
 #endif
 constexpr int kHintThreads = LFG_HINT_THREADS;
 
+__device__ void motion_order(const uint32_t *__restrict__ hints, const uint32_t *__restrict__ baseScan,
+                             const uint32_t *__restrict__ entryOfScan, uint32_t *__restrict__ order32,
+                             uint32_t *sOwner, uint32_t *sVotes, uint32_t *sWaveSum, uint32_t &sRunning, uint32_t &sTop);
+
+// ONE launch per call does three jobs (round 2: a memset, this kernel, and motion_order_kernel on one workgroup behind it):
+//   * every workgroup first clears its share of the call's control area (tile flags, segment marks and map, counters,
+//     queue: `clearWords` words from `clearFrom`, except the word that counts these workgroups) -- the prefilter launch
+//     behind this one is what reads them;
+//   * each workgroup block-matches one sample block;
+//   * the workgroup that finishes LAST (done: a counter) turns the 256 hints into this call's visiting order.
 __global__ __launch_bounds__(kHintThreads, kHintThreads <= 256 ? 4 : 1) void motion_hint_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
-    int W, int H, uint32_t *__restrict__ hints) {
+    int W, int H, uint32_t *__restrict__ hints, uint32_t *__restrict__ clearFrom, int clearWords, uint32_t *__restrict__ done,
+    const uint32_t *__restrict__ baseScan, const uint32_t *__restrict__ entryOfScan, uint32_t *__restrict__ order32) {
     __shared__ uint32_t sP[kHintWin * kHintWin];
     __shared__ uint32_t sC[kB * kB], sValid[kB * kB];
     __shared__ uint32_t sBest;
+    __shared__ uint32_t sOwner[kCand], sVotes[kCand], sWaveSum[kHints / 64], sRunning, sTop, sIsLast;
     const int tid = threadIdx.x;
+    for (int i = (int)blockIdx.x * kHintThreads + tid; i < clearWords; i += (int)gridDim.x * kHintThreads)
+        if (clearFrom + i != done) clearFrom[i] = 0u;
     const int gx = blockIdx.x % kHintGrid, gy = blockIdx.x / kHintGrid;
     const int bx = (2 * gx + 1) * W / (2 * kHintGrid) - kB / 2, by = (2 * gy + 1) * H / (2 * kHintGrid) - kB / 2;
     if (tid == 0) sBest = 0xFFFFFFFFu;
@@ -2888,17 +2956,26 @@ __global__ __launch_bounds__(kHintThreads, kHintThreads <= 256 ? 4 : 1) void mot
     }
     atomicMin(&sBest, best);
     __syncthreads();
-    if (tid == 0) hints[blockIdx.x] = sBest;           // best SAD << 11 | candidate (scan index)
+    // best SAD << 11 | candidate (scan index), for a reader on another XCD: an agent-scope store, then the count
+    // (an exchange, not a store: once it has returned the hint is where every XCD sees it, and the count -- which takes the
+    //  returned value as an operand -- cannot overtake it; no fence, whose L2 write-back and invalidation other lanes' kernels pay for)
+    if (tid == 0) {
+        const uint32_t before = atomicExch(&hints[blockIdx.x], sBest);
+        const uint32_t arrived = atomicAdd(done, 1u + (before & 0u));
+        sIsLast = arrived == gridDim.x - 1u ? 1u : 0u;
+        if (sIsLast) atomicExch(done, 0u);            // (for the next call: nobody else touches the word any more)
+    }
+    __syncthreads();
+    if (sIsLast == 0u) return;
+    static_assert(kHintThreads == kHints, "the ordering takes one hint per thread");
+    motion_order(hints, baseScan, entryOfScan, order32, sOwner, sVotes, sWaveSum, sRunning, sTop);
 }
 
-__global__ __launch_bounds__(kHints) void motion_order_kernel(
-    const uint32_t *__restrict__ hints, const uint32_t *__restrict__ baseScan,
-    const uint32_t *__restrict__ entryOfScan, uint32_t *__restrict__ order32) {
-    __shared__ uint32_t sOwner[kCand];               // lowest hint index that proposes this candidate
-    __shared__ uint32_t sVotes[kCand];               // how many sample blocks propose it
+// (sOwner: lowest hint index that proposes a candidate; sVotes: how many sample blocks propose it)
+__device__ void motion_order(const uint32_t *__restrict__ hints, const uint32_t *__restrict__ baseScan,
+                             const uint32_t *__restrict__ entryOfScan, uint32_t *__restrict__ order32,
+                             uint32_t *sOwner, uint32_t *sVotes, uint32_t *sWaveSum, uint32_t &sRunning, uint32_t &sTop) {
     constexpr int kWaves = kHints / 64;
-    __shared__ uint32_t sWaveSum[kWaves];
-    __shared__ uint32_t sRunning, sTop;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t zero = baseScan[0];               // zero motion
     for (int i = tid; i < kCand; i += kHints) { sOwner[i] = 0xFFFFFFFFu; sVotes[i] = 0u; }
@@ -2907,7 +2984,7 @@ __global__ __launch_bounds__(kHints) void motion_order_kernel(
     // Hints are taken in a scrambled order of the sample blocks: under a zoom or a rotation the hints vary smoothly
     // across the frame, and in raster order a pixel would see them approach its own motion -- one running minimum
     // after the other -- which is exactly what fills the lists.
-    const uint32_t hint = hints[(tid * 97 + 13) & (kHints - 1)];
+    const uint32_t hint = __hip_atomic_load(&hints[(tid * 97 + 13) & (kHints - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (written on other XCDs)
     const uint32_t mine = hint & 0x7FFu;
     // A sample block whose best SAD is 1020 or more has no candidate with a cost below 510 (a distance is at least
     // half the sum of its four absolute differences): such a segment would search in full.  Handing segments over
@@ -2985,25 +3062,32 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
     sp.dynUmin = reinterpret_cast<float *>(workspace + l.dynUmin);
     sp.dynCount = reinterpret_cast<uint32_t *>(workspace + l.dynCount);
     sp.dynInit = reinterpret_cast<uint32_t *>(workspace + l.dynInit);
+    sp.openList = reinterpret_cast<uint32_t *>(workspace + l.openList);
+    sp.openCount = reinterpret_cast<uint32_t *>(workspace + l.ctrl) + 4;
     uint32_t *segDone = reinterpret_cast<uint32_t *>(workspace + l.segDone);
-    hipError_t e = hipMemsetAsync(flags, 0, l.order - l.tileFlags, s);             // tile flags, segment marks and map, counters, queue
-    if (e != hipSuccess) return e;
-    if (useHints && curr.width >= 64u && curr.height >= 64u) {         // this call's visiting order
+    uint32_t *const ctrl = reinterpret_cast<uint32_t *>(workspace + l.ctrl);
+    hipError_t e = hipSuccess;
+    if (useHints && curr.width >= 64u && curr.height >= 64u) {
+        // this call's visiting order -- and the clearing of the call's control area (tile flags, segment marks and map,
+        // counters, queue), and the ordering: one launch (motion_hint_kernel)
         uint32_t *hints = reinterpret_cast<uint32_t *>(workspace + l.order);
         uint32_t *callOrder = hints + kHints;
         hipLaunchKernelGGL(motion_hint_kernel, dim3(kHints), dim3(kHintThreads), 0, s,
                            (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
-                           (int)curr.width, (int)curr.height, hints);
-        hipLaunchKernelGGL(motion_order_kernel, dim3(1), dim3(kHints), 0, s, hints, baseScan, entryOfScan, callOrder);
+                           (int)curr.width, (int)curr.height, hints, flags, (int)((l.order - l.tileFlags) / sizeof(uint32_t)), ctrl + 3,
+                           baseScan, entryOfScan, callOrder);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         order = callOrder;
+    } else {
+        e = hipMemsetAsync(flags, 0, l.order - l.tileFlags, s);         // (no hints: the fixed order; the area is cleared by a memset)
+        if (e != hipSuccess) return e;
     }
     const int groups = std::max(1, std::min(sp.units, l.slots > 0 ? l.slots : sp.units));
     hipLaunchKernelGGL(motion_prefilter_kernel, dim3(groups), dim3(kPNT), 0, s,
                        (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
                        (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, order, sp,
-                       (int8_t *)mv.data, (int)mv.pitch, rank2scan, segDone, reinterpret_cast<uint32_t *>(workspace + l.ctrl));
+                       (int8_t *)mv.data, (int)mv.pitch, rank2scan, segDone, ctrl);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
 #ifdef LFG_DIAG_NO_SLOW
@@ -3142,18 +3226,17 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
         }
     }
 #endif
-    hipLaunchKernelGGL(motion_resolve_kernel, dim3((curr.width + 63) / 64, (curr.height + 3) / 4), dim3(256), 0, s,
+    const int segments = sp.tilesX * (((int)curr.height + kPTH - 1) / kPTH) * (kPTH / kSeg);
+    hipLaunchKernelGGL(motion_resolve_kernel, dim3((unsigned)std::max(1, std::min(kResolveGroups, segments * (kSeg / 4)))), dim3(256), 0, s,
                        (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
-                       (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, sp, rank2scan, segDone,
-                       reinterpret_cast<unsigned long long *>(list));
+                       (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, sp, rank2scan, segDone);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-#ifdef LFG_DIAG_NO_FALLBACK             // (timing experiment: what the three launches that usually find nothing to do cost)
+#ifdef LFG_DIAG_NO_FALLBACK             // (timing experiment: what the launch that usually finds nothing to do costs)
     return hipSuccess;
 #endif
-    // (the flagged tiles' parts merge in record 0 of their pixels' lists, which nothing reads any more)
-    return launch_motion_tiled_8_16(s, prev, curr, mv, flags, rank2scan, reinterpret_cast<unsigned long long *>(list),
-                                    (size_t)kListK * (size_t)curr.width / 2u, sp.queueCount + 1);
+    return launch_motion_tiled_8_16(s, prev, curr, mv, flags, rank2scan, reinterpret_cast<unsigned long long *>(workspace + l.merge),
+                                    sp.queueCount + 1);
 }
 
 // Diagnostic: compares exact_sqrt with __builtin_sqrtf for every float whose bit pattern lies in
