@@ -151,7 +151,7 @@ int prefilter_slots();      // workgroups of the prefilter kernel the current de
 hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                           const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &layout, int units,
                                           const uint32_t *rank2scan, const uint32_t *order32,
-                                          const uint32_t *entryOfScan, const uint32_t *baseScan, bool useHints);
+                                          const uint32_t *entryOfScan, const uint32_t *baseScan, bool useHints, bool framesInFlight);
 hipError_t launch_motion_generic(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                  const lfg_frame &mv, int block_size, int radius, bool intended);
 hipError_t launch_interpolate(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,

@@ -347,8 +347,8 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
 // exact minimum while  S~(m) <= kRatio * min_j S~(j),  kRatio = 1 + 8e-5 >= (1+3.6e-5)/(1-3.6e-5) with room
 // for the rounding of the product.
 //
-//   motion_hint_kernel   this call's visiting order: the SAD-best candidates of 256 sample blocks in front (most popular
-//       first), then a fixed pseudo-random order of the rest (ordered by its last workgroup); it also clears the call's
+//   motion_hint_kernel, motion_order_kernel   this call's visiting order: the SAD-best candidates of 256 sample blocks in
+//       front (most popular first), then a fixed pseudo-random order of the rest; the hint kernel also clears the call's
 //       control area.
 //   motion_prefilter_kernel  a wave owns a 16-row segment of a 56 x 64 tile.  Per BATCH of up to 64 candidates (one
 //       per lane) a partial-distortion test drops every candidate whose distances at a lattice of block positions
@@ -1670,9 +1670,16 @@ __device__ __forceinline__ void prefilter_unit(
 #pragma unroll
                             for (int i = 0; i < kRun; ++i) {
                                 const float fx = thr2[i].x, fy = thr2[i].y;
+#ifdef LFG_DIAG_PUSH_FENCE             // (timing experiment: round 2's stores and fence)
+                                __hip_atomic_store(init + (2 * i + hb) * 64 + lane, __builtin_bit_cast(uint32_t, hb ? fy : fx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
                                 returned |= atomicExch(init + (2 * i + hb) * 64 + lane, __builtin_bit_cast(uint32_t, hb ? fy : fx));     // (lane-major: whole lines)
+#endif
                             }
                         }
+#ifdef LFG_DIAG_PUSH_FENCE
+                        __threadfence();
+#endif
                         asm volatile("" : "+v"(returned));
                         if (__ballot(returned == 0x7FC12345u) == ~0ull) return 2;      // (never: a NaN pattern no threshold holds; what counts is that every lane's exchanges have returned)
                     }
@@ -2409,12 +2416,20 @@ __global__ __launch_bounds__(256) void motion_resolve_kernel(
     int tilesX, PrefilterPlan sp, const uint32_t *__restrict__ rank2scan, const uint32_t *__restrict__ segDone) {
     __shared__ float sDist[4][kB * kB];    // one block of distances per wave (cooperative exact evaluation)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    // Rows are dealt out -- wave w takes items w, w + waves, ... -- not drawn with a counter: device-scope atomics on ONE address
-    // complete one every 14 ns (a draw per row and wave: 1.8 ms on a frame of noise, 56 us before the first wave of a frame
-    // with nothing to resolve has learnt that; a draw per segment and workgroup: the four rows at a time of a workgroup put
-    // four memory latencies in a row, 48 instead of 31 us under a pan -- all measured).
+    // How the rows get to the waves -- wave w takes items w, w + waves, ... -- is decided by the GRID (launch_motion_prefiltered_8_16):
+    //   * a context that runs one frame at a time launches kResolveGroups workgroups, and every row is dealt out: nothing but
+    //     these waves runs, they all start at once, and a frame's open rows are in flight together (19 us under a pan);
+    //   * a context with frames in flight launches one workgroup per four rows of the WORST case (every segment open), so
+    //     each wave has at most one row and the workgroups beyond the list's end leave after one scalar load: the hardware
+    //     dispatcher hands the rows to whatever slots the other frames' kernels free -- dealt out statically, a workgroup
+    //     that got its slot late held all its rows back (occluded frames 975 -> 915 frames/s with three frames in flight).
+    // Drawing rows with counters instead was measured and dropped: device-scope atomics AND loads on one line complete one
+    // every 14 ns -- one counter: 1.8 ms on a frame of noise, 56 us before the first wave of a frame with nothing to resolve
+    // has learnt that; 32 striped counters with a one-load look at all of them: 5 ms; a draw per segment and workgroup: four
+    // rows at a time put four memory latencies in a row (48 instead of 31 us under a pan).
     const uint32_t items = *sp.openCount * (uint32_t)kSeg;
     for (uint32_t item = blockIdx.x * 4u + (uint32_t)wv; item < items; item += gridDim.x * 4u) {
+    {
     const int kSegment = (int)sp.openList[item / (uint32_t)kSeg];
     const int px = ((kSegment / (kPTH / kSeg)) % sp.tilesX) * kPTW + lane;
     const int py = ((kSegment / (kPTH / kSeg)) / sp.tilesX) * kPTH + kSeg * (kSegment % (kPTH / kSeg)) + (int)(item % (uint32_t)kSeg);
@@ -2666,6 +2681,7 @@ __global__ __launch_bounds__(256) void motion_resolve_kernel(
         atomicMin(&gResolveStats[9], stampT0); atomicMax(&gResolveStats[10], t2);
     }
 #endif
+    }
     }   // items
 }
 
@@ -2707,7 +2723,7 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, int ri
     // a whole or is refused as a whole; beyond that a segment is searched by the wave that owns it, as before).  One
     // memset clears everything from the tile flags to here.
     l.queueCap = (int)std::min<size_t>(2048, std::max<size_t>(LFG_DYN_PARTS / 4, ptiles * (kPTH / kSeg) / 4 / (LFG_DYN_PARTS / 4) * (LFG_DYN_PARTS / 4)));
-    l.queue = l.ctrl + 8 * sizeof(uint32_t);     // ctrl: [0..2] the prefilter's unit counters, [3] hint workgroups done, [4] open segments
+    l.queue = l.ctrl + 8 * sizeof(uint32_t);     // ctrl: [0..2] the prefilter's unit counters, [4] open segments
     l.order = align(l.queue + (size_t)l.queueCap * sizeof(uint32_t));           // this call's hints and visiting order
     // work-unit tables and the auxiliary arrays of the shared tiles (see prefilter_plan): one 56 x 64 block per unit
     const PrefilterPlanHost plan = prefilter_plan(width, height, slots, rimSplit);
@@ -2873,7 +2889,7 @@ void motion_tables(bool intended, uint32_t *rank2scan, uint32_t *order32, uint32
 // The fewer running minima a pixel sees, the less the prefilter records.  Two tiny kernels put the candidates
 // that are likely to be the answer at the front of the visiting order of THIS call: motion_hint_kernel block-matches
 // 256 sample blocks (a 16 x 16 grid over the frame) with a plain SAD over all 1089 candidates and reports each
-// block's best; its last workgroup (motion_order) emits the most popular hint, zero motion, the other distinct hints, then the
+// block's best; motion_order_kernel emits the most popular hint, zero motion, the other distinct hints, then the
 // rest of the fixed pseudo-random order.  With a few dominant motions in the frame (a pan, a handful of objects) most pixels meet
 // their minimum within the first few candidates and close their thresholds at once.  The order only changes what
 // is recorded along the way: every candidate is still evaluated for every pixel and the results are identical.
@@ -2890,27 +2906,20 @@ constexpr int kHintWin = kB + 2 * kR;                // 40 x 40 texels of prev a
 #endif
 constexpr int kHintThreads = LFG_HINT_THREADS;
 
-__device__ void motion_order(const uint32_t *__restrict__ hints, const uint32_t *__restrict__ baseScan,
-                             const uint32_t *__restrict__ entryOfScan, uint32_t *__restrict__ order32,
-                             uint32_t *sOwner, uint32_t *sVotes, uint32_t *sWaveSum, uint32_t &sRunning, uint32_t &sTop);
-
-// ONE launch per call does three jobs (round 2: a memset, this kernel, and motion_order_kernel on one workgroup behind it):
-//   * every workgroup first clears its share of the call's control area (tile flags, segment marks and map, counters,
-//     queue: `clearWords` words from `clearFrom`, except the word that counts these workgroups) -- the prefilter launch
-//     behind this one is what reads them;
-//   * each workgroup block-matches one sample block;
-//   * the workgroup that finishes LAST (done: a counter) turns the 256 hints into this call's visiting order.
+// One launch does two jobs (round 2: a memset in front of it): every workgroup first clears its share of the call's control
+// area (tile flags, segment marks and map, counters, queue: `clearWords` words from `clearFrom`) -- the prefilter launch
+// behind this one is what reads them -- then block-matches one sample block.  The ordering of the 256 hints stays a launch of
+// its own (motion_order_kernel, one workgroup): folded into the workgroup that finishes last here it cost the occluded frames
+// 5 - 15 % with three frames in flight (983 -> 905 frames/s with its tables in LDS, which no longer fits beside two resident
+// prefilter workgroups; 837 with a 1.2 KB version that does) for 5 us of one call's latency.
 __global__ __launch_bounds__(kHintThreads, kHintThreads <= 256 ? 4 : 1) void motion_hint_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
-    int W, int H, uint32_t *__restrict__ hints, uint32_t *__restrict__ clearFrom, int clearWords, uint32_t *__restrict__ done,
-    const uint32_t *__restrict__ baseScan, const uint32_t *__restrict__ entryOfScan, uint32_t *__restrict__ order32) {
+    int W, int H, uint32_t *__restrict__ hints, uint32_t *__restrict__ clearFrom, int clearWords) {
     __shared__ uint32_t sP[kHintWin * kHintWin];
     __shared__ uint32_t sC[kB * kB], sValid[kB * kB];
     __shared__ uint32_t sBest;
-    __shared__ uint32_t sOwner[kCand], sVotes[kCand], sWaveSum[kHints / 64], sRunning, sTop, sIsLast;
     const int tid = threadIdx.x;
-    for (int i = (int)blockIdx.x * kHintThreads + tid; i < clearWords; i += (int)gridDim.x * kHintThreads)
-        if (clearFrom + i != done) clearFrom[i] = 0u;
+    for (int i = (int)blockIdx.x * kHintThreads + tid; i < clearWords; i += (int)gridDim.x * kHintThreads) clearFrom[i] = 0u;
     const int gx = blockIdx.x % kHintGrid, gy = blockIdx.x / kHintGrid;
     const int bx = (2 * gx + 1) * W / (2 * kHintGrid) - kB / 2, by = (2 * gy + 1) * H / (2 * kHintGrid) - kB / 2;
     if (tid == 0) sBest = 0xFFFFFFFFu;
@@ -2956,48 +2965,44 @@ __global__ __launch_bounds__(kHintThreads, kHintThreads <= 256 ? 4 : 1) void mot
     }
     atomicMin(&sBest, best);
     __syncthreads();
-    // best SAD << 11 | candidate (scan index), for a reader on another XCD: an agent-scope store, then the count
-    // (an exchange, not a store: once it has returned the hint is where every XCD sees it, and the count -- which takes the
-    //  returned value as an operand -- cannot overtake it; no fence, whose L2 write-back and invalidation other lanes' kernels pay for)
-    if (tid == 0) {
-        const uint32_t before = atomicExch(&hints[blockIdx.x], sBest);
-        const uint32_t arrived = atomicAdd(done, 1u + (before & 0u));
-        sIsLast = arrived == gridDim.x - 1u ? 1u : 0u;
-        if (sIsLast) atomicExch(done, 0u);            // (for the next call: nobody else touches the word any more)
-    }
-    __syncthreads();
-    if (sIsLast == 0u) return;
-    static_assert(kHintThreads == kHints, "the ordering takes one hint per thread");
-    motion_order(hints, baseScan, entryOfScan, order32, sOwner, sVotes, sWaveSum, sRunning, sTop);
+    if (tid == 0) hints[blockIdx.x] = sBest;           // best SAD << 11 | candidate (scan index)
 }
 
-// (sOwner: lowest hint index that proposes a candidate; sVotes: how many sample blocks propose it)
-__device__ void motion_order(const uint32_t *__restrict__ hints, const uint32_t *__restrict__ baseScan,
-                             const uint32_t *__restrict__ entryOfScan, uint32_t *__restrict__ order32,
-                             uint32_t *sOwner, uint32_t *sVotes, uint32_t *sWaveSum, uint32_t &sRunning, uint32_t &sTop) {
+// (sHint: the 256 hints, which every thread compares its own with -- who proposes it first, how many do; sProposed: one bit
+//  per candidate that some hint other than zero motion proposes)
+constexpr int kProposedWords = (kCand + 31) / 32;
+__global__ __launch_bounds__(kHints) void motion_order_kernel(
+    const uint32_t *__restrict__ hints, const uint32_t *__restrict__ baseScan,
+    const uint32_t *__restrict__ entryOfScan, uint32_t *__restrict__ order32) {
+    __shared__ uint32_t sHint[kHints], sProposed[kProposedWords], sWaveSum[kHints / 64], sRunning, sTop;
     constexpr int kWaves = kHints / 64;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t zero = baseScan[0];               // zero motion
-    for (int i = tid; i < kCand; i += kHints) { sOwner[i] = 0xFFFFFFFFu; sVotes[i] = 0u; }
-    if (tid == 0) sTop = 0u;
-    __syncthreads();
     // Hints are taken in a scrambled order of the sample blocks: under a zoom or a rotation the hints vary smoothly
     // across the frame, and in raster order a pixel would see them approach its own motion -- one running minimum
     // after the other -- which is exactly what fills the lists.
-    const uint32_t hint = __hip_atomic_load(&hints[(tid * 97 + 13) & (kHints - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (written on other XCDs)
+    const uint32_t hint = hints[(tid * 97 + 13) & (kHints - 1)];
     const uint32_t mine = hint & 0x7FFu;
+    sHint[tid] = mine;
+    for (int i = tid; i < kProposedWords; i += kHints) sProposed[i] = 0u;
+    if (tid == 0) sTop = 0u;
+    __syncthreads();
     // A sample block whose best SAD is 1020 or more has no candidate with a cost below 510 (a distance is at least
     // half the sum of its four absolute differences): such a segment would search in full.  Handing segments over
     // (motion_prefilter_kernel) pays when they are the exception; with a quarter of the samples unmatched it is off.
     const uint32_t unmatched = (uint32_t)__popcll(__ballot((hint >> 11) >= 1020u));
     if (lane == 0) sWaveSum[wv] = unmatched;
-    if (mine != zero) atomicMin(&sOwner[mine], (uint32_t)tid);
-    atomicAdd(&sVotes[mine], 1u);
-    __syncthreads();
+    uint32_t owner = (uint32_t)tid, votes = 0u;      // the first thread with my hint; how many have it
+    for (int j = 0; j < kHints; ++j) {
+        const bool same = sHint[j] == mine;          // (the same word in every lane: a broadcast read)
+        votes += same ? 1u : 0u;
+        owner = same ? min(owner, (uint32_t)j) : owner;
+    }
+    if (mine != zero) atomicOr(&sProposed[mine >> 5], 1u << (mine & 31u));
     // The most popular hint goes first: where it is the answer (a pan: nearly everywhere) the very first evaluation
     // closes the thresholds, and zero motion -- second -- already fails the cheap test instead of being recorded for
     // every pixel.  (Ties: the candidate earlier in scan order.)
-    atomicMax(&sTop, (sVotes[mine] << 11) | (uint32_t)(kCand - 1 - (int)mine));
+    atomicMax(&sTop, (votes << 11) | (uint32_t)(kCand - 1 - (int)mine));
     __syncthreads();
     const uint32_t top = (uint32_t)(kCand - 1) - (sTop & 0x7FFu);
     if (tid == 0) {
@@ -3026,19 +3031,19 @@ __device__ void motion_order(const uint32_t *__restrict__ hints, const uint32_t 
     uint32_t base[kRounds];                                            // this thread's entries of the fixed order, read up front
 #pragma unroll
     for (int k = 0; k < kRounds; ++k) base[k] = baseScan[min(1 + k * kHints + tid, kCand - 1)];
-    append(mine != zero && mine != top && sOwner[mine] == (uint32_t)tid, mine);       // the other distinct hints
+    append(mine != zero && mine != top && owner == (uint32_t)tid, mine);              // the other distinct hints
     if (tid == 0) order32[kCand + 1] = sRunning;                       // entries in front: top hint, zero motion, the other hints
 #pragma unroll
     for (int k = 0; k < kRounds; ++k) {                                // then everything no hint proposed
         const int e = 1 + k * kHints + tid;
-        append(e < kCand && sOwner[base[k]] == 0xFFFFFFFFu, base[k]);
+        append(e < kCand && ((sProposed[base[k] >> 5] >> (base[k] & 31u)) & 1u) == 0u, base[k]);
     }
 }
 
 hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                           const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &l, int units,
                                           const uint32_t *rank2scan, const uint32_t *order,
-                                          const uint32_t *entryOfScan, const uint32_t *baseScan, bool useHints) {
+                                          const uint32_t *entryOfScan, const uint32_t *baseScan, bool useHints, bool framesInFlight) {
     const int tilesX = ((int)curr.width + kTW - 1) / kTW;
     Rec *list = reinterpret_cast<Rec *>(workspace + l.list);
     float *umin = reinterpret_cast<float *>(workspace + l.umin);
@@ -3068,14 +3073,14 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
     uint32_t *const ctrl = reinterpret_cast<uint32_t *>(workspace + l.ctrl);
     hipError_t e = hipSuccess;
     if (useHints && curr.width >= 64u && curr.height >= 64u) {
-        // this call's visiting order -- and the clearing of the call's control area (tile flags, segment marks and map,
-        // counters, queue), and the ordering: one launch (motion_hint_kernel)
+        // this call's visiting order (motion_hint_kernel, which also clears the call's control area -- tile flags, segment
+        // marks and map, counters, queue -- and motion_order_kernel)
         uint32_t *hints = reinterpret_cast<uint32_t *>(workspace + l.order);
         uint32_t *callOrder = hints + kHints;
         hipLaunchKernelGGL(motion_hint_kernel, dim3(kHints), dim3(kHintThreads), 0, s,
                            (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
-                           (int)curr.width, (int)curr.height, hints, flags, (int)((l.order - l.tileFlags) / sizeof(uint32_t)), ctrl + 3,
-                           baseScan, entryOfScan, callOrder);
+                           (int)curr.width, (int)curr.height, hints, flags, (int)((l.order - l.tileFlags) / sizeof(uint32_t)));
+        hipLaunchKernelGGL(motion_order_kernel, dim3(1), dim3(kHints), 0, s, hints, baseScan, entryOfScan, callOrder);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         order = callOrder;
@@ -3227,7 +3232,8 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
     }
 #endif
     const int segments = sp.tilesX * (((int)curr.height + kPTH - 1) / kPTH) * (kPTH / kSeg);
-    hipLaunchKernelGGL(motion_resolve_kernel, dim3((unsigned)std::max(1, std::min(kResolveGroups, segments * (kSeg / 4)))), dim3(256), 0, s,
+    const int resolveGroups = framesInFlight ? segments * (kSeg / 4) : std::min(kResolveGroups, segments * (kSeg / 4));
+    hipLaunchKernelGGL(motion_resolve_kernel, dim3((unsigned)std::max(1, resolveGroups)), dim3(256), 0, s,
                        (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
                        (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, sp, rank2scan, segDone);
     e = hipGetLastError();
