@@ -25,17 +25,30 @@ template <bool INTENDED>
 __global__ __launch_bounds__(256) void interpolate_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     const int8_t *__restrict__ mv, int mvPitch, uint8_t *__restrict__ out, int outPitch,
-    int W, int H, float t) {
+    int W, int H, float t, const float *__restrict__ uvxTable, const float *__restrict__ uvyTable) {
     const int qx = blockIdx.x * 64 + (threadIdx.x & 63);         // group of four pixels
     const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int px0 = qx * 4;
     if (px0 >= W || py >= H) return;
-    const float uvy = ((float)py + 0.5f) / (float)H;
+    // ((float)p + 0.5f) / (float)size, interpolate.comp:30, from the host's tables (lfg_internal.hpp: UvTable; the tables are
+    // padded to whole groups of four)
+    const float uvy = uvyTable[py];
+    const float4 uvx4 = *reinterpret_cast<const float4 *>(uvxTable + px0);
+    const float uvxOf[4] = {uvx4.x, uvx4.y, uvx4.z, uvx4.w};
     const int8_t *mrow = mv + (size_t)py * (size_t)mvPitch;
     uint8_t *orow = out + (size_t)py * (size_t)outPitch;
     const bool full = (px0 + 3 < W) && ((mvPitch & 7) == 0) && ((outPitch & 15) == 0);
 
     int8_t m[8];
+#ifdef LFG_DIAG_MV_UNIFORM             // (timing experiment, DESIGN.md 4.4: what reading the vectors costs -- every pixel takes the
+                                       //  vector of the frame's centre, one scalar load; right for the benchmark's pan but for its rim)
+    if (true) {
+        const int8_t *centre = mv + (size_t)(H / 2) * (size_t)mvPitch + (size_t)(W / 2) * 2u;
+        const int8_t cx = centre[0], cy = centre[1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { m[2 * i] = cx; m[2 * i + 1] = cy; }
+    } else
+#endif
     if (full) {
         const uint2 mm = *reinterpret_cast<const uint2 *>(mrow + (size_t)px0 * 2u);
         m[0] = (int8_t)(mm.x & 0xff); m[1] = (int8_t)((mm.x >> 8) & 0xff);
@@ -53,8 +66,7 @@ __global__ __launch_bounds__(256) void interpolate_kernel(
     uint32_t o[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int px = px0 + i;
-        const float uvx = ((float)px + 0.5f) / (float)W;
+        const float uvx = uvxOf[i];
         float mx = (float)m[2 * i], my = (float)m[2 * i + 1];
         if (INTENDED) { mx = mx / (float)W; my = my / (float)H; }
         const V4 p = sample_with_motion(prev, W, H, prevPitch, uvx, uvy, mx, my, -t);
@@ -70,19 +82,19 @@ __global__ __launch_bounds__(256) void interpolate_kernel(
 }
 
 hipError_t launch_interpolate(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
-                              const lfg_frame &mv, const lfg_frame &out, float factor, bool intended) {
+                              const lfg_frame &mv, const lfg_frame &out, float factor, bool intended, const float *uvx, const float *uvy) {
     const int quads = ((int)out.width + 3) / 4;
     dim3 grid((quads + 63) / 64, (out.height + 3) / 4);
     if (intended)
         hipLaunchKernelGGL(interpolate_kernel<true>, grid, dim3(256), 0, s,
                            (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
                            (const int8_t *)mv.data, (int)mv.pitch, (uint8_t *)out.data, (int)out.pitch,
-                           (int)out.width, (int)out.height, factor);
+                           (int)out.width, (int)out.height, factor, uvx, uvy);
     else
         hipLaunchKernelGGL(interpolate_kernel<false>, grid, dim3(256), 0, s,
                            (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
                            (const int8_t *)mv.data, (int)mv.pitch, (uint8_t *)out.data, (int)out.pitch,
-                           (int)out.width, (int)out.height, factor);
+                           (int)out.width, (int)out.height, factor, uvx, uvy);
     return hipGetLastError();
 }
 
@@ -105,12 +117,15 @@ struct MultiTargets {
 template <int N, bool INTENDED>
 __global__ __launch_bounds__(256) void interpolate_multi_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
-    const int8_t *__restrict__ mv, int mvPitch, MultiTargets tg, int W, int H, bool wideStores) {
+    const int8_t *__restrict__ mv, int mvPitch, MultiTargets tg, int W, int H, bool wideStores,
+    const float *__restrict__ uvxTable, const float *__restrict__ uvyTable) {
     const int qx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int px0 = qx * 4;
     if (px0 >= W || py >= H) return;
-    const float uvy = ((float)py + 0.5f) / (float)H;
+    const float uvy = uvyTable[py];
+    const float4 uvx4 = *reinterpret_cast<const float4 *>(uvxTable + px0);
+    const float uvxOf[4] = {uvx4.x, uvx4.y, uvx4.z, uvx4.w};
     const int8_t *mrow = mv + (size_t)py * (size_t)mvPitch;
     const bool full = (px0 + 3 < W) && ((mvPitch & 7) == 0) && wideStores;
 
@@ -132,8 +147,7 @@ __global__ __launch_bounds__(256) void interpolate_multi_kernel(
     uint32_t o[N][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int px = px0 + i;
-        const float uvx = ((float)px + 0.5f) / (float)W;
+        const float uvx = uvxOf[i];
         float mx = (float)m[2 * i], my = (float)m[2 * i + 1];
         if (INTENDED) { mx = mx / (float)W; my = my / (float)H; }
         if (mx == 0.0f && my == 0.0f) {                   // the sample positions do not depend on t
@@ -168,27 +182,28 @@ __global__ __launch_bounds__(256) void interpolate_multi_kernel(
 
 template <int N>
 static void launch_multi_n(hipStream_t s, dim3 grid, const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv,
-                           const MultiTargets &tg, int W, int H, bool wide, bool intended) {
+                           const MultiTargets &tg, int W, int H, bool wide, bool intended, const float *uvx, const float *uvy) {
     if (intended)
         hipLaunchKernelGGL((interpolate_multi_kernel<N, true>), grid, dim3(256), 0, s,
                            (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
-                           (const int8_t *)mv.data, (int)mv.pitch, tg, W, H, wide);
+                           (const int8_t *)mv.data, (int)mv.pitch, tg, W, H, wide, uvx, uvy);
     else
         hipLaunchKernelGGL((interpolate_multi_kernel<N, false>), grid, dim3(256), 0, s,
                            (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
-                           (const int8_t *)mv.data, (int)mv.pitch, tg, W, H, wide);
+                           (const int8_t *)mv.data, (int)mv.pitch, tg, W, H, wide, uvx, uvy);
 }
 
 // `count` frames from one pass per group of up to kMaxMulti factors (a single factor takes interpolate_kernel).
 hipError_t launch_interpolate_multi(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv,
-                                    const lfg_frame *const *outs, const float *factors, int count, bool intended) {
+                                    const lfg_frame *const *outs, const float *factors, int count, bool intended,
+                                    const float *uvx, const float *uvy) {
     const int W = (int)curr.width, H = (int)curr.height;
     const int quads = (W + 3) / 4;
     dim3 grid((quads + 63) / 64, (H + 3) / 4);
     for (int first = 0; first < count; first += kMaxMulti) {
         const int n = count - first < kMaxMulti ? count - first : kMaxMulti;
         if (n == 1) {
-            hipError_t e = launch_interpolate(s, prev, curr, mv, *outs[first], factors[first], intended);
+            hipError_t e = launch_interpolate(s, prev, curr, mv, *outs[first], factors[first], intended, uvx, uvy);
             if (e != hipSuccess) return e;
             continue;
         }
@@ -200,9 +215,9 @@ hipError_t launch_interpolate_multi(hipStream_t s, const lfg_frame &prev, const 
             wide = wide && (o.pitch % 16u == 0) && ((uintptr_t)o.data % 16u == 0);
         }
         switch (n) {
-            case 2: launch_multi_n<2>(s, grid, prev, curr, mv, tg, W, H, wide, intended); break;
-            case 3: launch_multi_n<3>(s, grid, prev, curr, mv, tg, W, H, wide, intended); break;
-            default: launch_multi_n<4>(s, grid, prev, curr, mv, tg, W, H, wide, intended); break;
+            case 2: launch_multi_n<2>(s, grid, prev, curr, mv, tg, W, H, wide, intended, uvx, uvy); break;
+            case 3: launch_multi_n<3>(s, grid, prev, curr, mv, tg, W, H, wide, intended, uvx, uvy); break;
+            default: launch_multi_n<4>(s, grid, prev, curr, mv, tg, W, H, wide, intended, uvx, uvy); break;
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;

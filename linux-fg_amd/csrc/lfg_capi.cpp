@@ -136,6 +136,27 @@ hipError_t sync_lanes(lfg_context *ctx) {
     return e;
 }
 
+// uv table of one axis length (lfg_internal.hpp: UvTable); a handful of sizes per context, kept until it goes.
+int build_uv_table(lfg_context *ctx, int size, const float **out) {
+    for (auto &t : ctx->uv_tables)
+        if (t.size == size) { *out = t.d_uv; return LFG_OK; }
+    std::vector<float> uv(((size_t)size + 3u) & ~(size_t)3u, 0.0f);
+    for (int p = 0; p < size; ++p) uv[(size_t)p] = ((float)p + 0.5f) / (float)size;      // interpolate.comp:30
+    lfg::UvTable t;
+    t.size = size;
+    LFG_HIP(ctx, hipMalloc((void **)&t.d_uv, uv.size() * sizeof(float)));
+    const hipError_t e = hipMemcpy(t.d_uv, uv.data(), uv.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(t.d_uv); return fail_hip(ctx, e, "hipMemcpy(uv table)"); }
+    if (ctx->uv_tables.size() >= 16) {             // bounded: the oldest goes (a queued kernel may still read it)
+        (void)sync_lanes(ctx);
+        (void)hipFree(ctx->uv_tables.front().d_uv);
+        ctx->uv_tables.erase(ctx->uv_tables.begin());
+    }
+    ctx->uv_tables.push_back(t);
+    *out = t.d_uv;
+    return LFG_OK;
+}
+
 // Bounded cache: called at the top of lfg_scale, before any table pointer is taken, so the two
 // lookups that follow can never evict each other.
 void trim_axis_tables(lfg_context *ctx) {
@@ -336,6 +357,7 @@ LFG_EXPORT void lfg_context_destroy(lfg_context *ctx) {
     for (auto &s : ctx->prof_pending) { (void)hipEventDestroy(s.begin); (void)hipEventDestroy(s.end); }
     for (auto &p : ctx->prof_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto &t : ctx->tables) { (void)hipFree(t.d_start); (void)hipFree(t.d_weight); (void)hipFree(t.d_class); (void)hipFree(t.d_palette); }
+    for (auto &t : ctx->uv_tables) (void)hipFree(t.d_uv);
     if (ctx->mv_tmp.data && ctx->mv_tmp.owned) (void)hipFree(ctx->mv_tmp.data);
     if (ctx->mid_tmp.data && ctx->mid_tmp.owned) (void)hipFree(ctx->mid_tmp.data);
     if (ctx->motion_tables) (void)hipFree(ctx->motion_tables);
@@ -702,7 +724,26 @@ LFG_EXPORT int lfg_motion_last_stats(lfg_context *ctx, uint32_t *out_tiles, uint
         std::vector<uint32_t> dc(blocks * per);
         if (!dc.empty()) LFG_HIP(ctx, hipMemcpy(dc.data(), ctx->motion_ws + ctx->motion_ws_layout.dynCount, dc.size() * 4, hipMemcpyDeviceToHost));
         size_t hist[40] = {0};
-        for (size_t i = 0; i < dc.size(); ++i) { ++hist[std::min<uint32_t>(dc[i], 39u)]; if (dc[i] > 14u) fprintf(stderr, "lfg: dyn list block %zu (part %zu of its segment) pixel %zu: %u records\n", i / per, (i / per) % 8u, i % per, dc[i]); }
+        int dumped = 0;
+        const uint32_t deep = getenv("LFG_DEBUG_DYN_DEEP") ? (uint32_t)atoi(getenv("LFG_DEBUG_DYN_DEEP")) : 14u;
+        for (size_t i = 0; i < dc.size(); ++i) {
+            ++hist[std::min<uint32_t>(dc[i], 39u)];
+            if (dc[i] > deep) {
+                fprintf(stderr, "lfg: dyn list block %zu (part %zu of its segment) pixel %zu (row %zu, column %zu): %u records\n", i / per, (i / per) % 8u, i % per, (i % per) / 56u, (i % per) % 56u, dc[i]);
+                if (dumped++ < 6) {      // the records themselves: lower bound of the cost and the candidate's rank, in the order they were recorded
+                    const size_t blk = i / per, row = (i % per) / 56u, col = (i % per) % 56u;
+                    const int K = ctx->motion_ws_layout.listDyn;
+                    for (int k = 0; k < std::min<int>((int)dc[i], K); ++k) {
+                        uint32_t rec = 0; float thr = 0.f;
+                        (void)hipMemcpy(&rec, ctx->motion_ws + ctx->motion_ws_layout.dynList + (((blk * 16u + row) * (size_t)K + (size_t)k) * 56u + col) * 4u, 4, hipMemcpyDeviceToHost);
+                        (void)hipMemcpy(&thr, ctx->motion_ws + ctx->motion_ws_layout.dynUmin + ((blk * 16u + row) * 56u + col) * 4u, 4, hipMemcpyDeviceToHost);
+                        const uint32_t bits = (rec >> 11) << 10; float c; memcpy(&c, &bits, 4);
+                        fprintf(stderr, "      record %2d: cost >= %.3f rank %4u (dx %+d, dy %+d)%s\n", k, c, rec & 0x7FFu, (int)((rec & 0x7FFu) % 33u) - 16, (int)((rec & 0x7FFu) / 33u) - 16, k == 0 ? "" : "");
+                        if (k + 1 == std::min<int>((int)dc[i], K)) fprintf(stderr, "      final threshold %.3f\n", thr);
+                    }
+                }
+            }
+        }
         {   // which segments under the flagged tiles were handed over
             const uint32_t ptx = (ctx->motion_ws_w + 55u) / 56u, pty = (ctx->motion_ws_h + 63u) / 64u;
             std::vector<uint32_t> sm((size_t)ptx * pty * 4u);
@@ -771,8 +812,12 @@ LFG_EXPORT int lfg_interpolate(lfg_context *ctx, const lfg_frame *prev, const lf
         return fail(ctx, LFG_ERR_INVALID, "lfg_interpolate: row pitch not a multiple of the pixel size");
     if (out->data == prev->data || out->data == curr->data)
         return fail(ctx, LFG_ERR_INVALID, "lfg_interpolate: output aliases an input");
+    const float *uvx = nullptr, *uvy = nullptr;
+    int rc = build_uv_table(ctx, (int)curr->width, &uvx);
+    if (rc == LFG_OK) rc = build_uv_table(ctx, (int)curr->height, &uvy);
+    if (rc != LFG_OK) return rc;
     StageTimer timer(ctx, LFG_STAGE_INTERPOLATE);
-    hipError_t e = lfg::launch_interpolate(ctx->stream, *prev, *curr, *mv, *out, factor, ctx->semantics != 0);
+    hipError_t e = lfg::launch_interpolate(ctx->stream, *prev, *curr, *mv, *out, factor, ctx->semantics != 0, uvx, uvy);
     if (e != hipSuccess) return fail_hip(ctx, e, "interpolate kernel launch");
     return LFG_OK;
 }
@@ -812,8 +857,12 @@ LFG_EXPORT int lfg_interpolate_multi(lfg_context *ctx, const lfg_frame *prev, co
         for (uint32_t j = 0; j < i; ++j)
             if (outs[j]->data == o->data) return fail(ctx, LFG_ERR_INVALID, "lfg_interpolate_multi: two outputs alias each other");
     }
+    const float *uvx = nullptr, *uvy = nullptr;
+    int rc = build_uv_table(ctx, (int)curr->width, &uvx);
+    if (rc == LFG_OK) rc = build_uv_table(ctx, (int)curr->height, &uvy);
+    if (rc != LFG_OK) return rc;
     StageTimer timer(ctx, LFG_STAGE_INTERPOLATE);
-    hipError_t e = lfg::launch_interpolate_multi(ctx->stream, *prev, *curr, *mv, outs, factors, (int)count, ctx->semantics != 0);
+    hipError_t e = lfg::launch_interpolate_multi(ctx->stream, *prev, *curr, *mv, outs, factors, (int)count, ctx->semantics != 0, uvx, uvy);
     if (e != hipSuccess) return fail_hip(ctx, e, "interpolate kernel launch");
     return LFG_OK;
 }

@@ -34,8 +34,16 @@ struct AxisTable {
     int strips_per_xcd = 0;
 };
 
+// uv[p] = ((float)p + 0.5f) / (float)size for p = 0 .. size - 1 (shaders/interpolate.comp:30): the normalised coordinate of a
+// pixel centre depends on its column (row) alone, so the interpolate kernels read it from a table built once per size on the
+// host -- the same fp32 division, bit for bit -- instead of five IEEE divisions per thread (the kernel was VALU-bound on them).
+struct UvTable {
+    int size = 0;
+    float *d_uv = nullptr;        // [size rounded up to 4]
+};
+
 struct MotionWorkspaceLayout { size_t list, umin, count, tileFlags, segDone, segMap, queueCount, ctrl, order, plan, auxList, auxUmin, auxCount,
-                               queue, dynList, dynUmin, dynCount, dynInit, openList, merge, mergeBytes, total; int queueCap, slots, rimSplit; };
+                               queue, dynList, dynUmin, dynCount, dynInit, openList, merge, mergeBytes, total; int queueCap, slots, rimSplit, listMain, listAux, listDyn; };
 // Work units of the motion prefilter (motion.hip: prefilter_plan).  A unit is a 56 x 64 tile, or one of nChunks
 // contiguous parts of a tile's candidate order, or one 16-row segment of a tile with its four waves on four parts of
 // the order; parts have private lists in the aux arrays (merged by the resolve kernel).
@@ -96,6 +104,7 @@ struct lfg_context {
     hipStream_t stream = nullptr;
     std::string error;
     std::vector<lfg::AxisTable> tables;       // small cache, linear search
+    std::vector<lfg::UvTable> uv_tables;      // likewise (interpolate)
     lfg_frame mv_tmp{};                        // temporary of lfg_interpolate_frames
     lfg_frame mid_tmp{};                       // temporary of lfg_interpolate_scale where the fused kernel does not apply
     // prefiltered motion path: scratch for one frame size, grown on demand
@@ -155,9 +164,10 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
 hipError_t launch_motion_generic(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                  const lfg_frame &mv, int block_size, int radius, bool intended);
 hipError_t launch_interpolate(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
-                              const lfg_frame &mv, const lfg_frame &out, float factor, bool intended);
+                              const lfg_frame &mv, const lfg_frame &out, float factor, bool intended, const float *uvx, const float *uvy);
 hipError_t launch_interpolate_multi(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv,
-                                    const lfg_frame *const *outs, const float *factors, int count, bool intended);
+                                    const lfg_frame *const *outs, const float *factors, int count, bool intended,
+                                    const float *uvx, const float *uvy);
 hipError_t launch_mv_export(hipStream_t s, const lfg_frame &mv, float *rgba32f);
 hipError_t launch_sqrt_selftest(hipStream_t s, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *d_mismatch);
 

@@ -2127,7 +2127,11 @@ __device__ __forceinline__ void prefilter_unit(
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) {
                 const int row = 2 * rr + half, py = ty0 + kSeg * seg + row, px = tx0 + 2 * d;
+#ifdef LFG_DIAG_NO_MV_STORE            // (timing experiment, wrong results: what writing the settled segments' vectors costs)
+                if (false) {
+#else
                 if (laneE < 56 && py < H && px < W) {
+#endif
                     const uint32_t two = *reinterpret_cast<const uint32_t *>(rows + row * kPTW + 2 * d);
                     int8_t *dst = mv + (size_t)py * (size_t)mvPitch + (size_t)px * 2u;
                     if (wide && px + 1 < W) *reinterpret_cast<uint32_t *>(dst) = two;
@@ -2737,6 +2741,7 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, int ri
     l.dynList = align(l.auxCount + auxUnits * kPTH * kPTW * sizeof(uint32_t));
     l.slots = slots;
     l.rimSplit = rimSplit;
+    l.listMain = kListK; l.listAux = kListAux; l.listDyn = kListDyn;
     l.dynUmin = align(l.dynList + dynBlocks * kSeg * kPTW * kListDyn * sizeof(Rec));
     l.dynCount = align(l.dynUmin + dynBlocks * kSeg * kPTW * sizeof(float));
     l.dynInit = align(l.dynCount + dynBlocks * kSeg * kPTW * sizeof(uint32_t));

@@ -7,6 +7,11 @@ C=$R/linux-fg_amd/csrc
 mkdir -p $R/build_variants
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fvisibility=hidden -I$R/include -Wall -Wno-unused-function"
 /opt/rocm/bin/hipcc $FLAGS "$@" -c ${MOTION_SRC:-$C/motion.hip} -o /tmp/motion_$name.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/build_variants/lib_$name.so $C/lfg_capi.cpp.o $C/lfg_comm.cpp.o $C/scale.hip.o $C/interpolate.hip.o /tmp/motion_$name.o -ldl
+INTERP=$C/interpolate.hip.o
+if [ -n "$ALSO_INTERPOLATE" ]; then     # the same flags for interpolate.hip (diagnostic switches that live there)
+  /opt/rocm/bin/hipcc $FLAGS "$@" -c $C/interpolate.hip -o /tmp/interpolate_$name.o
+  INTERP=/tmp/interpolate_$name.o
+fi
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/build_variants/lib_$name.so $C/lfg_capi.cpp.o $C/lfg_comm.cpp.o $C/scale.hip.o $INTERP /tmp/motion_$name.o -ldl
 python3 $C/check_store_hazard.py $R/build_variants/lib_$name.so     # the same machine-code check as the product build
 echo built build_variants/lib_$name.so
