@@ -461,6 +461,61 @@ def test_motion_full_hd_both_modes_against_the_oracle(ctx, oracle):
     assert (inner[..., 0] == 5).all() and (inner[..., 1] == -9).all()
 
 
+def _uhd_mixture():
+    """3840x2160 pair of the benchmark's kind (a 1080p pan, both frames upscaled 2x by the device's own Lanczos kernel would be
+    the real thing; here the frames are synthesised at 4K directly so that the oracle and the kernels see the same bytes
+    without a scale stage in between) with everything the sweep's contents hold, each in a known place: a pan, a band of
+    sensor noise, patches of fresh noise (hand-over, full search), patches that move on their own, a static flat area and a
+    flat area one grey level apart (fallback tiles), and one of each at an image border."""
+    W, H = 3840, 2160
+    prev = synth.make_prev(W, H, seed=synth.BASE_SEED + 2160)
+    curr = synth.translate(prev, (6, -4), synth.BASE_SEED + 2160)
+    n = synth.noise_bytes(W, H, 161803) % 5
+    noisy = np.clip(curr.astype(np.int16) + n.astype(np.int16) - 2, 0, 255).astype(np.uint8)
+    curr[900:1100] = noisy[900:1100]
+    fresh = synth.noise_bytes(W, H, 577215)
+    for (x0, y0, w, h) in [(400, 300, 260, 150), (2500, 1500, 96, 300), (3700, 1900, 140, 260), (0, 1300, 50, 200)]:
+        curr[y0:y0 + h, x0:x0 + w] = fresh[y0:y0 + h, x0:x0 + w]
+    for (x0, y0, w, h, dx, dy) in [(1200, 200, 300, 160, 9, -5), (2900, 600, 180, 260, -13, 7), (1700, 1800, 400, 120, 3, 14)]:
+        curr[y0:y0 + h, x0:x0 + w] = prev[y0 - dy:y0 - dy + h, x0 - dx:x0 - dx + w]
+    prev[1250:1420, 300:800] = 37; curr[1250:1420, 300:800] = 37                 # static flat area
+    prev[1600:1690, 2200:2340] = 50; curr[1600:1690, 2200:2340] = 51             # fade patch in the interior
+    prev[0:80, 3000:3150] = 200; curr[0:80, 3000:3150] = 201                     # fade patch on the top border
+    return prev, curr
+
+
+def test_motion_4k_mixture_regions_against_the_oracle(ctx, oracle):
+    """BASELINE config 3's size against the ORACLE itself, on a frame that mixes everything the prefilter treats differently
+    (round 2 compared such frames at this size HIP against HIP only, and the oracle saw 4K through border regions of a pure
+    pan).  The oracle is too slow for all 8.3 M pixels, so it walks regions placed where each mechanism is at work: the
+    four borders and a corner (rim segment units, plateaus), the edge and the inside of an occlusion (hand-over, narrow
+    search, full search), the edge of a patch that moves on its own, the noise band's boundary (four- and sixteen-point
+    tests), the static flat area's rim (zero-cost ties), both fade patches (fallback tiles, shared and merged) -- and both
+    motion modes have to agree with it bit for bit there, and with each other everywhere."""
+    from linux_fg_amd import capi
+    prev, curr = _uhd_mixture()
+    a, stats = run_motion_mode(ctx, prev, curr, capi.MOTION_PREFILTERED)
+    b, _ = run_motion_mode(ctx, prev, curr, capi.MOTION_EXACT_ONLY)
+    assert (a == b).all(), f"{(a != b).any(-1).sum()} pixels differ between the two modes"
+    assert 0 < stats[1] < 64, stats                                # the fade patches went through the fallback, little else
+    W, H = 3840, 2160
+    rois = [(0, 0, 96, 40), (W - 96, 0, W, 40), (0, H - 40, 96, H), (W - 96, H - 40, W, H),      # corners
+            (1800, 0, 1960, 24), (1800, H - 24, 1960, H), (0, 1000, 24, 1100), (W - 24, 1000, W, 1100),   # borders (noise band on two)
+            (380, 280, 460, 330), (500, 350, 560, 380),            # an occlusion: its corner, its inside
+            (2480, 1480, 2520, 1560),                              # the narrow occlusion's edge
+            (1180, 180, 1260, 230), (2880, 840, 2960, 880),        # patches that move on their own: corners
+            (2000, 880, 2100, 920), (2000, 1080, 2100, 1120),      # the noise band's two boundaries
+            (280, 1230, 360, 1270), (760, 1400, 840, 1440),        # the static flat area's rim
+            (2180, 1580, 2260, 1620), (2980, 60, 3060, 100),       # the fade patches' rims (fallback tiles)
+            (0, 1290, 70, 1330)]                                   # the occlusion on the left border
+    for roi in rois:
+        x0, y0, x1, y1 = roi
+        want = as_int(oracle.motion(prev, curr, roi=roi))[y0:y1, x0:x1]
+        assert (a[y0:y1, x0:x1] == want).all(), f"prefiltered path differs from the oracle in {roi}: {(a[y0:y1, x0:x1] != want).any(-1).sum()} pixels"
+    inner = a[1450:1550, 1000:1600]                                # clean pan between the mechanisms
+    assert (inner[..., 0] == -6).all() and (inner[..., 1] == 4).all()
+
+
 @pytest.mark.parametrize("case", range(60))
 def test_motion_modes_agree_on_random_mixtures(ctx, case):
     """Seeded fuzz over frame sizes and content mixtures: small frames (tiles shared between workgroups), mid-size

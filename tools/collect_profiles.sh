@@ -2,7 +2,7 @@
 # Runs on the MI355X box (gpurun): regenerates every file profiles/README.md lists into gpurun_out/profiles_new/.
 # usage: tools/collect_profiles.sh rNN
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/profiles_new
 rm -rf $OUT && mkdir -p $OUT
@@ -18,11 +18,17 @@ stats pipeline --steps 300 --warmup 6                      # the default command
 stats pipeline_one_lane --steps 200 --warmup 5 --in-flight 1   # one frame at a time: the durations bench.py's stages / dominant_stage quote
 stats scale --workload scale --steps 2000 --warmup 50
 LFG_MOTION_MODE=1 stats pipeline_exact_only --steps 5 --warmup 1
+stats config5_one_lane --input 4k --factors 0.25,0.5,0.75 --in-flight 1 --steps 40 --warmup 4     # BASELINE config 5 on one GPU: 4K -> 8K, three generated frames per pair
+stats config5 --input 4k --factors 0.25,0.5,0.75 --steps 60 --warmup 6
 echo "kernel stats done"
 python3 $R/bench.py > $OUT/${TAG}_pipeline_bench.json 2> /tmp/bench.err
 python3 $R/bench.py --workload scale > $OUT/${TAG}_scale_bench.json 2>> /tmp/bench.err
 python3 $R/bench.py --in-flight 1 --no-extras --no-cpu-baseline > $OUT/${TAG}_pipeline_one_lane_bench.json 2>> /tmp/bench.err   # one frame at a time
 python3 $R/bench.py --workload pipeline_input_res --no-extras --no-cpu-baseline > $OUT/${TAG}_pipeline_input_res_bench.json 2>> /tmp/bench.err   # labelled variant: motion + interpolate at input resolution, then scale
+python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_pipeline_bench_driver_shape.json 2>> /tmp/bench.err   # the driver's command: a 7 ms region, repeated (the `repeats` field)
+python3 $R/bench.py --input 4k --factors 0.25,0.5,0.75 --in-flight 1 --no-extras --no-cpu-baseline --steps 200 --warmup 10 > $OUT/${TAG}_config5_one_lane_bench.json 2>> /tmp/bench.err
+python3 $R/bench.py --input 4k --factors 0.25,0.5,0.75 --no-extras --no-cpu-baseline --steps 300 --warmup 12 > $OUT/${TAG}_config5_bench.json 2>> /tmp/bench.err
+rc=0; python3 $R/bench.py --gpus 2 --steps 5 > $OUT/${TAG}_gpus2_on_one_gpu.txt 2>&1 || rc=$?; echo "exit code $rc" >> $OUT/${TAG}_gpus2_on_one_gpu.txt   # the launcher's refusal on a box with one GPU
 echo "bench done"
 N=10
 for c in FETCH_SIZE WRITE_SIZE; do
