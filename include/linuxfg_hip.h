@@ -103,7 +103,7 @@ int         lfg_sync(lfg_context *ctx);
 /* Lanes: several frames in flight on one GPU.  The reference has one queue and waits for it after every
  * submission (src/scaler.cpp:389-393, src/frame_manager.cpp:190-194); here a frame's last long motion units leave
  * most CUs idle for a third of its time, and the next frame's scale, hints and first units can run there.  A lane
- * is a stream plus the temporaries and the motion workspace (2.2 GB at 4K, 2.4 GB for the one lane of a context without lanes: lfg_motion_workspace_size) of the calls made while it is selected;
+ * is a stream plus the temporaries and the motion workspace (0.9 GB at 4K, 1.0 GB for the one lane of a context without lanes: lfg_motion_workspace_size) of the calls made while it is selected;
  * frames are plain device memory and may be used from any lane -- the caller orders producers and consumers:
  *   lfg_lanes(ctx, n)       1 <= n <= LFG_MAX_LANES lanes (lane 0 is the context's own stream); shrinking waits
  *                           for the lanes that go and frees what they own

@@ -423,13 +423,13 @@ constexpr int kRunIn = kRun + kB - 1;             // 13
 #define LFG_ZERO_COMPARE 1
 #endif
 #ifndef LFG_LIST_MAIN
-#define LFG_LIST_MAIN 32
+#define LFG_LIST_MAIN 10
 #endif
 #ifndef LFG_LIST_AUX
-#define LFG_LIST_AUX 24
+#define LFG_LIST_AUX 10
 #endif
 #ifndef LFG_LIST_DYN
-#define LFG_LIST_DYN 24
+#define LFG_LIST_DYN 10
 #endif
 #ifndef LFG_BORDER_PER_SEGMENT
 #define LFG_BORDER_PER_SEGMENT 1
@@ -472,22 +472,25 @@ static_assert(kSlabFloats >= 8 * kSlabP && 2 * (3 * kNarrowQ + 15) + 1 < kNarrow
 #endif
 constexpr int kHintGrid = LFG_HINT_GRID, kHints = kHintGrid * kHintGrid;      // sample blocks of the per-call visiting order
 // Recorded candidates per pixel and list.  A pseudo-random visiting order makes the number of running minima of a pixel
-// without any match ~Poisson(ln n) over the n candidates a wave visits, whatever the content; a list that overflows flags
-// its tile for the literal kernel (exact, slow), so the depths are sized for "no tile, ever, on a frame of pure noise":
-//   kListK    image-shaped lists of whole tiles: n = 1089, Poisson(7.6): P(> 32) ~ 1e-11 per unmatched pixel.  (24 was
-//             measured: P(> 24) ~ 5e-7, two or three tiles of a 4K noise frame through the literal kernel, 4 % of its time.)
-//   kListAux  private lists of the parts of a rim tile: n <= 273, Poisson(5.6): P(> 24) ~ 1e-9;
-//   kListDyn  private lists of the eight parts of a segment handed over at run time: n = 137, and a part starts from the
-//             thresholds of the wave that handed the segment over, which has tried the call's first eight candidates at
-//             least; sum 1 / (8 + j) = 2.9 expected records would allow 16 (P(> 16) = 3e-9, and the parts that finish hold
-//             15 at most on the hand-over test's 4K frame: LFG_DEBUG_DYN) -- yet two segments of that frame give up at
-//             16, with and without the inherited thresholds or the narrow search.  Not understood; 24 has the margin on
-//             every frame of the test-suite and the fuzz.  (12: 25 tiles of the occluded benchmark frame, as the count
-//             predicts.)
-// (32 / 32 / 32 before: 2.5 GB of workspace at 4K instead of 2.2.)
+// without any match ~Poisson(ln n) over the n candidates a wave visits, whatever the content -- 7.6 for a whole tile's wave,
+// and measured so: on the hand-over test's 4K frame (every segment handed over, 7.3 million pixel-parts) the eight parts hold
+// 2.8 records on average where sum 1 / (8 + j) says 2.84, P(>= 10) = 7e-4 for 5e-4, P(>= 14) = 1.5e-6 for 8e-7 -- and two lists
+// of 17 and 18, genuine runs of successive minima (tools/debug_dyn_lists.py prints them), a hundred times what the model's
+// far tail allows: what gave up at depth 16 in round 2, when the lists had to hold every record of a search (32 / 24 / 24:
+// 2.4 GB of workspace at 4K).  They do not have to.  A record whose cost bound exceeds the pixel's CURRENT threshold can
+// never pass the resolve kernel's test against the final, smaller one; and when a candidate undercuts the threshold by
+// more than the bracket is wide -- S~ < thr (1 - 3e-4): every earlier record has S~ >= the old minimum = thr / kRatio, its
+// stored bound is at most 2^-13 below that, and kRatio S~ lies under it -- ALL earlier records are dead at once, so the
+// pixel's count restarts at 0 (the record path, `restart`): no read, no pass over the list.  On content without ties
+// successive minima differ by a percent, not by 0.03 %: a list holds the running minimum and the odd near-tie, whatever
+// the length of the search (records held per pixel at the end of a noise frame: 1.3; recorded over it: 7.5).  What fills
+// a list now is a set of candidates within 0.03 % of each other -- ties: flat or periodic content -- and that flags the
+// tile for the literal kernel as before.  Depth 10 everywhere (one slot of it a spare: see listsOverflowed).
 constexpr int kListK = LFG_LIST_MAIN, kListAux = LFG_LIST_AUX, kListDyn = LFG_LIST_DYN;
-static_assert(kListK % 2 == 0 && kListK >= 4 && kListAux >= 4 && kListDyn >= 4 && kListK <= 64 && kListAux <= 64 && kListDyn <= 64, "list depths");
+static_assert(kListK >= 4 && kListAux >= 4 && kListDyn >= 4 && kListK <= 64 && kListAux <= 64 && kListDyn <= 64, "list depths");
 constexpr float kRatio = 1.00008f;      // >= (1 + 3.6e-5) / (1 - 3.6e-5) with room for the product's rounding ("Bracket")
+constexpr float kRestart = 0.9997f;     // S~ < thr kRestart: every earlier record of the pixel is dead ((1 - 2^-13) / kRatio^2 = 1 - 2.8e-4, with room)
+static_assert(kRestart < (1.0 - 1.0 / 8192.0) / (1.00008 * 1.00008) - 1e-5, "restart rule");
 static_assert((kHints & (kHints - 1)) == 0 && kHints >= 256 && kHints <= 1024, "one hint per thread of the order kernel, scrambled by an odd multiplier");
 static_assert(kPNT / 64 * kSeg == kPTH && 8 * kRun == kPTW && kPTH == kTH, "stage maps cover the tile");
 
@@ -844,13 +847,15 @@ __device__ __forceinline__ void prefilter_unit(
             }
         }
     }
-    // some pixel of this lane has more than listK records: bit 15 of a 16-bit counter biased by 0x7FFF - listK
+    // some pixel of this lane holds listK records or more: bit 15 of a 16-bit counter biased by 0x8000 - listK.  (The last
+    // slot is a spare -- candidates that are written without being counted, plateau duplicates and the head of the order
+    // in units that share a tile, go to slot `count` and must not land on a record -- so a list holds listK - 1.)
     auto listsOverflowed = [&]() -> bool {
         uint32_t any = 0u;
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
 #pragma unroll
-            for (int i = 0; i < (kRun + 1) / 2; ++i) any |= cnt2[hb][i] + (0x7FFFu - listK) * 0x10001u;
+            for (int i = 0; i < (kRun + 1) / 2; ++i) any |= cnt2[hb][i] + (0x8000u - listK) * 0x10001u;
         }
         return (any & 0x80008000u) != 0u;
     };
@@ -924,6 +929,10 @@ __device__ __forceinline__ void prefilter_unit(
                         asm("v_max_f32 %0, %2, %1" : "=v"(cap) : "v"(s * kRatio), "s"(zeroCap));   // no NaNs here
                         asm("v_min_f32 %0, %1, %2" : "=v"(t) : "v"(thr[hb][i]), "v"(cap));
                         if (hb) thr2[i].y = t; else thr2[i].x = t;
+                        // `restart`: the candidate undercuts the old threshold by more than the bracket's width, so every
+                        // earlier record of this pixel is dead (see the list depths): the count starts again at 0
+                        const bool restart = s < thr[hb][i] * kRestart;
+                        if (restart) cnt2[hb][i >> 1] &= ~(0xFFFFu << (16 * (i & 1)));
                         const uint32_t n = (cnt2[hb][i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
                         // past the end of the list the last slot is overwritten; the count keeps growing and
                         // flags the tile
@@ -1486,6 +1495,7 @@ __device__ __forceinline__ void prefilter_unit(
                         const float s = sN[j];
                         if (s <= thrN[j]) {                            // (the rules of rowSumsAndTest)
                             const float cap = __builtin_fmaxf(s * kRatio, __builtin_bit_cast(float, zeroCap));
+                            if (s < thrN[j] * kRestart) cntN[j] = 0u;   // (`restart`: every earlier record is dead)
                             thrN[j] = __builtin_fminf(thrN[j], cap);
                             const uint32_t at = __umul24(min(cntN[j], listK - 1u), rowStride) + nLaneOff + (uint32_t)j;
                             if (s != 0.0f) waveList[at] = rec_make(s, cand);
@@ -1512,7 +1522,7 @@ __device__ __forceinline__ void prefilter_unit(
                 if (!have && !pending) {                               // (the pipeline has drained) every 64 entries: give up?
                     if (idx0 >= iEnd) break;
                     started = 0;
-                    const bool over = cntN[0] > listK || cntN[1] > listK || cntN[2] > listK || cntN[3] > listK;
+                    const bool over = cntN[0] >= listK || cntN[1] >= listK || cntN[2] >= listK || cntN[3] >= listK;    // (the last slot is a spare)
                     if (__builtin_amdgcn_readfirstlane(__ballot(over) != 0ull)) sGiveUp = 1u;
                     if (__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)&sGiveUp) != 0) return false;
                     continue;

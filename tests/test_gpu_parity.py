@@ -315,7 +315,9 @@ def test_motion_4k_modes_agree_on_noise_and_translation(ctx):
     a, stats = run_motion_mode(ctx, noise_a, noise_b, capi.MOTION_PREFILTERED)
     b, _ = run_motion_mode(ctx, noise_a, noise_b, capi.MOTION_EXACT_ONLY)
     assert (a == b).all(), f"{(a != b).any(-1).sum()} pixels differ"
-    assert stats[1] == 0 and 5.0 < stats[2] < 10.0, stats
+    # (records HELD at the end, not recorded over the search -- 7.5: a pixel's count restarts whenever a candidate undercuts
+    #  its threshold by more than the bracket's width, which on noise is nearly every new minimum)
+    assert stats[1] == 0 and 1.0 <= stats[2] < 3.0, stats
     prev = synth.make_prev(W, H, seed=synth.BASE_SEED)
     curr = synth.translate(prev, (-7, 11), synth.BASE_SEED)
     a, _ = run_motion_mode(ctx, prev, curr, capi.MOTION_PREFILTERED)
@@ -1006,18 +1008,19 @@ def test_mv_export_is_the_reference_rgba32f_image(ctx, oracle):
 
 
 def test_motion_workspace_size_and_list_depths_on_pure_noise(ctx):
-    """lfg_motion_workspace_size: what the prefiltered path keeps per lane (at 4K 2.2 GB with frames in flight, 2.4 GB for a
-    context that runs one frame at a time and searches the top and bottom strips in eight parts; list depths 32 / 24 / 24),
-    refusals; and the depths are enough where lists are longest -- a pair of independent noise
-    frames, every pixel without a match, every list holding its ~ln(n) running minima: no tile overflows into the literal
-    kernel, and the vectors are the literal kernel's."""
+    """lfg_motion_workspace_size: what the prefiltered path keeps per lane (at 4K 0.90 GB with frames in flight, 1.00 GB for a
+    context that runs one frame at a time and searches the top and bottom strips in eight parts; list depth 10 -- round 2:
+    2.2 / 2.4 GB at depths 32 / 24 / 24, before a pixel's count restarted whenever a candidate undercut its threshold by more
+    than the bracket's width), refusals; and the depth is enough where lists used to be longest -- a pair of independent noise
+    frames, every pixel without a match, 7.5 records per pixel over the search of which a list holds the last one or two: no
+    tile overflows into the literal kernel, and the vectors are the literal kernel's."""
     from linux_fg_amd import capi
     n4k = ctx.motion_workspace_size(3840, 2160)
-    assert 0.5e9 < n4k < 2.5e9
+    assert 0.3e9 < n4k < 1.0e9
     other = capi.Context(0)
     try:
         other.lanes(2)
-        assert other.motion_workspace_size(3840, 2160) < min(n4k, 2.3e9)       # every rim segment in four parts
+        assert other.motion_workspace_size(3840, 2160) < min(n4k, 0.95e9)      # every rim segment in four parts
     finally:
         other.close()
     assert ctx.motion_workspace_size(1920, 1080) < n4k
