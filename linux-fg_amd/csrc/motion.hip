@@ -446,6 +446,12 @@ constexpr int kRunIn = kRun + kB - 1;             // 13
 #ifndef LFG_LOOKAHEAD
 #define LFG_LOOKAHEAD 2                 // candidates per lane of the lookahead (0 or 1: off)
 #endif
+#ifndef LFG_SAD_TEST
+#define LFG_SAD_TEST 1                   // one-point lattice test by SAD while the wave's largest threshold is small
+#endif
+#ifndef LFG_SAD_TEST_MAX
+#define LFG_SAD_TEST_MAX 8.0f
+#endif
 #ifndef LFG_EXACT_MATCH
 #define LFG_EXACT_MATCH 1                // a hint whose every block position is the same bytes in both frames skips its evaluation
 #endif
@@ -1222,6 +1228,16 @@ __device__ __forceinline__ void prefilter_unit(
                                 acc = min(acc, tex[ci][t] ^ (uint32_t)__builtin_amdgcn_readlane((int)c[kLatR0 + 8 * t], kLatC0 + 8 * ci));
                         }
                         dMin = acc == 0u ? 0u : 0x7F800000u;
+                    } else if (LFG_SAD_TEST && waveThr < LFG_SAD_TEST_MAX) {
+                        // (small thresholds: a distance is at least half its SAD -- see the lookahead of the batch loop)
+                        uint32_t sad = 0xFFFFFFFFu;
+#pragma unroll
+                        for (int ci = 0; ci < kLatCols; ++ci) {
+#pragma unroll
+                            for (int t = 0; t < kLatRows; ++t)
+                                sad = min(sad, __builtin_amdgcn_sad_u8((uint32_t)__builtin_amdgcn_readlane((int)c[kLatR0 + 8 * t], kLatC0 + 8 * ci), tex[ci][t], 0u));
+                        }
+                        dMin = (float)sad <= (2.0f * waveThr) * 1.00001f ? 0u : 0x7F800000u;
                     } else {
 #pragma unroll
                         for (int ci = 0; ci < kLatCols; ++ci) {
@@ -1796,6 +1812,27 @@ __device__ __forceinline__ void prefilter_unit(
                         }
 #pragma unroll
                         for (int a = 0; a < kA; ++a) keep[a] = accA[a] == 0u;
+                    } else if (LFG_SAD_TEST && waveThr < LFG_SAD_TEST_MAX) {
+                        // Small but not zero thresholds -- a match up to a rounding of the upscaler, a level here and there:
+                        // more than half of the interior waves of the benchmark's pan -- need no distance either: a distance
+                        // is at least half the sum of its four absolute differences (Cauchy-Schwarz), so "some lattice point
+                        // with SAD <= 2 thr" is a necessary condition too, one v_sad_u8 and half a v_min3 per point instead
+                        // of three dot products and two adds (wrong candidates have SADs in the hundreds).
+                        uint32_t sadA[kA];
+#pragma unroll
+                        for (int a = 0; a < kA; ++a) sadA[a] = 0xFFFFFFFFu;
+#pragma unroll
+                        for (int ci = 0; ci < kLatCols; ++ci) {
+#pragma unroll
+                            for (int t = 0; t < kLatRows; ++t) {
+                                const uint32_t cT = (uint32_t)__builtin_amdgcn_readlane((int)c[kLatR0 + 8 * t], kLatC0 + 8 * ci);
+#pragma unroll
+                                for (int a = 0; a < kA; ++a) sadA[a] = min(sadA[a], __builtin_amdgcn_sad_u8(cT, tex[a][ci][t], 0u));
+                            }
+                        }
+                        const float sadMax = (2.0f * waveThr) * 1.00001f;
+#pragma unroll
+                        for (int a = 0; a < kA; ++a) keep[a] = (float)sadA[a] <= sadMax;
                     } else {
                         uint32_t dMinA[kA];
 #pragma unroll
