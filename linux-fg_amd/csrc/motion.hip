@@ -3020,41 +3020,39 @@ __global__ __launch_bounds__(kHintThreads, kHintThreads <= 256 ? 4 : 1) void mot
     if (tid == 0) hints[blockIdx.x] = sBest;           // best SAD << 11 | candidate (scan index)
 }
 
-// (sHint: the 256 hints, which every thread compares its own with -- who proposes it first, how many do; sProposed: one bit
-//  per candidate that some hint other than zero motion proposes)
-constexpr int kProposedWords = (kCand + 31) / 32;
+// (one workgroup; sOwner: lowest hint index that proposes a candidate, sVotes: how many sample blocks propose it -- two LDS
+//  atomics per thread.  A version without the two tables, every thread comparing its hint with all 256, was built for the
+//  fold into the hint kernel and took 3 us longer.)
 __global__ __launch_bounds__(kHints) void motion_order_kernel(
     const uint32_t *__restrict__ hints, const uint32_t *__restrict__ baseScan,
     const uint32_t *__restrict__ entryOfScan, uint32_t *__restrict__ order32) {
-    __shared__ uint32_t sHint[kHints], sProposed[kProposedWords], sWaveSum[kHints / 64], sRunning, sTop;
+    __shared__ uint32_t sOwner[kCand];
+    __shared__ uint32_t sVotes[kCand];
     constexpr int kWaves = kHints / 64;
+    __shared__ uint32_t sWaveSum[kWaves];
+    __shared__ uint32_t sRunning, sTop;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t zero = baseScan[0];               // zero motion
+    for (int i = tid; i < kCand; i += kHints) { sOwner[i] = 0xFFFFFFFFu; sVotes[i] = 0u; }
+    if (tid == 0) sTop = 0u;
+    __syncthreads();
     // Hints are taken in a scrambled order of the sample blocks: under a zoom or a rotation the hints vary smoothly
     // across the frame, and in raster order a pixel would see them approach its own motion -- one running minimum
     // after the other -- which is exactly what fills the lists.
     const uint32_t hint = hints[(tid * 97 + 13) & (kHints - 1)];
     const uint32_t mine = hint & 0x7FFu;
-    sHint[tid] = mine;
-    for (int i = tid; i < kProposedWords; i += kHints) sProposed[i] = 0u;
-    if (tid == 0) sTop = 0u;
-    __syncthreads();
     // A sample block whose best SAD is 1020 or more has no candidate with a cost below 510 (a distance is at least
     // half the sum of its four absolute differences): such a segment would search in full.  Handing segments over
     // (motion_prefilter_kernel) pays when they are the exception; with a quarter of the samples unmatched it is off.
     const uint32_t unmatched = (uint32_t)__popcll(__ballot((hint >> 11) >= 1020u));
     if (lane == 0) sWaveSum[wv] = unmatched;
-    uint32_t owner = (uint32_t)tid, votes = 0u;      // the first thread with my hint; how many have it
-    for (int j = 0; j < kHints; ++j) {
-        const bool same = sHint[j] == mine;          // (the same word in every lane: a broadcast read)
-        votes += same ? 1u : 0u;
-        owner = same ? min(owner, (uint32_t)j) : owner;
-    }
-    if (mine != zero) atomicOr(&sProposed[mine >> 5], 1u << (mine & 31u));
+    if (mine != zero) atomicMin(&sOwner[mine], (uint32_t)tid);
+    atomicAdd(&sVotes[mine], 1u);
+    __syncthreads();
     // The most popular hint goes first: where it is the answer (a pan: nearly everywhere) the very first evaluation
     // closes the thresholds, and zero motion -- second -- already fails the cheap test instead of being recorded for
     // every pixel.  (Ties: the candidate earlier in scan order.)
-    atomicMax(&sTop, (votes << 11) | (uint32_t)(kCand - 1 - (int)mine));
+    atomicMax(&sTop, (sVotes[mine] << 11) | (uint32_t)(kCand - 1 - (int)mine));
     __syncthreads();
     const uint32_t top = (uint32_t)(kCand - 1) - (sTop & 0x7FFu);
     if (tid == 0) {
@@ -3083,12 +3081,12 @@ __global__ __launch_bounds__(kHints) void motion_order_kernel(
     uint32_t base[kRounds];                                            // this thread's entries of the fixed order, read up front
 #pragma unroll
     for (int k = 0; k < kRounds; ++k) base[k] = baseScan[min(1 + k * kHints + tid, kCand - 1)];
-    append(mine != zero && mine != top && owner == (uint32_t)tid, mine);              // the other distinct hints
+    append(mine != zero && mine != top && sOwner[mine] == (uint32_t)tid, mine);       // the other distinct hints
     if (tid == 0) order32[kCand + 1] = sRunning;                       // entries in front: top hint, zero motion, the other hints
 #pragma unroll
     for (int k = 0; k < kRounds; ++k) {                                // then everything no hint proposed
         const int e = 1 + k * kHints + tid;
-        append(e < kCand && ((sProposed[base[k] >> 5] >> (base[k] & 31u)) & 1u) == 0u, base[k]);
+        append(e < kCand && sOwner[base[k]] == 0xFFFFFFFFu, base[k]);
     }
 }
 
