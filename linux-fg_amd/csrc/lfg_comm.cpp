@@ -124,11 +124,13 @@ LFG_EXPORT int lfg_broadcast_frame(lfg_context *ctx, lfg_frame *frame, int root)
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess) e = hipEventRecord(ctx->comm_ready, ctx->stream);
     if (e == hipSuccess) e = hipStreamWaitEvent(ctx->comm_stream, ctx->comm_ready, 0);
+#ifndef LFG_DIAG_COMM_SELECTED_LANE_ONLY   // (diagnostic build: round 2's ordering, to see tests/test_gpu_comm.py's ordering test fail)
     for (size_t j = 0; j < ctx->lanes.size() && e == hipSuccess; ++j) {
         if ((int)j == ctx->lane || !ctx->lanes[j].stream) continue;       // (the selected lane's stream is ctx->stream, above)
         e = hipEventRecord(ctx->comm_ready, ctx->lanes[j].stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(ctx->comm_stream, ctx->comm_ready, 0);
     }
+#endif
     if (e != hipSuccess) return fail(ctx, LFG_ERR_DEVICE, std::string("lfg_broadcast_frame: ") + hipGetErrorString(e));
     const ncclResult_t rc = rccl().Broadcast(frame->data, frame->data, bytes, ncclUint8, root, (ncclComm_t)ctx->comm, ctx->comm_stream);
     if (rc != ncclSuccess) return fail_nccl(ctx, rc, "ncclBroadcast");

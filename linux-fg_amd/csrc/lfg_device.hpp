@@ -119,7 +119,9 @@ __device__ __forceinline__ void store_b128_guarded(u32x4_store q, __amdgpu_buffe
     __builtin_amdgcn_raw_buffer_store_b128(q, rsrc, voffset, 0, AUX);
     // The data registers are an INPUT of the wait states: the compiler must keep them intact until the s_nop has
     // issued, and it does not move a volatile asm across the store.
+#ifndef LFG_DIAG_NO_STORE_GUARD      // (diagnostic build of tools/repro_store_hazard.py only: the store without its wait states)
     asm volatile("s_nop 1" : : "v"(q));
+#endif
 }
 
 // Orders this wave's LDS traffic for cross-lane exchange inside ONE wave: a wavefront-scope fence

@@ -101,3 +101,45 @@ def test_shared_frame_broadcast_with_frames_in_flight():
             for a in pinned:
                 ctx.staging_destroy(a)
         ctx.lanes(1)
+
+
+def test_broadcast_is_ordered_after_every_lane():
+    """lfg_broadcast_frame is ordered after everything enqueued so far on EVERY lane's stream (include/linuxfg_hip.h), not
+    after the selected lane only: a frame that another lane is still going to read must not be overwritten by what
+    follows the broadcast.  Lane 0 queues something long and then an upscale that reads F; lane 1 -- with no lfg_lane_wait
+    anywhere -- broadcasts F, waits for the broadcast and uploads new content into F.  The upscale has to see the OLD
+    content.  (One rank: the broadcast moves no data, its ordering is what is tested.  A receiver's slot being overwritten
+    by the broadcast itself needs a second GPU and cannot be seen here.)"""
+    from linux_fg_amd import capi
+    w, h = 320, 180
+    old, new = synth.make_prev(w, h, seed=4101), synth.make_prev(w, h, seed=4102)
+    big_a, big_b = synth.make_uncorrelated_pair(1280, 720, stream=3)      # a motion call of several milliseconds
+    with capi.Context(0) as ctx:
+        ctx.comm_init(1, 0, capi.Context.comm_unique_id())
+        f = ctx.frame_from(old)
+        up = ctx.create_frame(2 * w, 2 * h)
+        ctx.scale(f, up)
+        want = ctx.download(up).copy()
+        ctx.lanes(2)
+        fa, fb = ctx.frame_from(big_a), ctx.frame_from(big_b)
+        mv = ctx.create_frame(1280, 720, capi.FORMAT_MV_S8X2)
+        pinned = ctx.staging_create(w * h * 4)
+        pinned[:] = new.reshape(-1)
+        for attempt in range(6):
+            ctx.lane_select(0)
+            ctx.upload(f, old)
+            ctx.sync()
+            ctx.motion(fa, fb, mv, 8, 16.0)                   # lane 0 is busy ...
+            ctx.scale(f, up)                                  # ... and reads F only afterwards
+            ctx.lane_select(1)
+            ctx.broadcast_frame(f, 0)
+            ctx.comm_wait()
+            ctx.upload_async(f, pinned)                       # F changes as soon as lane 1 gets there
+            ctx.sync()
+            assert (ctx.download(up) == want).all(), attempt
+            assert (ctx.download(f) == new).all(), attempt
+        ctx.lane_select(0)
+        ctx.staging_destroy(pinned)
+        for x in (f, up, fa, fb, mv):
+            ctx.destroy_frame(x)
+        ctx.lanes(1)
