@@ -1111,10 +1111,20 @@ __device__ __forceinline__ void prefilter_unit(
 #ifndef LFG_FOURPOINT_MAX
 #define LFG_FOURPOINT_MAX (4.0f * 510.0f)
 #endif
-        bool useFourPoint = true, useSixteen = LFG_SIXTEEN != 0;
+#ifndef LFG_FOUR_SAD
+#define LFG_FOUR_SAD 0                   // the four-point test by sums of absolute differences first (see fourPointBatch): measured, no gain
+#endif
+        bool useFourPoint = true, useFourSad = LFG_FOUR_SAD != 0, useSixteen = LFG_SIXTEEN != 0;
         auto fourPointApplies = [&]() { return useFourPoint && !(waveThr < kOnePointMax) && waveThr < LFG_FOURPOINT_MAX; };
         // (per lane: the candidate `ordL` still has to be evaluated in full)
-        auto fourPointBatch = [&](const uint32_t ordL, bool need, const bool fullBatch) -> bool {
+        // sadC: the same walk with every distance replaced by half the sum of its four absolute differences -- a distance is
+        // at least that (Cauchy-Schwarz: |d|_1 <= 2 |d|_2 for four channels), so "every group's four SADs sum to more than
+        // 2 waveThr" clears a candidate just as well, for one v_sad_u8 per point instead of three dot products, two adds and
+        // a square root.  On frames with sensor noise it clears 98.3 % of the candidates for the whole wave where the
+        // distances clear 99.6 % (tools/measure_bounds.py); what it leaves waits in the list of deferred candidates for
+        // the test by distances.
+        auto fourPointBatch = [&](const uint32_t ordL, bool need, const bool fullBatch, auto sadC) -> bool {
+                constexpr bool kSad = decltype(sadC)::value;
                 // FOUR-point test, for thresholds a single distance rarely exceeds (a match under sensor noise costs a
                 // few hundred).  Block positions = 3 mod 4 form a lattice of 5 x 15 points of which every pixel's
                 // 8 x 8 block holds exactly a 2 x 2 group (columns 3 + 4 g, 7 + 4 g with g = i / 4 for pixel column i,
@@ -1127,8 +1137,9 @@ __device__ __forceinline__ void prefilter_unit(
                 // (Positions = 0 mod 4 did the same with 6 x 16 points until late in round 2.)
                 lds_ro_u32_ptr w = (lds_ro_u32_ptr)(sWin + kSeg * seg) + (ordL >> 16) + (3 * kWinH + 3);
                 auto bitsOf = [](float d) { return __builtin_bit_cast(uint32_t, d); };
-                uint32_t pMin = 0x7F800000u;
+                uint32_t pMin = kSad ? 0xFFFFFFFFu : 0x7F800000u;
                 float vPrev[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                uint32_t vPrevI[4] = {0u, 0u, 0u, 0u};
                 int tx0L = tx0, rowsL = ty0 + kSeg * seg;
                 asm volatile("" : "+s"(tx0L), "+s"(rowsL));
                 uint32_t rowRelevant = 0u;                              // bit h: some pixel row inside the image maps to vertical group h (rows 4 h .. 4 h + 3)
@@ -1139,10 +1150,17 @@ __device__ __forceinline__ void prefilter_unit(
                 //  for instruction-cache misses, SQC_ICACHE_MISSES stays at 0.01 %)
                 const int gLo = bandLo >> 2, gHi = bandHi >> 2;         // groups i / 4 of the band's pixel columns i
                 const bool restricted = LFG_BAND && (bandLo > 0 || bandHi < kPTW - 1);
-                // (two copies of the walk, with and without the band's bounds: the bounds' tests in the one walk cost the
-                //  segments whose band is the whole width -- noise everywhere -- 6 %)
-                auto walk = [&](auto banded) {
-                constexpr bool kBanded = decltype(banded)::value;
+                // (four copies of the walk: with and without the band's bounds -- the bounds' tests in the one walk cost the
+                //  segments whose band is the whole width, noise everywhere, 6 % -- and with and without the masks of a segment
+                //  at the image border: a select per point and per group is a third of the SAD walk's instructions)
+                auto walk = [&](auto banded, auto atBorder) {
+                constexpr bool kBanded = decltype(banded)::value, kBorder = decltype(atBorder)::value;
+                // a group that is not wanted -- the one "before" the first lattice column -- is kept out of the minimum by a
+                // previous column whose sums are huge, not by a select per group
+                if (!kBorder) {
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) { vPrevI[h] = 0x01000000u; vPrev[h] = 1.0e30f; }
+                }
 #pragma unroll 3
                 for (int a = 0; a < kPTW / 4 + 1; ++a, w += 4 * kWinH) {   // lattice column 3 + 4 a closes group a - 1
                     if (kBanded && (a < gLo || a > gHi + 1)) continue;  // (wave-uniform)
@@ -1153,34 +1171,59 @@ __device__ __forceinline__ void prefilter_unit(
                     uint32_t tex[5];
 #pragma unroll
                     for (int b = 0; b < 5; ++b) tex[b] = w[4 * b];
-                    const uint32_t inImage = border ? (uint32_t)__builtin_amdgcn_readlane((int)valid, colL) : 0xFFFFFFFFu;
+                    const uint32_t inImage = kBorder ? (uint32_t)__builtin_amdgcn_readlane((int)valid, colL) : 0xFFFFFFFFu;
+                    // group (a - 1, h): its pixels are columns 4 (a - 1) .. + 3, rows 4 h .. + 3
+                    const bool colRelevant = a > (kBanded ? gLo : 0) && (!kBorder || tx0L + 4 * (a - 1) < W);
+                    if constexpr (kSad) {
+                        uint32_t dI[5];
+#pragma unroll
+                        for (int b = 0; b < 5; ++b) {
+                            const uint32_t sad = __builtin_amdgcn_sad_u8((uint32_t)__builtin_amdgcn_readlane((int)c[3 + 4 * b], colL), tex[b], 0u);
+                            const uint32_t keep = 0u - ((inImage >> (3 + 4 * b)) & 1u);
+                            dI[b] = kBorder ? (sad & keep) : sad;
+                        }
+#pragma unroll
+                        for (int h = 0; h < 4; ++h) {
+                            const uint32_t vI = dI[h] + dI[h + 1];
+                            if (kBorder) pMin = min(pMin, (colRelevant && ((rowRelevant >> h) & 1u)) ? vPrevI[h] + vI : 0xFFFFFFFFu);
+                            else pMin = min(pMin, vPrevI[h] + vI);
+                            vPrevI[h] = vI;
+                        }
+                    } else {
                     float d[5];
 #pragma unroll
                     for (int b = 0; b < 5; ++b) {
                         const float dd = __builtin_amdgcn_sqrtf(distanceOf((uint32_t)__builtin_amdgcn_readlane((int)c[3 + 4 * b], colL), tex[b]));
                         const uint32_t keep = 0u - ((inImage >> (3 + 4 * b)) & 1u);    // scalar: all ones or zero
-                        d[b] = border ? __builtin_bit_cast(float, bitsOf(dd) & keep) : dd;
+                        d[b] = kBorder ? __builtin_bit_cast(float, bitsOf(dd) & keep) : dd;
                     }
                     float v[4];
 #pragma unroll
                     for (int h = 0; h < 4; ++h) v[h] = d[h] + d[h + 1];
-                    // group (a - 1, h): its pixels are columns 4 (a - 1) .. + 3, rows 4 h .. + 3
-                    const bool colRelevant = a > (kBanded ? gLo : 0) && (!border || tx0L + 4 * (a - 1) < W);
 #pragma unroll
                     for (int h = 0; h < 4; ++h) {
                         const uint32_t g = bitsOf(vPrev[h] + v[h]);
-                        pMin = min(pMin, (colRelevant && ((rowRelevant >> h) & 1u)) ? g : 0x7F800000u);
+                        if (kBorder) pMin = min(pMin, (colRelevant && ((rowRelevant >> h) & 1u)) ? g : 0x7F800000u);
+                        else pMin = min(pMin, g);
                         vPrev[h] = v[h];
+                    }
                     }
                 }
                 };
-                if (restricted) walk(std::true_type{}); else walk(std::false_type{});
-                bool pass = !(pMin > bitsOf(waveThr * 1.000002f));
+                if (border) { if (restricted) walk(std::true_type{}, std::true_type{}); else walk(std::false_type{}, std::true_type{}); }
+                else        { if (restricted) walk(std::true_type{}, std::false_type{}); else walk(std::false_type{}, std::false_type{}); }
+                // (by SADs: the smallest group sum is an exact integer, at most 4080, and half of it bounds the four distances)
+                bool pass = kSad ? !((float)pMin * 0.5f > waveThr * 1.000002f) : !(pMin > bitsOf(waveThr * 1.000002f));
                 if (restricted) pass = zeroHit(ordL) || pass;          // (the settled pixels outside the band)
                 need = need && pass;
-                if (fullBatch && __builtin_popcountll(__ballot(need)) >= 48) useFourPoint = false;
+                if (fullBatch && __builtin_popcountll(__ballot(need)) >= 48) { if (kSad) useFourSad = false; else useFourPoint = false; }
                 return need;
         };
+#ifndef LFG_SIXTEEN_MAX
+#define LFG_SIXTEEN_MAX 2048.0f
+#endif
+        auto sixteenApplies = [&]() { return useSixteen && !(waveThr < kOnePointMax) && waveThr < LFG_SIXTEEN_MAX; };
+        bool deferSurvivors = false;       // set by latticeBatch: what it left has only passed the test by SADs and joins the deferred candidates
         // bit k of the result: candidate i0 + k of the staged order has to be evaluated in full
         // (ordL: this lane's candidate, an entry of the order; need: it has to be looked at; fullBatch: 64 candidates)
         auto latticeBatch = [&](const uint32_t ordL, bool need, const bool fullBatch) -> unsigned long long {
@@ -1256,13 +1299,27 @@ __device__ __forceinline__ void prefilter_unit(
             }
             // (only where the one-point test has just let more than an eighth of the batch through, and not any more once
             //  a full batch came out of it three quarters intact: segments that search in full anyway stop paying for it)
-            if (fourPointApplies() && __builtin_popcountll(__ballot(need)) > 8) need = fourPointBatch(ordL, need, fullBatch);
+            // (where the one-point test does not apply at all -- thresholds of a hundred and more: a match under sensor noise --
+            //  every candidate of the batch is still there, and the walk costs as much as evaluating two or three of them in
+            //  full: worth it from three on.  The seven candidates that follow the top hint on such frames used to be
+            //  evaluated one by one, a sixth of the wave's time.)
+#ifndef LFG_FOUR_MIN_WIDE
+#define LFG_FOUR_MIN_WIDE 2
+#endif
+            const int fourFrom = waveThr < LFG_ONEPOINT_OFF ? 8 : LFG_FOUR_MIN_WIDE;
+            deferSurvivors = false;
+            if (fourPointApplies() && __builtin_popcountll(__ballot(need)) > fourFrom) {
+                if (useFourSad && sixteenApplies()) {
+                    need = fourPointBatch(ordL, need, fullBatch, std::true_type{});
+                    // many left: the distances at once; a few: they wait for company (and for the distances) with the deferred ones
+                    if (__builtin_popcountll(__ballot(need)) > 8) need = fourPointBatch(ordL, need, fullBatch, std::false_type{});
+                    else deferSurvivors = true;
+                } else {
+                    need = fourPointBatch(ordL, need, fullBatch, std::false_type{});
+                }
+            }
             return __ballot(need);
         };
-#ifndef LFG_SIXTEEN_MAX
-#define LFG_SIXTEEN_MAX 2048.0f
-#endif
-        auto sixteenApplies = [&]() { return useSixteen && !(waveThr < kOnePointMax) && waveThr < LFG_SIXTEEN_MAX; };
         // bit k of the result: lane k's candidate (ordL) still has to be evaluated in full
         auto sixteenBatch = [&](const uint32_t ordL, const unsigned long long needMask, const bool fullBatch) -> unsigned long long {
             uint32_t l16;
@@ -1295,8 +1352,12 @@ __device__ __forceinline__ void prefilter_unit(
                 for (int a = 0; a < 9; ++a) rowRelevant |= (!border || rowsL + max(0, 2 * a - 1) < H) ? (1u << a) : 0u;
                 const int bLo = (bandLo + 1) >> 1, bHi = (bandHi + 1) >> 1;   // groups ceil(i / 2) of the band's pixel columns i
                 const bool restricted = LFG_BAND && (bandLo > 0 || bandHi < kPTW - 1);
-                auto walk = [&](auto banded) {                          // (two copies: see the four-point test)
-                constexpr bool kBanded = decltype(banded)::value;
+                auto walk = [&](auto banded, auto atBorder) {           // (four copies: see the four-point test)
+                constexpr bool kBanded = decltype(banded)::value, kBorder = decltype(atBorder)::value;
+                if (!kBorder) {             // (the groups that the first three columns would close: kept out of the minimum by huge sums)
+#pragma unroll
+                    for (int a = 0; a < 9; ++a) { vOld[a] = 1.0e30f; hOld[0][a] = 1.0e30f; hOld[1][a] = 1.0e30f; }
+                }
 #pragma unroll 2
                 for (int t = 0; t < 32; ++t, w += 2 * kWinH) {
                     if (kBanded && (t < bLo || t > bHi + 3)) continue;  // (wave-uniform)
@@ -1305,13 +1366,13 @@ __device__ __forceinline__ void prefilter_unit(
                     uint32_t tex[12];
 #pragma unroll
                     for (int k = 0; k < 12; ++k) tex[k] = w[2 * k];
-                    const uint32_t inImage = border ? (uint32_t)__builtin_amdgcn_readlane((int)valid, colL) : 0xFFFFFFFFu;
+                    const uint32_t inImage = kBorder ? (uint32_t)__builtin_amdgcn_readlane((int)valid, colL) : 0xFFFFFFFFu;
                     float d[12];
 #pragma unroll
                     for (int k = 0; k < 12; ++k) {
                         const float dd = __builtin_amdgcn_sqrtf(distanceOf((uint32_t)__builtin_amdgcn_readlane((int)c[2 * k], colL), tex[k]));
                         const uint32_t keep = 0u - ((inImage >> (2 * k)) & 1u);       // scalar: all ones or zero
-                        d[k] = border ? __builtin_bit_cast(float, bitsOf(dd) & keep) : dd;
+                        d[k] = kBorder ? __builtin_bit_cast(float, bitsOf(dd) & keep) : dd;
                     }
                     float pr[11], v[9];
 #pragma unroll
@@ -1320,19 +1381,21 @@ __device__ __forceinline__ void prefilter_unit(
                     for (int a = 0; a < 9; ++a) v[a] = pr[a] + pr[a + 2];
                     // columns t-1, t; with the pair sum of columns t-3, t-2 the group b = t - 3, whose first pixel
                     // column is max(0, 2 b - 1)
-                    const bool colRelevant = t >= (kBanded ? bLo : 0) + 3 && (!border || tx0 + max(0, 2 * (t - 3) - 1) < W);
+                    const bool colRelevant = t >= (kBanded ? bLo : 0) + 3 && (!kBorder || tx0 + max(0, 2 * (t - 3) - 1) < W);
                     const int sel = t & 1;                             // hOld[sel] holds the pair sum made two columns ago
 #pragma unroll
                     for (int a = 0; a < 9; ++a) {
                         const float h = vOld[a] + v[a];
                         const uint32_t g = bitsOf((sel ? hOld[1][a] : hOld[0][a]) + h);
-                        gMin = min(gMin, (colRelevant && ((rowRelevant >> a) & 1u)) ? g : 0x7F800000u);
+                        if (kBorder) gMin = min(gMin, (colRelevant && ((rowRelevant >> a) & 1u)) ? g : 0x7F800000u);
+                        else gMin = min(gMin, g);
                         if (sel) hOld[1][a] = h; else hOld[0][a] = h;
                         vOld[a] = v[a];
                     }
                 }
                 };
-                if (restricted) walk(std::true_type{}); else walk(std::false_type{});
+                if (border) { if (restricted) walk(std::true_type{}, std::true_type{}); else walk(std::false_type{}, std::true_type{}); }
+                else        { if (restricted) walk(std::true_type{}, std::false_type{}); else walk(std::false_type{}, std::false_type{}); }
                 bool pass = !(gMin > bitsOf(waveThr * 1.000002f));
                 if (restricted) pass = zeroHit(ordL) || pass;          // (the settled pixels outside the band)
                 need = need && pass;
@@ -1892,7 +1955,7 @@ __device__ __forceinline__ void prefilter_unit(
                     else { i0 += count; count = i0 == LFG_FIRST_BATCH ? hintsEnd - LFG_FIRST_BATCH : 64; }
                     continue;
                 }
-                if (sixteenApplies() && __builtin_popcountll(m) > 8) {     // the survivors wait for company
+                if ((sixteenApplies() && __builtin_popcountll(m) > 8) || (deferSurvivors && m != 0ull)) {     // the survivors wait for company
                     const uint32_t at = (uint32_t)pendCount + (uint32_t)__builtin_popcountll(m & ((1ull << l) - 1ull));
                     wave_lds_sync();
                     if ((m >> l) & 1ull) pend[at] = ordL;
@@ -1927,6 +1990,9 @@ __device__ __forceinline__ void prefilter_unit(
                     wave_lds_sync();
                     pendCount -= take;
                     m = __ballot((int)l < take && (ordL & 0xFFFFu) < zeroBound);
+                    // (what waits here has passed the four-point test by SADs, or by distances against larger thresholds)
+                    if (useFourSad && fourPointApplies() && __builtin_popcountll(m) > LFG_FOUR_MIN_WIDE)
+                        m = __ballot(fourPointBatch(ordL & 0x7FFFFFFFu, ((m >> l) & 1ull) != 0ull, false, std::false_type{}));
                     if (sixteenApplies() && __builtin_popcountll(m) > 8) m = sixteenBatch(ordL & 0x7FFFFFFFu, m, take == 64);
                     if (flushNow && firstFull) firstBatchSurvivors = __builtin_popcountll(m);
                     flushNow = false;

@@ -11,7 +11,8 @@ candidates that a bound clears
 for   sea     the successive-elimination bound |sum ||c|| - sum ||p||| <= sum ||c - p|| on box sums of texel norms,
       one     one distance of the block (the prefilter's 14-point lattice: every block holds one point),
       four    the four distances of the 4 x 4 lattice inside the block,
-      sixteen the sixteen distances of the 2 x 2 lattice inside the block.
+      sixteen the sixteen distances of the 2 x 2 lattice inside the block,
+      four_sad, sixteen_sad  the same with every distance replaced by half the sum of its absolute differences (<= the distance).
 
 The frames come from lfg_scale on the synthetic 1080p content (the bench's), nothing else runs on the GPU.
 usage: measure_bounds.py [content ...]        (default: noisy occluded objects)"""
@@ -53,7 +54,7 @@ def segment_stats(prev, curr, sx, sy, unmatched_only):
     cn = np.sqrt((c * c).sum(-1))
     cbox = box(cn)
     costs = np.empty((2 * R + 1, 2 * R + 1, SEG_H, SEG_W), np.float32)
-    bounds = {k: np.empty_like(costs) for k in ("sea", "one", "four", "sixteen")}
+    bounds = {k: np.empty_like(costs) for k in ("sea", "one", "four", "four_sad", "sixteen", "sixteen_sad")}
     for dy in range(-R, R + 1):
         for dx in range(-R, R + 1):
             p = prev[sy - 4 + dy:sy - 4 + dy + SEG_H + B - 1, sx - 4 + dx:sx - 4 + dx + SEG_W + B - 1].astype(np.float32)
@@ -63,6 +64,9 @@ def segment_stats(prev, curr, sx, sy, unmatched_only):
             bounds["one"][dy + R, dx + R] = lattice(d, 8, 7, 7)
             bounds["four"][dy + R, dx + R] = lattice(d, 4, 3, 3)
             bounds["sixteen"][dy + R, dx + R] = lattice(d, 2, 0, 0)
+            half_sad = 0.5 * np.abs(p - c).sum(-1)               # a distance is at least half the sum of its absolute differences
+            bounds["four_sad"][dy + R, dx + R] = lattice(half_sad, 4, 3, 3)
+            bounds["sixteen_sad"][dy + R, dx + R] = lattice(half_sad, 2, 0, 0)
     thr = costs.reshape(-1, SEG_H, SEG_W).min(0)
     out = {"thr_median": float(np.median(thr)), "thr_max": float(thr.max()), "unmatched": float((thr >= 2048).mean())}
     for k, b in bounds.items():
