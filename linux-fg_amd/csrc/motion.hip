@@ -1111,20 +1111,14 @@ __device__ __forceinline__ void prefilter_unit(
 #ifndef LFG_FOURPOINT_MAX
 #define LFG_FOURPOINT_MAX (4.0f * 510.0f)
 #endif
-#ifndef LFG_FOUR_SAD
-#define LFG_FOUR_SAD 0                   // the four-point test by sums of absolute differences first (see fourPointBatch): measured, no gain
-#endif
-        bool useFourPoint = true, useFourSad = LFG_FOUR_SAD != 0, useSixteen = LFG_SIXTEEN != 0;
+        bool useFourPoint = true, useSixteen = LFG_SIXTEEN != 0;
         auto fourPointApplies = [&]() { return useFourPoint && !(waveThr < kOnePointMax) && waveThr < LFG_FOURPOINT_MAX; };
         // (per lane: the candidate `ordL` still has to be evaluated in full)
-        // sadC: the same walk with every distance replaced by half the sum of its four absolute differences -- a distance is
-        // at least that (Cauchy-Schwarz: |d|_1 <= 2 |d|_2 for four channels), so "every group's four SADs sum to more than
-        // 2 waveThr" clears a candidate just as well, for one v_sad_u8 per point instead of three dot products, two adds and
-        // a square root.  On frames with sensor noise it clears 98.3 % of the candidates for the whole wave where the
-        // distances clear 99.6 % (tools/measure_bounds.py); what it leaves waits in the list of deferred candidates for
-        // the test by distances.
-        auto fourPointBatch = [&](const uint32_t ordL, bool need, const bool fullBatch, auto sadC) -> bool {
-                constexpr bool kSad = decltype(sadC)::value;
+        // (Tried in round 3 and dropped: the same walk on sums of absolute differences first -- a distance is at least half
+        //  its SAD, one v_sad_u8 per point instead of three dot products, two adds and a square root; it clears 98.3 % of
+        //  the candidates for a whole wave on frames with sensor noise where the distances clear 99.6 %, its survivors
+        //  deferred to the test by distances -- +1 % on those frames with frames in flight, -2 % one at a time and on a pan.)
+        auto fourPointBatch = [&](const uint32_t ordL, bool need, const bool fullBatch) -> bool {
                 // FOUR-point test, for thresholds a single distance rarely exceeds (a match under sensor noise costs a
                 // few hundred).  Block positions = 3 mod 4 form a lattice of 5 x 15 points of which every pixel's
                 // 8 x 8 block holds exactly a 2 x 2 group (columns 3 + 4 g, 7 + 4 g with g = i / 4 for pixel column i,
@@ -1137,9 +1131,8 @@ __device__ __forceinline__ void prefilter_unit(
                 // (Positions = 0 mod 4 did the same with 6 x 16 points until late in round 2.)
                 lds_ro_u32_ptr w = (lds_ro_u32_ptr)(sWin + kSeg * seg) + (ordL >> 16) + (3 * kWinH + 3);
                 auto bitsOf = [](float d) { return __builtin_bit_cast(uint32_t, d); };
-                uint32_t pMin = kSad ? 0xFFFFFFFFu : 0x7F800000u;
+                uint32_t pMin = 0x7F800000u;
                 float vPrev[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                uint32_t vPrevI[4] = {0u, 0u, 0u, 0u};
                 int tx0L = tx0, rowsL = ty0 + kSeg * seg;
                 asm volatile("" : "+s"(tx0L), "+s"(rowsL));
                 uint32_t rowRelevant = 0u;                              // bit h: some pixel row inside the image maps to vertical group h (rows 4 h .. 4 h + 3)
@@ -1159,7 +1152,7 @@ __device__ __forceinline__ void prefilter_unit(
                 // previous column whose sums are huge, not by a select per group
                 if (!kBorder) {
 #pragma unroll
-                    for (int h = 0; h < 4; ++h) { vPrevI[h] = 0x01000000u; vPrev[h] = 1.0e30f; }
+                    for (int h = 0; h < 4; ++h) vPrev[h] = 1.0e30f;
                 }
 #pragma unroll 3
                 for (int a = 0; a < kPTW / 4 + 1; ++a, w += 4 * kWinH) {   // lattice column 3 + 4 a closes group a - 1
@@ -1174,22 +1167,6 @@ __device__ __forceinline__ void prefilter_unit(
                     const uint32_t inImage = kBorder ? (uint32_t)__builtin_amdgcn_readlane((int)valid, colL) : 0xFFFFFFFFu;
                     // group (a - 1, h): its pixels are columns 4 (a - 1) .. + 3, rows 4 h .. + 3
                     const bool colRelevant = a > (kBanded ? gLo : 0) && (!kBorder || tx0L + 4 * (a - 1) < W);
-                    if constexpr (kSad) {
-                        uint32_t dI[5];
-#pragma unroll
-                        for (int b = 0; b < 5; ++b) {
-                            const uint32_t sad = __builtin_amdgcn_sad_u8((uint32_t)__builtin_amdgcn_readlane((int)c[3 + 4 * b], colL), tex[b], 0u);
-                            const uint32_t keep = 0u - ((inImage >> (3 + 4 * b)) & 1u);
-                            dI[b] = kBorder ? (sad & keep) : sad;
-                        }
-#pragma unroll
-                        for (int h = 0; h < 4; ++h) {
-                            const uint32_t vI = dI[h] + dI[h + 1];
-                            if (kBorder) pMin = min(pMin, (colRelevant && ((rowRelevant >> h) & 1u)) ? vPrevI[h] + vI : 0xFFFFFFFFu);
-                            else pMin = min(pMin, vPrevI[h] + vI);
-                            vPrevI[h] = vI;
-                        }
-                    } else {
                     float d[5];
 #pragma unroll
                     for (int b = 0; b < 5; ++b) {
@@ -1207,23 +1184,20 @@ __device__ __forceinline__ void prefilter_unit(
                         else pMin = min(pMin, g);
                         vPrev[h] = v[h];
                     }
-                    }
                 }
                 };
                 if (border) { if (restricted) walk(std::true_type{}, std::true_type{}); else walk(std::false_type{}, std::true_type{}); }
                 else        { if (restricted) walk(std::true_type{}, std::false_type{}); else walk(std::false_type{}, std::false_type{}); }
-                // (by SADs: the smallest group sum is an exact integer, at most 4080, and half of it bounds the four distances)
-                bool pass = kSad ? !((float)pMin * 0.5f > waveThr * 1.000002f) : !(pMin > bitsOf(waveThr * 1.000002f));
+                bool pass = !(pMin > bitsOf(waveThr * 1.000002f));
                 if (restricted) pass = zeroHit(ordL) || pass;          // (the settled pixels outside the band)
                 need = need && pass;
-                if (fullBatch && __builtin_popcountll(__ballot(need)) >= 48) { if (kSad) useFourSad = false; else useFourPoint = false; }
+                if (fullBatch && __builtin_popcountll(__ballot(need)) >= 48) useFourPoint = false;
                 return need;
         };
 #ifndef LFG_SIXTEEN_MAX
 #define LFG_SIXTEEN_MAX 2048.0f
 #endif
         auto sixteenApplies = [&]() { return useSixteen && !(waveThr < kOnePointMax) && waveThr < LFG_SIXTEEN_MAX; };
-        bool deferSurvivors = false;       // set by latticeBatch: what it left has only passed the test by SADs and joins the deferred candidates
         // bit k of the result: candidate i0 + k of the staged order has to be evaluated in full
         // (ordL: this lane's candidate, an entry of the order; need: it has to be looked at; fullBatch: 64 candidates)
         auto latticeBatch = [&](const uint32_t ordL, bool need, const bool fullBatch) -> unsigned long long {
@@ -1307,17 +1281,7 @@ __device__ __forceinline__ void prefilter_unit(
 #define LFG_FOUR_MIN_WIDE 2
 #endif
             const int fourFrom = waveThr < LFG_ONEPOINT_OFF ? 8 : LFG_FOUR_MIN_WIDE;
-            deferSurvivors = false;
-            if (fourPointApplies() && __builtin_popcountll(__ballot(need)) > fourFrom) {
-                if (useFourSad && sixteenApplies()) {
-                    need = fourPointBatch(ordL, need, fullBatch, std::true_type{});
-                    // many left: the distances at once; a few: they wait for company (and for the distances) with the deferred ones
-                    if (__builtin_popcountll(__ballot(need)) > 8) need = fourPointBatch(ordL, need, fullBatch, std::false_type{});
-                    else deferSurvivors = true;
-                } else {
-                    need = fourPointBatch(ordL, need, fullBatch, std::false_type{});
-                }
-            }
+            if (fourPointApplies() && __builtin_popcountll(__ballot(need)) > fourFrom) need = fourPointBatch(ordL, need, fullBatch);
             return __ballot(need);
         };
         // bit k of the result: lane k's candidate (ordL) still has to be evaluated in full
@@ -1955,7 +1919,18 @@ __device__ __forceinline__ void prefilter_unit(
                     else { i0 += count; count = i0 == LFG_FIRST_BATCH ? hintsEnd - LFG_FIRST_BATCH : 64; }
                     continue;
                 }
-                if ((sixteenApplies() && __builtin_popcountll(m) > 8) || (deferSurvivors && m != 0ull)) {     // the survivors wait for company
+#ifndef LFG_DEFER_FROM
+#define LFG_DEFER_FROM 0                // a batch's survivors wait in the list when they are more than this many (0: always -- a
+                                        // lone survivor evaluated on the spot is an evaluation without anything to overlap with: window
+                                        // reads, column sums, slab round trip and row sums one after the other; a dozen together at
+                                        // the end of the search run software-pipelined.  8 until round 3: noisy frames +3 % with
+                                        // frames in flight, +8 % one at a time)
+#endif
+#ifndef LFG_SIXTEEN_FROM
+#define LFG_SIXTEEN_FROM 12             // ... and the sixteen-point test runs on more than this many of them (its 4,400 instructions
+                                        // are a dozen evaluations)
+#endif
+                if (sixteenApplies() && __builtin_popcountll(m) > LFG_DEFER_FROM) {     // the survivors wait for company
                     const uint32_t at = (uint32_t)pendCount + (uint32_t)__builtin_popcountll(m & ((1ull << l) - 1ull));
                     wave_lds_sync();
                     if ((m >> l) & 1ull) pend[at] = ordL;
@@ -1990,10 +1965,7 @@ __device__ __forceinline__ void prefilter_unit(
                     wave_lds_sync();
                     pendCount -= take;
                     m = __ballot((int)l < take && (ordL & 0xFFFFu) < zeroBound);
-                    // (what waits here has passed the four-point test by SADs, or by distances against larger thresholds)
-                    if (useFourSad && fourPointApplies() && __builtin_popcountll(m) > LFG_FOUR_MIN_WIDE)
-                        m = __ballot(fourPointBatch(ordL & 0x7FFFFFFFu, ((m >> l) & 1ull) != 0ull, false, std::false_type{}));
-                    if (sixteenApplies() && __builtin_popcountll(m) > 8) m = sixteenBatch(ordL & 0x7FFFFFFFu, m, take == 64);
+                    if (sixteenApplies() && __builtin_popcountll(m) > LFG_SIXTEEN_FROM) m = sixteenBatch(ordL & 0x7FFFFFFFu, m, take == 64);
                     if (flushNow && firstFull) firstBatchSurvivors = __builtin_popcountll(m);
                     flushNow = false;
                 }
