@@ -14,6 +14,17 @@ stats() {   # $1 = name, rest = bench args [env prefix via LFG_MOTION_MODE]
       > $OUT/${TAG}_${name}_bench_under_rocprof.json 2> /tmp/prof_$name.err
   cp $(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${name}_kernel_stats.csv
 }
+N=10
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_$c
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 $R/tools/run_stage.py pipeline $N > /dev/null 2>&1
+done
+python3 $R/tools/pmc_per_step.py $N /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE > $OUT/${TAG}_hbm_traffic_pmc.txt
+rm -rf /tmp/pmc_sq
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT \
+    --output-format csv -d /tmp/pmc_sq -- python3 $R/tools/run_stage.py pipeline $N > /dev/null 2>&1
+python3 $R/tools/pmc_per_step.py $N /tmp/pmc_sq > $OUT/${TAG}_sq_counters.txt
+cp $OUT/${TAG}_hbm_traffic_pmc.txt $OUT/${TAG}_sq_counters.txt $R/profiles/    # (this box's copy of the tree: the bench lines below quote the tables of the library they ran)
 stats pipeline --steps 300 --warmup 6                      # the default command: three frames in flight (kernels of neighbouring steps overlap)
 stats pipeline_one_lane --steps 200 --warmup 5 --in-flight 1   # one frame at a time: the durations bench.py's stages / dominant_stage quote
 stats scale --workload scale --steps 2000 --warmup 50
@@ -30,14 +41,4 @@ python3 $R/bench.py --input 4k --factors 0.25,0.5,0.75 --in-flight 1 --no-extras
 python3 $R/bench.py --input 4k --factors 0.25,0.5,0.75 --no-extras --no-cpu-baseline --steps 300 --warmup 12 > $OUT/${TAG}_config5_bench.json 2>> /tmp/bench.err
 rc=0; python3 $R/bench.py --gpus 2 --steps 5 > $OUT/${TAG}_gpus2_on_one_gpu.txt 2>&1 || rc=$?; echo "exit code $rc" >> $OUT/${TAG}_gpus2_on_one_gpu.txt   # the launcher's refusal on a box with one GPU
 echo "bench done"
-N=10
-for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pmc_$c
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 $R/tools/run_stage.py pipeline $N > /dev/null 2>&1
-done
-python3 $R/tools/pmc_per_step.py $N /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE > $OUT/${TAG}_hbm_traffic_pmc.txt
-rm -rf /tmp/pmc_sq
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT \
-    --output-format csv -d /tmp/pmc_sq -- python3 $R/tools/run_stage.py pipeline $N > /dev/null 2>&1
-python3 $R/tools/pmc_per_step.py $N /tmp/pmc_sq > $OUT/${TAG}_sq_counters.txt
 echo "pmc done"; ls -la $OUT
