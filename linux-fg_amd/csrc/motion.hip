@@ -444,7 +444,7 @@ constexpr int kRunIn = kRun + kB - 1;             // 13
 #define LFG_QUEUE_INIT 1
 #endif
 #ifndef LFG_LOOKAHEAD
-#define LFG_LOOKAHEAD 2                 // candidates per lane of the lookahead (0 or 1: off)
+#define LFG_LOOKAHEAD 3                 // candidates per lane of the lookahead (0 or 1: off; 2 until the ranks gave the window offsets by arithmetic)
 #endif
 #ifndef LFG_SAD_TEST
 #define LFG_SAD_TEST 1                   // one-point lattice test by SAD while the wave's largest threshold is small
@@ -588,6 +588,12 @@ __device__ __forceinline__ void prefilter_unit(
     // (the two flags of this call's order, requested here: read where they are used -- behind the staging barrier -- each
     //  was a scalar load from memory with nothing to hide its latency, two microseconds per unit)
     const uint32_t orderHandOver = order32[kCand], orderHints = order32[kCand + 1];
+#ifndef LFG_RANK_ARITH
+#define LFG_RANK_ARITH 1                 // by rank, the window offset of a candidate from its rank by arithmetic (see candidateAt)
+#endif
+    // (the shaders' own tie order: a candidate's rank IS its place in the scan -- rank 0 is the scan's first vector, not the
+    //  zero vector the intended order starts with)
+    const bool rankIsScan = LFG_RANK_ARITH && rank2scan[0] == 0u;
     const uint32_t unitAuxFirst = (!whole && !fromQueue) ? sp.unitAux[unit] : 0u;      // (likewise: its lists are addressed behind the barrier)
     // A unit that shares its tile first runs the head of the order -- zero motion and the first hints -- for the
     // thresholds only (not recorded: the unit that owns those entries records them).  Without it a unit whose part
@@ -1785,14 +1791,24 @@ __device__ __forceinline__ void prefilter_unit(
                         return nd;
                     }
                     const int r = rank0 + ahead + (int)l;
-                    const int e = (int)sInv[min(r, kCand - 1)];                       // where the order visits rank r
-                    ord = ((lds_ro_u32_ptr)sOrder)[e] | 0x80000000u;
+                    const int rc = min(r, kCand - 1);
+                    const int e = (int)sInv[rc];                                      // where the order visits rank r
+                    if (rankIsScan) {
+                        // rank = scan index = 33 (dy + R) + (dx + R): the entry the order holds for it, without asking the order -- the
+                        // window reads then wait for nothing but this arithmetic, and `e` only decides whether the lane counts
+                        // (three dependent LDS round trips per pass were two too many)
+                        const uint32_t dyi = ((uint32_t)rc * 1986u) >> 16;            // rc / 33 for rc < 1089
+                        const uint32_t dxi = (uint32_t)rc - 33u * dyi;
+                        ord = (uint32_t)rc | ((dxi * (uint32_t)kWinH + dyi) << 16) | 0x80000000u;
+                    } else {
+                        ord = ((lds_ro_u32_ptr)sOrder)[e] | 0x80000000u;
+                    }
                     return r < (int)zeroBound && e >= eBegin && e < eEnd && nHead + (e - eBegin) >= visited;
                 };
                 // LOOKAHEAD.  While the thresholds are small (the one-point test alone decides, and nearly always "no") a
                 // batch is three LDS round trips of latency around a few dozen instructions -- and a workgroup's time on
                 // its CU slot, not its instruction count, is what a frame costs once frames overlap.  So
-                // the wave first asks about the next 128 candidates at once -- two per lane (LFG_LOOKAHEAD), their window reads in flight
+                // the wave first asks about the next 192 candidates at once -- three per lane (LFG_LOOKAHEAD), their window reads in flight
                 // together, the current-frame texels of the lattice points fetched once for both -- and if none of them
                 // has to be looked at, skips both batches.  Otherwise the batches are taken one by one as usual.
                 constexpr int kAhead = LFG_LOOKAHEAD;                  // candidates per lane (0: off)
