@@ -2247,7 +2247,14 @@ __device__ __forceinline__ void prefilter_unit(
             thresholdsNeeded = true;
         }
     }
-    if (thresholdsNeeded) writeThresholds();
+#ifndef LFG_LATE_THRESHOLDS
+#define LFG_LATE_THRESHOLDS 1            // a segment unit that pools its four parts writes thresholds and counts only if a pixel stays open
+#endif
+    // (a segment unit whose four waves hold all parts of the order learns below whether any pixel is left to the resolve
+    //  kernel; if none is -- most rim segments under a pan -- its 4 x 7 KB of thresholds and counts are never read: they were
+    //  25 MB of the prefilter's 53 MB of writes per 4K frame, against 17 MB of vectors)
+    const bool pooledUnit = LFG_LATE_THRESHOLDS && segUnit && nChunks == 4;
+    if (thresholdsNeeded && !pooledUnit) writeThresholds();
     // A segment that is left to the resolve kernel goes onto its list, once: by the wave that owns it (whole tiles), by the
     // unit that holds the first part of the order (tiles shared between units), or -- segment units -- further down.
     if (thresholdsNeeded && !gaveUp && !segUnit && chunk == 0 && lane == 0)
@@ -2367,6 +2374,7 @@ __device__ __forceinline__ void prefilter_unit(
             if (*sOpen == 0u) segDone[tile * (kPTH / kSeg) + seg] = 1u;
             else sp.openList[atomicAdd(sp.openCount, 1u)] = (uint32_t)(tile * (kPTH / kSeg) + seg);
         }
+        if (pooledUnit && *(volatile uint32_t *)sOpen != 0u) writeThresholds();
     }
 #ifdef LFG_MOTION_STAMPS
     if (lane == 0 && (fromQueue ? sp.units + unit : unit) < 8192)      // (the end of the unit with its epilogue)
