@@ -81,6 +81,9 @@ def parse_args():
                          "buffers, so one frame's scale / hints / first prefilter units fill the CUs that the previous frame's last "
                          "long units leave idle; 1 = strictly one frame at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fused-motion-interpolate", action="store_true",
+                    help="pipeline workload, one factor: lfg_interpolate_frames in the north-star order (lfg_set_fused_motion_interpolate: the motion "
+                         "kernels write the generated frame themselves, no interpolate dispatch, no motion-vector frame); a labelled variant, not the default")
     ap.add_argument("--no-extras", action="store_true", help="skip scale_only / scale_interpolate / content_sweep (profiling runs)")
     return ap.parse_args()
 
@@ -466,6 +469,10 @@ def main():
             keep_alive.append(bufs)
             lane_bufs.append((bufs[0][1], bufs[1][1], [f for _, f in bufs[2:2 + len(factors)]], fp4))
 
+    fused_mi = bool(args.fused_motion_interpolate) and args.workload == "pipeline" and len(factors) == 1
+    if fused_mi:
+        ctx.set_fused_motion_interpolate(True)
+
     def interpolate_all(fp, fc, fm, fouts=None):
         fouts = f_outs if fouts is None else fouts
         if len(factors) == 1:
@@ -486,6 +493,9 @@ def main():
         ctx.scale(fc_in, fc4)
         if lanes > 1:
             ctx.lane_mark()
+        if fused_mi:
+            ctx.interpolate_frames(fp4, fc4, fouts[0], factors[0])   # motion + interpolate in one call: the motion kernels write the frame
+            return
         ctx.motion(fp4, fc4, fmv, 8, 16.0)
         interpolate_all(fp4, fc4, fmv, fouts)
 
@@ -778,6 +788,8 @@ def main():
                                                                     else "motion(8,16)+interpolate at input resolution, then scale real and generated frame" if in_res
                                                                     else "scale only")),
                        "input": [w_in, h_in], "output": [w, h], "factors": factors if args.workload != "scale" else [],
+                       "order": ("north-star, fused: lfg_interpolate_frames with lfg_set_fused_motion_interpolate -- the motion kernels write the generated frame, "
+                                 "no interpolate dispatch, no motion-vector frame (a labelled variant)" if fused_mi else "one call per stage"),
                        "frames_in_flight": n_lanes,       # lanes of the C-ABI; 1 = strictly one frame at a time
                        "devices": devices,                # HIP device ordinal of every rank, in rank order
                        "content": args.content + (" (the motion stage's best case but `static`; see content_sweep)" if args.content == "translated" and args.workload != "scale" else ""),

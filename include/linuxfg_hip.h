@@ -245,6 +245,15 @@ int  lfg_interpolate_frames(lfg_context *ctx, const lfg_frame *prev, const lfg_f
 #define LFG_MAX_FACTORS 16
 int  lfg_interpolate_multi(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *curr, const lfg_frame *mv,
                            lfg_frame *const *outs, const float *factors, uint32_t count);
+/* lfg_interpolate_frames in the north-star ORDER (the reference dispatches motion and then
+ * interpolate on the same grid, src/frame_manager.cpp:342-366, the second reading what the first wrote): with 1, the
+ * motion kernels (blockSize 8, searchRadius 16 paths) write the generated frame from each vector at the moment it is
+ * decided -- the same per-pixel function the interpolate kernel is made of, so the bytes are identical -- the interpolate
+ * dispatch is gone and the motion-vector temporary is never written.  Default 0: the two stages (measured: DESIGN.md
+ * section 4.4).  Also set by LFG_FUSED_MOTION_INTERPOLATE=1 in the environment at context creation.  lfg_interpolate_frames_multi
+ * always runs the two stages. */
+int  lfg_set_fused_motion_interpolate(lfg_context *ctx, int enabled);
+
 /* lfg_interpolate_frames for several factors: motion (blockSize 8, searchRadius 16) ONCE, then
  * lfg_interpolate_multi with the context-owned motion-vector temporary. */
 int  lfg_interpolate_frames_multi(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *curr,

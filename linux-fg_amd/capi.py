@@ -84,6 +84,7 @@ SIGNATURES = {
     "lfg_interpolate_frames_multi": (_i, [_vp, _FP, _FP, ctypes.POINTER(_FP), ctypes.POINTER(ctypes.c_float), _u32]),
     "lfg_interpolate_scale": (_i, [_vp, _FP, _FP, _FP, _FP, ctypes.c_float]),
     "lfg_set_fused_interpolate_scale": (_i, [_vp, _i]),
+    "lfg_set_fused_motion_interpolate": (_i, [_vp, _i]),
     "lfg_mv_export_rgba32f": (_i, [_vp, _FP, _vp]),
     "lfg_selftest_sqrt": (_i, [_vp, _u32, _u32, ctypes.POINTER(ctypes.c_uint64)]),
     "lfg_comm_unique_id": (_i, [_vp]),
@@ -310,6 +311,10 @@ class Context:
         po, pf, n = self._multi_args(outs, factors)
         self._check(self.lib.lfg_interpolate_frames_multi(self.h, ctypes.byref(prev), ctypes.byref(curr), po, pf, n),
                     "lfg_interpolate_frames_multi")
+
+    def set_fused_motion_interpolate(self, on: bool):
+        """lfg_interpolate_frames in the north-star order: the motion kernels write the generated frame themselves."""
+        self._check(self.lib.lfg_set_fused_motion_interpolate(self.h, int(on)), "lfg_set_fused_motion_interpolate")
 
     def set_fused_interpolate_scale(self, on: bool):
         self._check(self.lib.lfg_set_fused_interpolate_scale(self.h, int(on)), "lfg_set_fused_interpolate_scale")

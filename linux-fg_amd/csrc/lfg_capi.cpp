@@ -316,6 +316,7 @@ LFG_EXPORT int lfg_context_create(int device_ordinal, lfg_context **out_ctx) {
     if (const char *m = getenv("LFG_MOTION_HINTS")) ctx->motion_hints = atoi(m) != 0;
     if (const char *m = getenv("LFG_MOTION_RIM_SPLIT")) { const int v = atoi(m); if (v == 4 || v == 8 || v == 48) ctx->rim_split_env = v; }
     if (const char *m = getenv("LFG_FUSED_INTERPOLATE_SCALE")) ctx->fuse_interpolate_scale = atoi(m) != 0;
+    if (const char *m = getenv("LFG_FUSED_MOTION_INTERPOLATE")) ctx->fuse_motion_interpolate = atoi(m) != 0;
     if (const char *m = getenv("LFG_MOTION_MODE")) ctx->motion_mode = atoi(m) == 1 ? LFG_MOTION_EXACT_ONLY : LFG_MOTION_PREFILTERED;
     *out_ctx = ctx;
     return LFG_OK;
@@ -627,8 +628,12 @@ LFG_EXPORT int lfg_scale(lfg_context *ctx, const lfg_frame *in, lfg_frame *out) 
     return LFG_OK;
 }
 
-LFG_EXPORT int lfg_motion(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *curr, lfg_frame *mv,
-                          int block_size, float search_radius) {
+// lfg_motion, and -- fused != nullptr -- the motion stage of lfg_interpolate_frames in the north-star order: the kernels
+// write the generated frame themselves (lfg_internal.hpp: FusedOut).  *fusedDone tells the caller whether they did (the
+// generic kernel, for other block sizes, radii and frames of 2 GiB, does not).
+static int motion_run(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *curr, lfg_frame *mv,
+                      int block_size, float search_radius, const lfg::FusedOut *fused, bool *fusedDone) {
+    if (fusedDone) *fusedDone = false;
     if (!ctx) return LFG_ERR_INVALID;
     LFG_HIP(ctx, hipSetDevice(ctx->device));          // the stream belongs to this device (multi-GPU hosts)
     if (!frame_ok(prev, LFG_FORMAT_RGBA8_UNORM) || !frame_ok(curr, LFG_FORMAT_RGBA8_UNORM) ||
@@ -661,14 +666,21 @@ LFG_EXPORT int lfg_motion(lfg_context *ctx, const lfg_frame *prev, const lfg_fra
     }
     StageTimer timer(ctx, LFG_STAGE_MOTION);
     hipError_t e;
+    const lfg::FusedOut fo = (fused && tiled) ? *fused : lfg::FusedOut();
     if (tiled && ctx->motion_mode == LFG_MOTION_PREFILTERED)
         e = lfg::launch_motion_prefiltered_8_16(ctx->stream, *prev, *curr, *mv, ctx->motion_ws, ctx->motion_ws_layout, ctx->motion_units,
                                                 rank2scan, order32, order32 + lfg::kMotionTableWords,
-                                                ctx->motion_tables + 6 * lfg::kMotionTableWords, ctx->motion_hints, ctx->lanes.size() >= 2);
-    else if (tiled) e = lfg::launch_motion_tiled_8_16(ctx->stream, *prev, *curr, *mv, nullptr, rank2scan);
+                                                ctx->motion_tables + 6 * lfg::kMotionTableWords, ctx->motion_hints, ctx->lanes.size() >= 2, fo);
+    else if (tiled) e = lfg::launch_motion_tiled_8_16(ctx->stream, *prev, *curr, *mv, nullptr, rank2scan, nullptr, nullptr, fo);
     else e = lfg::launch_motion_generic(ctx->stream, *prev, *curr, *mv, block_size, R, ctx->semantics != 0);
     if (e != hipSuccess) return fail_hip(ctx, e, "motion kernel launch");
+    if (fusedDone) *fusedDone = fo.data != nullptr;
     return LFG_OK;
+}
+
+LFG_EXPORT int lfg_motion(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *curr, lfg_frame *mv,
+                          int block_size, float search_radius) {
+    return motion_run(ctx, prev, curr, mv, block_size, search_radius, nullptr, nullptr);
 }
 
 LFG_EXPORT int lfg_set_semantics(lfg_context *ctx, int semantics) {
@@ -831,6 +843,21 @@ LFG_EXPORT int lfg_interpolate_frames(lfg_context *ctx, const lfg_frame *prev, c
         int rc = lfg_frame_create(ctx, curr->width, curr->height, LFG_FORMAT_MV_S8X2, &mv);
         if (rc != LFG_OK) return fail(ctx, rc, "Failed to create motion vectors frame");
     }
+    if (ctx->fuse_motion_interpolate) {
+        // The north-star order: the motion kernels write the generated frame from the vectors while they
+        // hold them; the vector frame -- this call's temporary -- is not written at all.  `out` is checked as lfg_interpolate
+        // checks it; whatever the fused path does not cover (see motion_run) takes the two stages below.
+        if (!frame_ok(prev, LFG_FORMAT_RGBA8_UNORM) || !frame_ok(out, LFG_FORMAT_RGBA8_UNORM) || !same_size(curr, out) || out->pitch % 4u)
+            return fail(ctx, LFG_ERR_INVALID, "lfg_interpolate_frames: bad output frame (NULL, empty, wrong format, size or pitch)");
+        if (out->data == prev->data || out->data == curr->data)
+            return fail(ctx, LFG_ERR_INVALID, "lfg_interpolate_frames: the output aliases an input");
+        lfg::FusedOut fo;
+        fo.data = (uint8_t *)out->data; fo.pitch = (int)out->pitch; fo.t = factor; fo.intended = ctx->semantics != 0 ? 1 : 0; fo.storeMv = 0;
+        bool done = false;
+        int rc = motion_run(ctx, prev, curr, &mv, 8, 16.0f, &fo, &done);
+        if (rc != LFG_OK || done) return rc;
+        return lfg_interpolate(ctx, prev, curr, &mv, out, factor);     // (the generic kernel ran: it wrote the vectors)
+    }
     int rc = lfg_motion(ctx, prev, curr, &mv, 8, 16.0f);                      // frame_manager.cpp:332-333
     if (rc != LFG_OK) return rc;
     return lfg_interpolate(ctx, prev, curr, &mv, out, factor);
@@ -879,6 +906,12 @@ LFG_EXPORT int lfg_interpolate_frames_multi(lfg_context *ctx, const lfg_frame *p
     int rc = lfg_motion(ctx, prev, curr, &mv, 8, 16.0f);                      // frame_manager.cpp:332-333
     if (rc != LFG_OK) return rc;
     return lfg_interpolate_multi(ctx, prev, curr, &mv, outs, factors, count);
+}
+
+LFG_EXPORT int lfg_set_fused_motion_interpolate(lfg_context *ctx, int enabled) {
+    if (!ctx) return LFG_ERR_INVALID;
+    ctx->fuse_motion_interpolate = enabled != 0;
+    return LFG_OK;
 }
 
 LFG_EXPORT int lfg_set_fused_interpolate_scale(lfg_context *ctx, int enabled) {

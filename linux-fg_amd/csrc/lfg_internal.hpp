@@ -42,6 +42,18 @@ struct UvTable {
     float *d_uv = nullptr;        // [size rounded up to 4]
 };
 
+// lfg_interpolate_frames in the north-star order (the reference: motion dispatch, then interpolate
+// dispatch on the same grid, src/frame_manager.cpp:342-366): the motion kernels (8 / 16 paths) write the GENERATED frame from the
+// vector they have just decided, while it is in a register -- csrc/lfg_interp.hpp: interpolate_pixel, the very function the
+// interpolate kernel is made of -- and the motion-vector frame becomes an optional output.  data == nullptr: off.
+struct FusedOut {
+    uint8_t *data = nullptr;      // RGBA8, the size of curr
+    int pitch = 0;
+    float t = 0.5f;               // interpolationFactor
+    int intended = 0;             // lfg_set_semantics: the vector divided by the image size before it displaces uv
+    int storeMv = 1;              // 0: the caller has no use for the vectors (lfg_interpolate_frames' temporary)
+};
+
 struct MotionWorkspaceLayout { size_t list, umin, count, tileFlags, segDone, segMap, queueCount, ctrl, order, plan, auxList, auxUmin, auxCount,
                                queue, dynList, dynUmin, dynCount, dynInit, openList, merge, mergeBytes, total; int queueCap, slots, rimSplit, listMain, listAux, listDyn; };
 // Work units of the motion prefilter (motion.hip: prefilter_plan).  A unit is a 56 x 64 tile, or one of nChunks
@@ -66,6 +78,7 @@ struct PrefilterPlan {               // passed by value to the kernels
     uint32_t *dynCount;
     uint32_t *dynInit;               // per handed-over segment: the 16 x 56 thresholds of the wave that handed it over
     uint32_t *openList, *openCount;  // the segments left to the resolve kernel (tile * 4 + segment), appended as units end
+    FusedOut fused;                  // the generated frame, written where the vectors are decided (off: data == nullptr)
 };
 struct PrefilterPlanHost {
     int tilesX = 0, tiles = 0, units = 0, auxUnits = 0;
@@ -119,6 +132,7 @@ struct lfg_context {
     int semantics = 0;                         // 0: the shaders as written, 1: "intended" (lfg_set_semantics)
     uint32_t *motion_tables = nullptr;         // device: [semantics][rank2scan | order32 | entryOfScan], then baseScan
     bool fuse_interpolate_scale = false;       // lfg_interpolate_scale: one fused kernel instead of the two stages (measured slower)
+    bool fuse_motion_interpolate = false;      // lfg_interpolate_frames: the motion kernels write the generated frame themselves
     bool motion_hints = true;                  // per-call visiting order from sample-block hints (LFG_MOTION_HINTS=0: off)
     // the one exchange of the path (lfg_comm.cpp): an RCCL communicator, its stream and two events
     void *comm = nullptr;                      // ncclComm_t
@@ -149,7 +163,7 @@ int scale_2x_strips_per_xcd(int inH);
 void scale_2x_strip_host(int inH, int xcd, int index, int &first, int &steps);
 hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                     const lfg_frame &mv, const uint32_t *tileFlags, const uint32_t *rank2scan,
-                                    unsigned long long *merge = nullptr, uint32_t *flaggedTiles = nullptr);
+                                    unsigned long long *merge = nullptr, uint32_t *flaggedTiles = nullptr, const FusedOut &fused = FusedOut());
 // Candidate tables of the blockSize 8 / searchRadius 16 paths for one tie-break rule (motion.hip: motion_tables).
 constexpr int kMotionTableWords = 1092;     // 33 * 33 candidates + the sentinel, padded to a multiple of 4
 void motion_tables(bool intended, uint32_t *rank2scan, uint32_t *order32, uint32_t *entryOfScan, uint32_t *baseScan);
@@ -160,7 +174,8 @@ int prefilter_slots();      // workgroups of the prefilter kernel the current de
 hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                           const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &layout, int units,
                                           const uint32_t *rank2scan, const uint32_t *order32,
-                                          const uint32_t *entryOfScan, const uint32_t *baseScan, bool useHints, bool framesInFlight);
+                                          const uint32_t *entryOfScan, const uint32_t *baseScan, bool useHints, bool framesInFlight,
+                                          const FusedOut &fused = FusedOut());
 hipError_t launch_motion_generic(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                  const lfg_frame &mv, int block_size, int radius, bool intended);
 hipError_t launch_interpolate(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,

@@ -32,6 +32,7 @@
 //   straight from global memory (slow; used for non-default parameters and as an on-device cross-check).
 #include "lfg_device.hpp"
 #include "lfg_internal.hpp"
+#include "lfg_interp.hpp"
 
 #include <algorithm>
 #include <cstring>
@@ -55,6 +56,19 @@ __device__ __forceinline__ float exact_sqrt(float x) {
     const float r = __builtin_fmaf(-g, g, x);
     const float g2 = __builtin_fmaf(r, h, g);
     return x == 0.0f ? 0.0f : g2;          // rsq(0) = inf
+}
+
+// (The kernels that decide vectors are templates on kFused: the mere presence of this code in the default kernels -- a larger
+//  plan structure, a few scalar tests in the epilogues -- cost the default path 2-3 %, measured; instantiated twice, it costs nothing.)
+// The north-star order (lfg_internal.hpp: FusedOut): one pixel of the generated frame from the vector just decided for it --
+// interpolate_pixel is the function the interpolate kernel is made of (csrc/lfg_interp.hpp), its uv the same fp32 division
+// the kernel's tables hold, so the bytes are those of lfg_motion followed by lfg_interpolate.
+__device__ __forceinline__ void fused_pixel(const FusedOut &fo, const uint8_t *__restrict__ prev, int prevPitch,
+                                            const uint8_t *__restrict__ curr, int currPitch, int W, int H, int px, int py, int dx, int dy) {
+    float mx = (float)dx, my = (float)dy;
+    if (fo.intended) { mx = mx / (float)W; my = my / (float)H; }
+    *reinterpret_cast<uint32_t *>(fo.data + (size_t)py * (size_t)fo.pitch + (size_t)px * 4u) =
+        interpolate_pixel(prev, prevPitch, curr, currPitch, W, H, px, py, mx, my, fo.t);
 }
 
 // distance() of two texels already converted to float, oracle choice (7):
@@ -91,11 +105,12 @@ static_assert(kNT / 64 * kMainRows >= kDH && kExtra <= kNT, "phase-A map covers 
 
 constexpr int kShareBelow = 256;        // flagged tiles up to which the exact kernel shares each between several workgroups
 constexpr int kFallbackParts = 8;       // workgroups that share a flagged tile (contiguous parts of the tie order)
+template <bool kFused>
 __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int8_t *__restrict__ mv, int mvPitch, int W, int H, const uint32_t *__restrict__ tileFlags,
     const uint32_t *__restrict__ rank2scan, unsigned long long *__restrict__ merge,
-    uint32_t *__restrict__ flaggedTiles, int tilesX, int tiles) {
+    uint32_t *__restrict__ flaggedTiles, int tilesX, int tiles, FusedOut fo) {
     // Two uses.  tileFlags == nullptr: the literal kernel for the whole frame (LFG_MOTION_MODE=1), one workgroup per tile of
     // the 2-D grid.  Otherwise the SECOND PASS of the prefiltered path, ONE launch of a 1-D grid (max(tiles, kShareBelow *
     // kFallbackParts) workgroups) whatever the prefilter flagged -- usually nothing: every workgroup reads the count and leaves:
@@ -313,9 +328,11 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
             const int dyi = scan / kSide, dxi = scan - dyi * kSide;
             const uint32_t v = (uint32_t)(uint8_t)(int8_t)(dxi - kR) | ((uint32_t)(uint8_t)(int8_t)(dyi - kR) << 8);
             o[i >> 1] |= v << (16 * (i & 1));
+            if (kFused && fo.data && px0 + i < W) fused_pixel(fo, prev, prevPitch, curr, currPitch, W, H, px0 + i, py, dxi - kR, dyi - kR);
         }
         int8_t *dst = mv + (size_t)py * (size_t)mvPitch + (size_t)px0 * 2u;
-        if (px0 + 7 < W && (mvPitch & 15) == 0) {
+        if (kFused && !fo.storeMv) {
+        } else if (px0 + 7 < W && (mvPitch & 15) == 0) {
             *reinterpret_cast<uint4 *>(dst) = uint4{o[0], o[1], o[2], o[3]};
         } else {
 #pragma unroll
@@ -546,6 +563,7 @@ static_assert(LFG_DYN_PARTS == 4 || LFG_DYN_PARTS == 8, "four parts per queue en
 
 // One work unit of the prefilter (see motion_prefilter_kernel below, which hands units to its workgroups).
 // `unit` indexes the plan's unit table, or -- fromQueue -- the queue of segments handed over at run time.
+template <bool kFused>
 __device__ __forceinline__ void prefilter_unit(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int W, int H, Rec *__restrict__ list, float *__restrict__ uminOut,
@@ -2234,8 +2252,13 @@ __device__ __forceinline__ void prefilter_unit(
                 if (laneE < 56 && py < H && px < W) {
 #endif
                     const uint32_t two = *reinterpret_cast<const uint32_t *>(rows + row * kPTW + 2 * d);
+                    if (kFused && sp.fused.data) {           // (wave-uniform) the north-star order: the generated pixels of these two vectors
+                        fused_pixel(sp.fused, prev, prevPitch, curr, currPitch, W, H, px, py, (int)(int8_t)(two & 0xFFu), (int)(int8_t)((two >> 8) & 0xFFu));
+                        if (px + 1 < W) fused_pixel(sp.fused, prev, prevPitch, curr, currPitch, W, H, px + 1, py, (int)(int8_t)((two >> 16) & 0xFFu), (int)(int8_t)(two >> 24));
+                    }
                     int8_t *dst = mv + (size_t)py * (size_t)mvPitch + (size_t)px * 2u;
-                    if (wide && px + 1 < W) *reinterpret_cast<uint32_t *>(dst) = two;
+                    if (kFused && !sp.fused.storeMv) {
+                    } else if (wide && px + 1 < W) *reinterpret_cast<uint32_t *>(dst) = two;
                     else {
                         *reinterpret_cast<uint16_t *>(dst) = (uint16_t)two;
                         if (px + 1 < W) *reinterpret_cast<uint16_t *>(dst + 2) = (uint16_t)(two >> 16);
@@ -2361,7 +2384,9 @@ __device__ __forceinline__ void prefilter_unit(
                     const int dyi = scan / kSide, dxi = scan - dyi * kSide;
                     if (singleOf[hb][i] && block_leaves_prev(px0 + i, py, dxi - kR, dyi - kR, W, H)) settled = false;
                     if (settled) {
+                        if (kFused && sp.fused.data) fused_pixel(sp.fused, prev, prevPitch, curr, currPitch, W, H, px0 + i, py, dxi - kR, dyi - kR);
                         int8_t *dst = mv + (size_t)py * (size_t)mvPitch + (size_t)(px0 + i) * 2u;
+                        if (!kFused || sp.fused.storeMv)
                         *reinterpret_cast<uint16_t *>(dst) = (uint16_t)(uint8_t)(int8_t)(dxi - kR) | (uint16_t)((uint16_t)(uint8_t)(int8_t)(dyi - kR) << 8);   // both components, one store
                     }
                 }
@@ -2407,6 +2432,7 @@ constexpr uint32_t kNoUnit = 0xFFFFFFFFu;
 __device__ __forceinline__ uint32_t peek(uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t peek_hard(uint32_t *p) { return atomicCAS(p, 0xFFFFFFFFu, 0xFFFFFFFFu); }
 
+template <bool kFused>
 __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int W, int H, Rec *__restrict__ list, float *__restrict__ uminOut,
@@ -2481,7 +2507,7 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
         const uint32_t next = sNext[0], entry = sNext[1];
         if (next == kNoUnit) return;
         const bool fromQueue = (next >> 31) != 0u;
-        prefilter_unit(prev, prevPitch, curr, currPitch, W, H, list, uminOut, countOut, tileFlags, flagTilesX, order32, sp,
+        prefilter_unit<kFused>(prev, prevPitch, curr, currPitch, W, H, list, uminOut, countOut, tileFlags, flagTilesX, order32, sp,
                        mv, mvPitch, rank2scan, segDone, (int)(next & 0x7FFFFFFFu), fromQueue, entry, sWin, sSlab, sOrder, sInv, sGiveUp, sNarrow, sPending);
         if (!fromQueue) {
             __syncthreads();               // every wave of the unit is past its pushes
@@ -2522,6 +2548,7 @@ __device__ float exact_cost(const uint8_t *__restrict__ prev, int prevPitch, con
 // per 64 x 4 pixels of the frame -- 32,400 at 4K -- of which nine in ten read three flags and left: 51 us under a pan for ~550
 // segments with work.  Nothing waits for anything here: the list is complete when this launch starts.
 constexpr int kResolveGroups = 1024;
+template <bool kFused>
 __global__ __launch_bounds__(256) void motion_resolve_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int8_t *__restrict__ mv, int mvPitch, int W, int H, const Rec *__restrict__ list,
@@ -2780,7 +2807,9 @@ __global__ __launch_bounds__(256) void motion_resolve_kernel(
     if (live) {
         const int bscan = (int)rank2scan[bestC];
         const int dyi = bscan / kSide, dxi = bscan - dyi * kSide;
+        if (kFused && sp.fused.data) fused_pixel(sp.fused, prev, prevPitch, curr, currPitch, W, H, px, py, dxi - kR, dyi - kR);
         int8_t *dst = mv + (size_t)py * (size_t)mvPitch + (size_t)px * 2u;
+        if (!kFused || sp.fused.storeMv)
         *reinterpret_cast<uint16_t *>(dst) = (uint16_t)(uint8_t)(int8_t)(dxi - kR) | (uint16_t)((uint16_t)(uint8_t)(int8_t)(dyi - kR) << 8);   // both components, one store
     }
 #ifdef LFG_MOTION_STAMPS
@@ -2802,14 +2831,20 @@ __global__ __launch_bounds__(256) void motion_resolve_kernel(
 // whatever was flagged (see the kernel).
 hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                     const lfg_frame &mv, const uint32_t *tileFlags, const uint32_t *rank2scan,
-                                    unsigned long long *merge, uint32_t *flaggedTiles) {
+                                    unsigned long long *merge, uint32_t *flaggedTiles, const FusedOut &fused) {
     const int tilesX = ((int)curr.width + kTW - 1) / kTW, tilesY = ((int)curr.height + kTH - 1) / kTH;
     const dim3 grid = tileFlags ? dim3((unsigned)std::max(tilesX * tilesY, kShareBelow * kFallbackParts), 1, 1)
                                 : dim3((unsigned)tilesX, (unsigned)tilesY, 1);
-    hipLaunchKernelGGL(motion_tiled_8_16_kernel, grid, dim3(kNT), 0, s,
-                       (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
-                       (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, tileFlags, rank2scan,
-                       merge, flaggedTiles, tilesX, tilesX * tilesY);
+    if (fused.data)
+        hipLaunchKernelGGL(motion_tiled_8_16_kernel<true>, grid, dim3(kNT), 0, s,
+                           (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
+                           (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, tileFlags, rank2scan,
+                           merge, flaggedTiles, tilesX, tilesX * tilesY, fused);
+    else
+        hipLaunchKernelGGL(motion_tiled_8_16_kernel<false>, grid, dim3(kNT), 0, s,
+                           (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
+                           (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, tileFlags, rank2scan,
+                           merge, flaggedTiles, tilesX, tilesX * tilesY, fused);
     return hipGetLastError();
 }
 
@@ -2951,7 +2986,7 @@ int prefilter_slots() {
     int dev = 0, cus = 0, perCu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, motion_prefilter_kernel, kPNT, 0) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, motion_prefilter_kernel<false>, kPNT, 0) != hipSuccess) return 0;
     return cus * perCu;
 }
 
@@ -3155,7 +3190,8 @@ __global__ __launch_bounds__(kHints) void motion_order_kernel(
 hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                           const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &l, int units,
                                           const uint32_t *rank2scan, const uint32_t *order,
-                                          const uint32_t *entryOfScan, const uint32_t *baseScan, bool useHints, bool framesInFlight) {
+                                          const uint32_t *entryOfScan, const uint32_t *baseScan, bool useHints, bool framesInFlight,
+                                          const FusedOut &fused) {
     const int tilesX = ((int)curr.width + kTW - 1) / kTW;
     Rec *list = reinterpret_cast<Rec *>(workspace + l.list);
     float *umin = reinterpret_cast<float *>(workspace + l.umin);
@@ -3181,6 +3217,7 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
     sp.dynInit = reinterpret_cast<uint32_t *>(workspace + l.dynInit);
     sp.openList = reinterpret_cast<uint32_t *>(workspace + l.openList);
     sp.openCount = reinterpret_cast<uint32_t *>(workspace + l.ctrl) + 4;
+    sp.fused = fused;
     uint32_t *segDone = reinterpret_cast<uint32_t *>(workspace + l.segDone);
     uint32_t *const ctrl = reinterpret_cast<uint32_t *>(workspace + l.ctrl);
     hipError_t e = hipSuccess;
@@ -3201,10 +3238,16 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
         if (e != hipSuccess) return e;
     }
     const int groups = std::max(1, std::min(sp.units, l.slots > 0 ? l.slots : sp.units));
-    hipLaunchKernelGGL(motion_prefilter_kernel, dim3(groups), dim3(kPNT), 0, s,
-                       (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
-                       (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, order, sp,
-                       (int8_t *)mv.data, (int)mv.pitch, rank2scan, segDone, ctrl);
+    if (fused.data)
+        hipLaunchKernelGGL(motion_prefilter_kernel<true>, dim3(groups), dim3(kPNT), 0, s,
+                           (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
+                           (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, order, sp,
+                           (int8_t *)mv.data, (int)mv.pitch, rank2scan, segDone, ctrl);
+    else
+        hipLaunchKernelGGL(motion_prefilter_kernel<false>, dim3(groups), dim3(kPNT), 0, s,
+                           (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
+                           (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, order, sp,
+                           (int8_t *)mv.data, (int)mv.pitch, rank2scan, segDone, ctrl);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
 #ifdef LFG_DIAG_NO_SLOW
@@ -3345,16 +3388,21 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
 #endif
     const int segments = sp.tilesX * (((int)curr.height + kPTH - 1) / kPTH) * (kPTH / kSeg);
     const int resolveGroups = framesInFlight ? segments * (kSeg / 4) : std::min(kResolveGroups, segments * (kSeg / 4));
-    hipLaunchKernelGGL(motion_resolve_kernel, dim3((unsigned)std::max(1, resolveGroups)), dim3(256), 0, s,
-                       (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
-                       (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, sp, rank2scan, segDone);
+    if (fused.data)
+        hipLaunchKernelGGL(motion_resolve_kernel<true>, dim3((unsigned)std::max(1, resolveGroups)), dim3(256), 0, s,
+                           (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
+                           (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, sp, rank2scan, segDone);
+    else
+        hipLaunchKernelGGL(motion_resolve_kernel<false>, dim3((unsigned)std::max(1, resolveGroups)), dim3(256), 0, s,
+                           (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
+                           (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, sp, rank2scan, segDone);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
 #ifdef LFG_DIAG_NO_FALLBACK             // (timing experiment: what the launch that usually finds nothing to do costs)
     return hipSuccess;
 #endif
     return launch_motion_tiled_8_16(s, prev, curr, mv, flags, rank2scan, reinterpret_cast<unsigned long long *>(workspace + l.merge),
-                                    sp.queueCount + 1);
+                                    sp.queueCount + 1, fused);
 }
 
 // Diagnostic: compares exact_sqrt with __builtin_sqrtf for every float whose bit pattern lies in

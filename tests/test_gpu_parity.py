@@ -873,6 +873,54 @@ def test_interpolate_frames_entry_point(ctx, oracle):
         ctx.destroy_frame(f)
 
 
+def test_interpolate_frames_in_the_north_star_order(ctx, oracle):
+    """lfg_set_fused_motion_interpolate: the motion kernels write the generated frame from each vector
+    as they decide it, the interpolate dispatch and the vector temporary are gone.  The frame has to be, byte for byte,
+    what the two stages produce -- on content that takes every route to a vector: segments settled in the prefilter (a
+    pan, a still), pooled rim segments, pixels the resolve kernel decides (noise, patches), tiles through the literal
+    kernel (a fade), the literal kernel alone, both tie orders, ragged and pitched frames -- and what the oracle says."""
+    from linux_fg_amd import capi
+    cases = [(128, 64, 5), (1000, 350, 6), (777, 301, 7), (1920, 1080, 8)]
+    for (w, h, seed) in cases:
+        prev, curr = _mixed_pair(w, h, 5100 + seed)
+        p, c = ctx.frame_from(prev), ctx.frame_from(curr)
+        a, b = ctx.create_frame(w, h), ctx.create_frame(w, h)
+        for mode in (capi.MOTION_PREFILTERED, capi.MOTION_EXACT_ONLY):
+            for semantics in (capi.SEMANTICS_REFERENCE, capi.SEMANTICS_INTENDED):
+                if (w, mode) == (1920, capi.MOTION_EXACT_ONLY) and semantics == capi.SEMANTICS_INTENDED:
+                    continue                                     # (17 ms a call: one tie order is enough at this size)
+                for t in (0.5, 0.25):
+                    ctx.set_motion_mode(mode); ctx.set_semantics(semantics)
+                    ctx.set_fused_motion_interpolate(False)
+                    ctx.interpolate_frames(p, c, a, t)
+                    ctx.set_fused_motion_interpolate(True)
+                    ctx.upload(b, np.full((h, w, 4), 0xA5, np.uint8))       # (every pixel has to be written)
+                    ctx.interpolate_frames(p, c, b, t)
+                    ctx.set_fused_motion_interpolate(False)
+                    assert (ctx.download(a) == ctx.download(b)).all(), (w, h, mode, semantics, t)
+        ctx.set_motion_mode(capi.MOTION_PREFILTERED); ctx.set_semantics(capi.SEMANTICS_REFERENCE)
+        if w <= 128:                                             # ... and the oracle, where it finishes in seconds
+            ctx.set_fused_motion_interpolate(True)
+            ctx.interpolate_frames(p, c, b, 0.5)
+            ctx.set_fused_motion_interpolate(False)
+            assert (ctx.download(b) == oracle.interpolate(prev, curr, oracle.motion(prev, curr), 0.5)).all()
+        for f in (p, c, a, b):
+            ctx.destroy_frame(f)
+    # a still and a pan at 4K-class size: the settled-in-place route for nearly every pixel
+    w, h = 2240, 1280
+    prev = synth.make_prev(w, h, seed=5200)
+    for curr in (prev.copy(), synth.translate(prev, (6, -4), 5201)):
+        p, c = ctx.frame_from(prev), ctx.frame_from(curr)
+        a, b = ctx.create_frame(w, h), ctx.create_frame(w, h)
+        ctx.interpolate_frames(p, c, a, 0.5)
+        ctx.set_fused_motion_interpolate(True)
+        ctx.interpolate_frames(p, c, b, 0.5)
+        ctx.set_fused_motion_interpolate(False)
+        assert (ctx.download(a) == ctx.download(b)).all()
+        for f in (p, c, a, b):
+            ctx.destroy_frame(f)
+
+
 def test_three_stage_path_small(ctx, oracle):
     """north_star order at small size: scale(prev), scale(curr) -> motion -> interpolate, each stage
     fed with the DEVICE result of the previous one; oracle chained the same way from the device's
