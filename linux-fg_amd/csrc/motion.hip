@@ -2094,8 +2094,8 @@ __device__ __forceinline__ void prefilter_unit(
         unsigned long long *o = gMotionStamps + ((size_t)(fromQueue ? sp.units + unit : unit) * 4 + wave) * 8;
         o[0] = stampStart; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = stampEvals; o[3] = ((unsigned long long)borderTile << 32) | stampBatches | (((stampRunEnd - stampStart) & 0x3FFFFFFFull) << 33);
 #ifdef LFG_STAMP_LATTICE
-        stampFirst = stampStaged + stampLattice;      // ("first batch": the time in the lattice tests; "staging": in lookahead passes that skipped)
-        stampStaged = stampStart + stampAhead;
+        stampStaged = stampStart + stampAhead;        // ("staging": the time in lookahead passes that skipped; "first batch": in the lattice tests)
+        stampFirst = stampStaged + stampLattice;
 #ifdef LFG_STAMP_LATTICE2
         stampStaged = stampAheadFirst ? stampAheadFirst : stampStart;     // ("staging": when the first lookahead pass began)
 #endif
