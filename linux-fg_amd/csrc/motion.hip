@@ -3049,11 +3049,16 @@ constexpr int kHintWin = kB + 2 * kR;                // 40 x 40 texels of prev a
 // prefilter launch leaves on a CU.  With 1,024 threads (one or two candidates each, 10 us on an idle chip instead of 13)
 // it needed a CU with no prefilter workgroup at all, and with frames in flight (lanes) the next frame's hints waited
 // 300-500 us for one (kernel trace; the frame rate is the same -- the prefilter's workgroup slots are the bound -- but the
-// lanes' latency is not).
+// lanes' latency is not).  A context that runs one frame at a time has the chip to itself: there the kernel is launched
+// with 1,024 threads (round 3: a call under a pan 0.328 -> 0.324 ms).
 #ifndef LFG_HINT_THREADS
 #define LFG_HINT_THREADS 256
 #endif
-constexpr int kHintThreads = LFG_HINT_THREADS;
+constexpr int kHintThreadsInFlight = LFG_HINT_THREADS;
+#ifndef LFG_HINT_THREADS_ALONE
+#define LFG_HINT_THREADS_ALONE 1024      // a context that runs one frame at a time: nothing else wants the CU, and a call's latency is what counts
+#endif
+constexpr int kHintThreadsAlone = LFG_HINT_THREADS_ALONE;
 
 // One launch does two jobs (round 2: a memset in front of it): every workgroup first clears its share of the call's control
 // area (tile flags, segment marks and map, counters, queue: `clearWords` words from `clearFrom`) -- the prefilter launch
@@ -3061,6 +3066,7 @@ constexpr int kHintThreads = LFG_HINT_THREADS;
 // its own (motion_order_kernel, one workgroup): folded into the workgroup that finishes last here it cost the occluded frames
 // 5 - 15 % with three frames in flight (983 -> 905 frames/s with its tables in LDS, which no longer fits beside two resident
 // prefilter workgroups; 837 with a 1.2 KB version that does) for 5 us of one call's latency.
+template <int kHintThreads>
 __global__ __launch_bounds__(kHintThreads, kHintThreads <= 256 ? 4 : 1) void motion_hint_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int W, int H, uint32_t *__restrict__ hints, uint32_t *__restrict__ clearFrom, int clearWords) {
@@ -3226,9 +3232,15 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
         // marks and map, counters, queue -- and motion_order_kernel)
         uint32_t *hints = reinterpret_cast<uint32_t *>(workspace + l.order);
         uint32_t *callOrder = hints + kHints;
-        hipLaunchKernelGGL(motion_hint_kernel, dim3(kHints), dim3(kHintThreads), 0, s,
-                           (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
-                           (int)curr.width, (int)curr.height, hints, flags, (int)((l.order - l.tileFlags) / sizeof(uint32_t)));
+        // (256 threads a workgroup beside the prefilter launches of other frames in flight -- see the kernel --, 1,024 alone)
+        if (framesInFlight)
+            hipLaunchKernelGGL(motion_hint_kernel<kHintThreadsInFlight>, dim3(kHints), dim3(kHintThreadsInFlight), 0, s,
+                               (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
+                               (int)curr.width, (int)curr.height, hints, flags, (int)((l.order - l.tileFlags) / sizeof(uint32_t)));
+        else
+            hipLaunchKernelGGL(motion_hint_kernel<kHintThreadsAlone>, dim3(kHints), dim3(kHintThreadsAlone), 0, s,
+                               (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
+                               (int)curr.width, (int)curr.height, hints, flags, (int)((l.order - l.tileFlags) / sizeof(uint32_t)));
         hipLaunchKernelGGL(motion_order_kernel, dim3(1), dim3(kHints), 0, s, hints, baseScan, entryOfScan, callOrder);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
