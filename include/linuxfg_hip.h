@@ -198,6 +198,10 @@ int  lfg_set_motion_mode(lfg_context *ctx, int mode);
  * and the mean number of candidates recorded per pixel in the others (synchronises; reporting only). */
 int  lfg_motion_last_stats(lfg_context *ctx, uint32_t *out_tiles, uint32_t *out_fallback_tiles,
                            double *out_mean_recorded);
+/* After a prefiltered lfg_motion: how many 16-row segments of its 56 x 64 work tiles the prefilter left to the resolve
+ * kernel, and how many the frame has; every open segment is listed exactly once (synchronises; reporting and tests only).
+ * No reference counterpart: motion.comp (shaders/motion.comp:27-52) has one pass and no work lists. */
+int  lfg_motion_open_segments(lfg_context *ctx, uint32_t *out_open, uint32_t *out_segments);
 /* Bytes of device memory the prefiltered lfg_motion keeps for frames of this size (allocated on the first such call, kept
  * until the size changes or the context goes; one per lane).  No reference counterpart -- the reference's motion pass keeps
  * nothing between its two images (src/frame_manager.cpp:262-300); a host budgets lanes with it.  Needs no GPU work.

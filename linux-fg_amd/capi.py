@@ -75,6 +75,7 @@ SIGNATURES = {
     "lfg_motion": (_i, [_vp, _FP, _FP, _FP, _i, ctypes.c_float]),
     "lfg_set_motion_mode": (_i, [_vp, _i]),
     "lfg_motion_last_stats": (_i, [_vp, ctypes.POINTER(_u32), ctypes.POINTER(_u32), ctypes.POINTER(ctypes.c_double)]),
+    "lfg_motion_open_segments": (_i, [_vp, ctypes.POINTER(_u32), ctypes.POINTER(_u32)]),
     "lfg_motion_workspace_size": (_i, [_vp, _u32, _u32, ctypes.POINTER(ctypes.c_uint64)]),
     "lfg_motion_plan": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "lfg_set_semantics": (_i, [_vp, _i]),
@@ -273,6 +274,12 @@ class Context:
         t, f, m = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_double()
         self._check(self.lib.lfg_motion_last_stats(self.h, ctypes.byref(t), ctypes.byref(f), ctypes.byref(m)), "lfg_motion_last_stats")
         return t.value, f.value, m.value
+
+    def motion_open_segments(self):
+        """(segments the prefilter left to the resolve kernel, segments of the frame) of the last prefiltered lfg_motion."""
+        a, b = ctypes.c_uint32(), ctypes.c_uint32()
+        self._check(self.lib.lfg_motion_open_segments(self.h, ctypes.byref(a), ctypes.byref(b)), "lfg_motion_open_segments")
+        return a.value, b.value
 
     def motion_workspace_size(self, width: int, height: int) -> int:
         """Bytes the prefiltered motion path keeps for frames of this size (per lane)."""

@@ -137,23 +137,75 @@ hipError_t sync_lanes(lfg_context *ctx) {
 }
 
 // uv table of one axis length (lfg_internal.hpp: UvTable); a handful of sizes per context, kept until it goes.
-int build_uv_table(lfg_context *ctx, int size, const float **out) {
-    for (auto &t : ctx->uv_tables)
-        if (t.size == size) { *out = t.d_uv; return LFG_OK; }
-    std::vector<float> uv(((size_t)size + 3u) & ~(size_t)3u, 0.0f);
-    for (int p = 0; p < size; ++p) uv[(size_t)p] = ((float)p + 0.5f) / (float)size;      // interpolate.comp:30
-    lfg::UvTable t;
-    t.size = size;
-    LFG_HIP(ctx, hipMalloc((void **)&t.d_uv, uv.size() * sizeof(float)));
-    const hipError_t e = hipMemcpy(t.d_uv, uv.data(), uv.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(t.d_uv); return fail_hip(ctx, e, "hipMemcpy(uv table)"); }
-    if (ctx->uv_tables.size() >= 16) {             // bounded: the oldest goes (a queued kernel may still read it)
-        (void)sync_lanes(ctx);
+// Bounded like the axis tables: trim_uv_tables runs at the top of the interpolate entry points, BEFORE any pointer is taken,
+// so that the two lookups of a call (width, height) can never free each other's table.
+void trim_uv_tables(lfg_context *ctx) {
+    while (ctx->uv_tables.size() > 14) {
+        (void)sync_lanes(ctx);                                 // a queued kernel may still read it
         (void)hipFree(ctx->uv_tables.front().d_uv);
         ctx->uv_tables.erase(ctx->uv_tables.begin());
     }
+}
+int build_uv_table(lfg_context *ctx, int size, const lfg::UvTable **out) {
+    for (auto &t : ctx->uv_tables)
+        if (t.size == size) { *out = &t; return LFG_OK; }
+    const size_t n4 = ((size_t)size + 3u) & ~(size_t)3u, quads = n4 / 4u;
+    std::vector<float> uv(n4, 0.0f);
+    std::vector<uint8_t> centre(n4, 0);
+    for (int p = 0; p < size; ++p) {
+        uv[(size_t)p] = ((float)p + 0.5f) / (float)size;                                  // interpolate.comp:30
+        // texture() at uv[p] itself (csrc/lfg_interp.hpp: texture_bilinear, the same two roundings): texel p, fraction 0?
+        const float u = uv[(size_t)p] * (float)size - 0.5f;
+        const float fu = floorf(u);
+        centre[(size_t)p] = (fu == (float)p && u - fu == 0.0f) ? 1 : 0;
+    }
+    lfg::UvTable t;
+    t.size = size;
+    t.blocks = (int)((quads + 63u) / 64u);
+    std::vector<uint64_t> good((size_t)t.blocks, 0ull);
+    std::vector<uint16_t> bad;
+    const bool indexable = quads < 0xFFFFu;
+    for (size_t q = 0; q < quads; ++q) {
+        const bool all = 4 * q + 3 < (size_t)size && centre[4 * q] && centre[4 * q + 1] && centre[4 * q + 2] && centre[4 * q + 3];
+        if (all && indexable) good[q / 64u] |= 1ull << (q % 64u);
+        else if (indexable) bad.push_back((uint16_t)q);
+    }
+    bad.resize((bad.size() + 63u) / 64u * 64u, (uint16_t)0xFFFFu);
+    t.badSlots = (int)bad.size();
+    const size_t c64 = ((size_t)size + 63u) & ~(size_t)63u;
+    const size_t offCentre = n4 * sizeof(float), offGood = (offCentre + c64 + 15u) & ~(size_t)15u;
+    const size_t offBad = offGood + good.size() * sizeof(uint64_t);
+    const size_t bytes = offBad + bad.size() * sizeof(uint16_t) + 16u;
+    std::vector<uint8_t> host(bytes, 0);
+    memcpy(host.data(), uv.data(), n4 * sizeof(float));
+    memcpy(host.data() + offCentre, centre.data(), n4);
+    memcpy(host.data() + offGood, good.data(), good.size() * sizeof(uint64_t));
+    if (!bad.empty()) memcpy(host.data() + offBad, bad.data(), bad.size() * sizeof(uint16_t));
+    uint8_t *d = nullptr;
+    LFG_HIP(ctx, hipMalloc((void **)&d, bytes));
+    const hipError_t e = hipMemcpy(d, host.data(), bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); return fail_hip(ctx, e, "hipMemcpy(uv table)"); }
+    t.d_uv = reinterpret_cast<float *>(d);
+    t.d_centre = d + offCentre;
+    t.d_goodMask = indexable ? reinterpret_cast<uint64_t *>(d + offGood) : nullptr;
+    t.d_badQuads = indexable ? reinterpret_cast<uint16_t *>(d + offBad) : nullptr;
     ctx->uv_tables.push_back(t);
-    *out = t.d_uv;
+    *out = &ctx->uv_tables.back();
+    return LFG_OK;
+}
+
+// Both axes' tables of one interpolate call.  (The x table is looked up again after the y table has been built: the push may
+// have moved the vector.)
+int interp_tables(lfg_context *ctx, int width, int height, lfg::InterpTables *tb) {
+    trim_uv_tables(ctx);
+    const lfg::UvTable *tx = nullptr, *ty = nullptr;
+    int rc = build_uv_table(ctx, width, &tx);
+    if (rc == LFG_OK) rc = build_uv_table(ctx, height, &ty);
+    if (rc == LFG_OK) rc = build_uv_table(ctx, width, &tx);
+    if (rc != LFG_OK) return rc;
+    tb->uvx = tx->d_uv; tb->uvy = ty->d_uv;
+    tb->centreX = tx->d_centre; tb->centreY = ty->d_centre;
+    tb->goodMask = tx->d_goodMask; tb->badQuads = tx->d_badQuads; tb->blocks = tx->blocks; tb->badSlots = tx->badSlots;
     return LFG_OK;
 }
 
@@ -713,6 +765,21 @@ LFG_EXPORT int lfg_motion_plan(const lfg_context *ctx, int *out_rim_split, int *
     return LFG_OK;
 }
 
+// Reporting only: how many 16-row segments the prefilter of the last lfg_motion left to the resolve kernel, of how many the
+// frame has (64 x 64 tiles x 4).  A segment is listed once; tests hold the list to that.
+LFG_EXPORT int lfg_motion_open_segments(lfg_context *ctx, uint32_t *out_open, uint32_t *out_segments) {
+    if (!ctx) return LFG_ERR_INVALID;
+    if (!out_open || !out_segments) return fail(ctx, LFG_ERR_INVALID, "lfg_motion_open_segments: NULL argument");
+    if (!ctx->motion_ws || ctx->motion_ws_w == 0) return fail(ctx, LFG_ERR_INVALID, "lfg_motion_open_segments: the prefiltered path has not run");
+    LFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t tx = (ctx->motion_ws_w + 55u) / 56u, ty = (ctx->motion_ws_h + 63u) / 64u;      // (prefilter tiles: 56 x 64 pixels)
+    uint32_t open = 0;
+    LFG_HIP(ctx, hipMemcpy(&open, ctx->motion_ws + ctx->motion_ws_layout.ctrl + 4 * sizeof(uint32_t), sizeof(uint32_t), hipMemcpyDeviceToHost));
+    *out_open = open;
+    *out_segments = tx * ty * 4u;
+    return LFG_OK;
+}
+
 LFG_EXPORT int lfg_motion_last_stats(lfg_context *ctx, uint32_t *out_tiles, uint32_t *out_fallback_tiles,
                                      double *out_mean_recorded) {
     if (!ctx) return LFG_ERR_INVALID;
@@ -824,12 +891,11 @@ LFG_EXPORT int lfg_interpolate(lfg_context *ctx, const lfg_frame *prev, const lf
         return fail(ctx, LFG_ERR_INVALID, "lfg_interpolate: row pitch not a multiple of the pixel size");
     if (out->data == prev->data || out->data == curr->data)
         return fail(ctx, LFG_ERR_INVALID, "lfg_interpolate: output aliases an input");
-    const float *uvx = nullptr, *uvy = nullptr;
-    int rc = build_uv_table(ctx, (int)curr->width, &uvx);
-    if (rc == LFG_OK) rc = build_uv_table(ctx, (int)curr->height, &uvy);
+    lfg::InterpTables tb;
+    int rc = interp_tables(ctx, (int)curr->width, (int)curr->height, &tb);
     if (rc != LFG_OK) return rc;
     StageTimer timer(ctx, LFG_STAGE_INTERPOLATE);
-    hipError_t e = lfg::launch_interpolate(ctx->stream, *prev, *curr, *mv, *out, factor, ctx->semantics != 0, uvx, uvy);
+    hipError_t e = lfg::launch_interpolate(ctx->stream, *prev, *curr, *mv, *out, factor, ctx->semantics != 0, tb);
     if (e != hipSuccess) return fail_hip(ctx, e, "interpolate kernel launch");
     return LFG_OK;
 }
@@ -884,12 +950,11 @@ LFG_EXPORT int lfg_interpolate_multi(lfg_context *ctx, const lfg_frame *prev, co
         for (uint32_t j = 0; j < i; ++j)
             if (outs[j]->data == o->data) return fail(ctx, LFG_ERR_INVALID, "lfg_interpolate_multi: two outputs alias each other");
     }
-    const float *uvx = nullptr, *uvy = nullptr;
-    int rc = build_uv_table(ctx, (int)curr->width, &uvx);
-    if (rc == LFG_OK) rc = build_uv_table(ctx, (int)curr->height, &uvy);
+    lfg::InterpTables tb;
+    int rc = interp_tables(ctx, (int)curr->width, (int)curr->height, &tb);
     if (rc != LFG_OK) return rc;
     StageTimer timer(ctx, LFG_STAGE_INTERPOLATE);
-    hipError_t e = lfg::launch_interpolate_multi(ctx->stream, *prev, *curr, *mv, outs, factors, (int)count, ctx->semantics != 0, uvx, uvy);
+    hipError_t e = lfg::launch_interpolate_multi(ctx->stream, *prev, *curr, *mv, outs, factors, (int)count, ctx->semantics != 0, tb);
     if (e != hipSuccess) return fail_hip(ctx, e, "interpolate kernel launch");
     return LFG_OK;
 }

@@ -37,9 +37,32 @@ struct AxisTable {
 // uv[p] = ((float)p + 0.5f) / (float)size for p = 0 .. size - 1 (shaders/interpolate.comp:30): the normalised coordinate of a
 // pixel centre depends on its column (row) alone, so the interpolate kernels read it from a table built once per size on the
 // host -- the same fp32 division, bit for bit -- instead of five IEEE divisions per thread (the kernel was VALU-bound on them).
+//
+// Round 4: where nothing displaces the sample (a zero motion vector -- under the literal semantics the only vector whose samples
+// stay inside the image) texture() is asked for uv[p] itself, and fl(uv[p] * size - 0.5) is texel p with fraction 0
+// for most p but not for all: in fp32 102 of 3840 columns and 85 of 2160 rows miss by an ulp and get real bilinear weights.
+// `centre` marks the p that hit (the sample IS texel p: no coordinate arithmetic, no weights).  For the x axis the groups of four
+// pixels a thread works on ("quads") are split in two: `goodMask` has one bit per quad, set where all four pixels are centres --
+// a wave of the kernel's normal blocks covers 64 consecutive quads and switches the others' lanes off with one scalar load --
+// and `badQuads` lists the others, which the kernel's extra blocks work on, so that no lane of a normal wave ever needs the
+// bilinear code (interpolate.hip).
 struct UvTable {
     int size = 0;
-    float *d_uv = nullptr;        // [size rounded up to 4]
+    float *d_uv = nullptr;          // [size rounded up to 4]; the base of ONE allocation that also holds the arrays below
+    uint8_t *d_centre = nullptr;    // [size rounded up to 64]: 1 where the undisplaced sample of p is exactly texel p
+    uint64_t *d_goodMask = nullptr; // [blocks]: bit l of word b: quad 64 b + l lies inside the axis and is all centres
+    uint16_t *d_badQuads = nullptr; // [badSlots]: the other quads, ascending; padded with 0xFFFF.  nullptr: the axis is too long for 16-bit indices
+    int blocks = 0;                 // ceil(quads / 64)
+    int badSlots = 0;               // a multiple of 64
+};
+
+// What the interpolate kernels take besides the frames (interpolate.hip).
+struct InterpTables {
+    const float *uvx = nullptr, *uvy = nullptr;
+    const uint8_t *centreX = nullptr, *centreY = nullptr;
+    const uint64_t *goodMask = nullptr;        // of the x axis
+    const uint16_t *badQuads = nullptr;
+    int blocks = 0, badSlots = 0;
 };
 
 // lfg_interpolate_frames in the north-star order (the reference: motion dispatch, then interpolate
@@ -179,10 +202,10 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
 hipError_t launch_motion_generic(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                  const lfg_frame &mv, int block_size, int radius, bool intended);
 hipError_t launch_interpolate(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
-                              const lfg_frame &mv, const lfg_frame &out, float factor, bool intended, const float *uvx, const float *uvy);
+                              const lfg_frame &mv, const lfg_frame &out, float factor, bool intended, const InterpTables &tb);
 hipError_t launch_interpolate_multi(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv,
                                     const lfg_frame *const *outs, const float *factors, int count, bool intended,
-                                    const float *uvx, const float *uvy);
+                                    const InterpTables &tb);
 hipError_t launch_mv_export(hipStream_t s, const lfg_frame &mv, float *rgba32f);
 hipError_t launch_sqrt_selftest(hipStream_t s, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *d_mismatch);
 

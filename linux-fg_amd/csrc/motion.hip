@@ -2282,7 +2282,9 @@ __device__ __forceinline__ void prefilter_unit(
     // unit that holds the first part of the order (tiles shared between units), or -- segment units -- further down.
     if (thresholdsNeeded && !gaveUp && !segUnit && chunk == 0 && lane == 0)
         sp.openList[atomicAdd(sp.openCount, 1u)] = (uint32_t)(tile * (kPTH / kSeg) + seg);
-    if (segUnit && nChunks != 4 && !gaveUp && chunk == 0 && lane == 0)       // (eight parts, two workgroups: no pooled settling below)
+    // (eight parts, two workgroups: no pooled settling below.  Plan units only: a handed-over segment was listed by the wave
+    //  that pushed it -- listing it again here resolved it twice and could run past the list's tiles * 4 words)
+    if (segUnit && nChunks != 4 && !fromQueue && !gaveUp && chunk == 0 && lane == 0)
         sp.openList[atomicAdd(sp.openCount, 1u)] = (uint32_t)(tile * (kPTH / kSeg) + seg);
     // A segment unit does the same for its segment, its four waves pooling what each learnt about its part of the
     // candidate order: the tightest threshold of the four is the pixel's bound, every wave holds its own records

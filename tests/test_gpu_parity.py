@@ -565,6 +565,51 @@ def test_motion_hand_over_queue_overflows_gracefully(ctx):
     assert tuple(a[cy, cx]) == (-5, -3)                     # inside an island the translation is found
 
 
+def test_handed_over_segments_are_listed_once_then_flagged_tiles_merge_cleanly(ctx):
+    """Round 3 listed a handed-over segment twice for the resolve kernel (once by the wave that pushed it, once by the queue
+    unit that ran its first part): on a pair where the queue fills up the list of open segments ran past its tiles x 4 words
+    into the scratch where the parts of a flagged tile meet, and the NEXT call of that size merged against garbage.  Same
+    context, same size, no re-plan in between: a pair that hands over as many segments as the queue holds, then a pair with
+    flagged tiles (fade patches) -- the prefiltered path must equal the literal kernel on both, and no segment may be listed
+    twice."""
+    from linux_fg_amd import capi
+    W, H = 3840, 2160
+    prev = synth.make_prev(W, H, seed=synth.BASE_SEED + 9)
+    curr = synth.noise_bytes(W, H, 778)
+    moved = synth.translate(prev, (5, 3), synth.BASE_SEED + 9)
+    for gy in range(16):
+        for gx in range(16):
+            cx, cy = (2 * gx + 1) * W // 32, (2 * gy + 1) * H // 32
+            curr[cy - 14:cy + 14, cx - 14:cx + 14] = moved[cy - 14:cy + 14, cx - 14:cx + 14]
+    mix_prev, mix_curr = _uhd_mixture()
+    ctx.set_motion_mode(capi.MOTION_PREFILTERED)
+    p, c = ctx.frame_from(prev), ctx.frame_from(curr)
+    mp, mc = ctx.frame_from(mix_prev), ctx.frame_from(mix_curr)
+    mv = ctx.create_frame(W, H, capi.FORMAT_MV_S8X2)
+    try:
+        ctx.motion(p, c, mv)
+        a1 = ctx.download(mv)
+        open1, segments = ctx.motion_open_segments()
+        assert segments == ((W + 55) // 56) * ((H + 63) // 64) * 4
+        assert 0 < open1 <= segments, (open1, segments)
+        ctx.motion(mp, mc, mv)                                   # flagged tiles: their parts meet in the scratch behind the list
+        a2 = ctx.download(mv)
+        open2, _ = ctx.motion_open_segments()
+        assert open2 <= segments, (open2, segments)
+        assert ctx.motion_last_stats()[1] > 0                    # (the fade patches did go through the fallback)
+        ctx.set_motion_mode(capi.MOTION_EXACT_ONLY)
+        ctx.motion(p, c, mv)
+        b1 = ctx.download(mv)
+        ctx.motion(mp, mc, mv)
+        b2 = ctx.download(mv)
+    finally:
+        ctx.set_motion_mode(capi.MOTION_PREFILTERED)
+        for f in (p, c, mp, mc, mv):
+            ctx.destroy_frame(f)
+    assert (a1 == b1).all(), f"{(a1 != b1).any(-1).sum()} pixels differ on the hand-over pair"
+    assert (a2 == b2).all(), f"{(a2 != b2).any(-1).sum()} pixels differ on the pair that followed it"
+
+
 def test_three_stages_at_8k(ctx, oracle):
     """BASELINE config 5 size (4K -> 8K, three interpolation factors): scale against the oracle on regions, motion by
     the translation property and against the literal kernel everywhere, interpolate exact on regions for each factor."""
@@ -586,6 +631,13 @@ def test_three_stages_at_8k(ctx, oracle):
         assert_within_1lsb(Cn[y0:y1, x0:x1], oracle.scale(cin, W, H, roi=roi)[y0:y1, x0:x1], max_mismatch=0.08)
     inner = Mn[48:H - 48, 48:W - 48]
     assert (inner[..., 0] == 4).all() and (inner[..., 1] == -10).all()
+    # ... and against the ORACLE itself where the oracle can afford it at this size (round 3 checked 8K vectors by the
+    # translation property and against the literal kernel only): a corner that holds both strips the pan exposes (the top rows
+    # and the right columns), the right border's strip alone, the bottom-left corner, and the interior
+    for roi in [(W - 72, 0, W, 28), (W - 40, 2000, W, 2032), (0, H - 28, 64, H), (3800, 2150, 3864, 2174), (0, 0, 64, 24)]:
+        x0, y0, x1, y1 = roi
+        want = as_int(oracle.motion(Pn, Cn, roi=roi))[y0:y1, x0:x1]
+        assert (Mn[y0:y1, x0:x1] == want).all(), f"8K vectors differ from the oracle in {roi}: {(Mn[y0:y1, x0:x1] != want).any(-1).sum()} pixels"
     ctx.set_motion_mode(capi.MOTION_EXACT_ONLY)
     try:
         ctx.motion(P, C, M)
@@ -679,6 +731,27 @@ def test_interpolate_ragged_sizes_exact(ctx, oracle, wh):
     got = run_interpolate(ctx, p, c, mv, 0.5)
     want = oracle.interpolate(p, c, mv.astype(np.float32), 0.5)
     assert (got == want).all()
+
+
+def test_interpolate_table_cache_survives_many_sizes(oracle):
+    """The per-size uv tables of the interpolate entry points are a bounded cache.  Round 3 evicted while a call already held
+    the width's table (the height's lookup could free it): more sizes than the cache holds, each checked against the oracle,
+    widths and heights arranged so that a call's width is the oldest entry when its height is new."""
+    from linux_fg_amd import capi
+    rng = np.random.default_rng(99)
+    c = capi.Context(0)
+    try:
+        sizes = [(40 + 4 * i, 20 + i) for i in range(12)]           # 24 distinct axis lengths
+        sizes += [(56, 70), (64, 71), (72, 72), (80, 73)]            # (56, 70): the width's table is the oldest cached entry, the height is new
+        for (w, h) in sizes:
+            prev = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+            curr = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+            mv = np.zeros((h, w, 2), np.int8)
+            mv[h // 2:] = rng.integers(-2, 3, size=(h - h // 2, w, 2))
+            got = run_interpolate(c, prev, curr, mv, 0.5)
+            assert (got == oracle.interpolate(prev, curr, mv.astype(np.float32), 0.5)).all(), (w, h)
+    finally:
+        c.close()
 
 
 def test_interpolate_kats(ctx):
