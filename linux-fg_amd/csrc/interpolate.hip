@@ -25,36 +25,120 @@ namespace lfg {
 // vector: static content, and under the literal semantics (F5) the ONLY vector whose samples stay inside the image -- and the
 // pixel centres' own uv land on texel centres in fp32, which the host has worked out per column and per row (lfg_internal.hpp:
 // UvTable::d_centre).  There texture() returns texel (px, py) itself (fraction 0: the other three bilinear products are exactly
-// 0), so the thread spends nothing on coordinates, range tests or weights: eight format-converting loads -- an 8_8_8_8 UNORM
-// descriptor makes the texture-address unit hand over byte / 255.0f as four floats, bit for bit the oracle's conversion
-// (tests/test_gpu_parity.py: test_interpolate_all_byte_values_round_trip) -- then mix and the packing, the same two functions as
-// everywhere else.  The columns whose uv misses its texel centre by an ulp (102 of 3840) would make some lane of EVERY wave
-// take the bilinear path, so the x axis is walked in the host's order: all-centre quads first, the others together in the
-// row's last waves, where the few pixels that need it are recomputed by the generic code.
-constexpr int kRsrcRgba8Unorm = (int)(4u | (5u << 3) | (6u << 6) | (7u << 9) | (0u << 12) | (10u << 15));
+// 0), so the thread spends nothing on coordinates, range tests or weights: eight loads, mix and the packing -- the same two
+// functions as everywhere else.  (tools/bench_blend.hip: the shape's floor on this chip, and the load forms against each other.)
+// The columns whose uv misses its texel centre by an ulp (102 of 3840, in 47 groups of four) are scattered over most waves of a
+// row.  In a centre ROW such a pixel is a blend of two neighbouring texels of its own row (fraction b = 0: the second row's two
+// products are exactly 0), so a lane whose quad holds one -- the host's mask, one scalar load per wave -- fetches the quad's
+// two neighbours as well and runs its pixels through `row_blend` below: the bilinear sum of csrc/lfg_interp.hpp with the terms
+// that are exactly zero left out.  (What did NOT work, each measured: those quads in extra blocks of their own -- 28 us of a 53 us
+// launch, every one of their loads fetched a line some other XCD had fetched already; per-column tables read by those lanes
+// -- the same few L2 lines asked for by every wave of the chip; a patch for ONE such pixel per quad -- they come in runs, two
+// thirds of the quads hold several and fell back to the generic code.)
+// Rows whose uv misses (85 of 2160) do the same with two texel rows (`cell_blend`), the whole wave together.
+constexpr int kRsrcRgba8Unorm = (int)(4u | (5u << 3) | (6u << 6) | (7u << 9) | (0u << 12) | (10u << 15));     // DST_SEL RGBA, NUM_FORMAT UNORM, DATA_FORMAT 8_8_8_8
 
-struct QuadTexels { f32x4 p[4], c[4]; };
-
-__device__ __forceinline__ QuadTexels load_quad_texels(const uint8_t *prev, int prevPitch, const uint8_t *curr, int currPitch,
-                                                       int H, int px0, int py) {
-    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(prev), 0, H * prevPitch, kRsrcRgba8Unorm);
-    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(curr), 0, H * currPitch, kRsrcRgba8Unorm);
-    const int offP = py * prevPitch + px0 * 4, offC = py * currPitch + px0 * 4;
-    QuadTexels q;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) q.p[k] = buffer_load_rgba8_format(rP, offP + 4 * k, 0);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) q.c[k] = buffer_load_rgba8_format(rC, offC + 4 * k, 0);
-    return q;
-}
-
-__device__ __forceinline__ uint32_t mix_pack(const f32x4 p, const f32x4 c, float t) {
+__device__ __forceinline__ uint32_t mix_pack(const V4 p, const V4 c, float t) {
     return pack_rgba8_unorm(mixf(p.x, c.x, t), mixf(p.y, c.y, t), mixf(p.z, c.z, t), mixf(p.w, c.w, t));
 }
 
-// Which quad this thread works on, and whether its wave holds all-centre quads only.
-__device__ __forceinline__ int quad_of_slot(const InterpTables &tb, int slot) {
-    return tb.quads ? (int)tb.quads[slot] : slot;
+// A pixel of a centre row at zero displacement whose COLUMN misses its texel centre: texture() at (uvx, the row's uvy) is
+// ((w00 t00 + w10 t10) + w01 t01) + w11 t11 with b = 0, i.e. w00 = (1 - a) * 1, w10 = a * 1, w01 = w11 = 0 and j0 = py: the sum
+// is fl(fl(w00 t00) + fl(w10 t10)) -- adding the two exact zeros changes nothing (all terms are >= 0) -- of two neighbouring
+// texels of the pixel's own row: u = uvx W - 0.5 lies within 0.001 of the pixel's column p for any width below a million, so
+// floor(u) is p (a tiny) or p - 1 (a just below 1).  A column that does hit has a = 0 and comes out as t00 by the same
+// arithmetic, so a lane that owns any such column runs all four of its pixels through it.
+struct RowTaps { bool below; float w00, w10; };          // below: floor(u) = p - 1, the texels are p - 1 and p; else p and p + 1
+
+// ((float)p + 0.5f) / (float)size, interpolate.comp:30: three instructions where the host has checked that they give the IEEE
+// quotient for every p of the axis (lfg_internal.hpp: UvTable::rcp), the host's table otherwise.
+__device__ __forceinline__ float uv_of(int p, int size, float rcp, int rcpExact, const float *__restrict__ table) {
+#ifdef LFG_DIAG_UV_TABLE            // (A/B: always the table)
+    return table[p];
+#endif
+    if (!rcpExact) return table[p];
+    const float x = (float)p + 0.5f, q0 = x * rcp;
+    return __builtin_fmaf(__builtin_fmaf(-q0, (float)size, x), rcp, q0);
+}
+
+// ... and by the division itself (the few lanes of the fast path that need it: measured 1.7 us faster there than the form above
+// with its run-time switch, 20.7 against 22.4 us per 4K launch)
+__device__ __forceinline__ float uv_div(int p, int size) { return ((float)p + 0.5f) / (float)size; }
+
+__device__ __forceinline__ RowTaps row_taps(int p, int W, float uvx) {
+    const float pk = (float)p;
+    const float u = uvx * (float)W - 0.5f;
+    const float fu = __builtin_floorf(u);
+    const float a = u - fu;
+    return RowTaps{fu < pk, (1.0f - a) * (1.0f - 0.0f), a * (1.0f - 0.0f)};
+}
+
+__device__ __forceinline__ V4 row_blend(const RowTaps &t, const f32x4 left, const f32x4 mid, const f32x4 right) {
+    const f32x4 t00 = t.below ? left : mid, t10 = t.below ? mid : right;
+    return V4{t.w00 * t00.x + t.w10 * t10.x, t.w00 * t00.y + t.w10 * t10.y, t.w00 * t00.z + t.w10 * t10.z, t.w00 * t00.w + t.w10 * t10.w};
+}
+
+// The same for a ROW that misses (85 of 2160): two texel rows, weights (1 - b) and b, and in a column that misses as well all
+// four products -- texture_bilinear's sum with its weights formed from the same factors: w00 = (1 - a)(1 - b), w10 = a (1 - b),
+// w01 = (1 - a) b, w11 = a b.  In a column that hits a = 0: w10 and w11 are exactly 0 and their terms add nothing.
+struct QuadRows { uint32_t t[2][6]; };     // [row][left neighbour, the quad's four texels, right neighbour]
+
+__device__ __forceinline__ V4 cell_blend(const RowTaps &tx, const RowTaps &ty, const QuadRows &q, int i) {
+    const float w00 = tx.w00 * ty.w00, w10 = tx.w10 * ty.w00, w01 = tx.w00 * ty.w10, w11 = tx.w10 * ty.w10;
+    const V4 t00 = unorm4(tx.below ? q.t[0][i] : q.t[0][i + 1]), t10 = unorm4(tx.below ? q.t[0][i + 1] : q.t[0][i + 2]);
+    const V4 t01 = unorm4(tx.below ? q.t[1][i] : q.t[1][i + 1]), t11 = unorm4(tx.below ? q.t[1][i + 1] : q.t[1][i + 2]);
+    V4 r;
+    r.x = ((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x;
+    r.y = ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y;
+    r.z = ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z;
+    r.w = ((w00 * t00.w + w10 * t10.w) + w01 * t01.w) + w11 * t11.w;
+    return r;
+}
+
+__device__ __forceinline__ QuadRows load_quad_rows(const uint8_t *__restrict__ img, int pitch, int W, int r0, int r1, int px0, bool edges) {
+    const uint8_t *a = img + (size_t)r0 * (size_t)pitch, *b = img + (size_t)r1 * (size_t)pitch;
+    const uint4 qa = *reinterpret_cast<const uint4 *>(a + (size_t)px0 * 4u), qb = *reinterpret_cast<const uint4 *>(b + (size_t)px0 * 4u);
+    QuadRows q;
+    q.t[0][0] = q.t[0][5] = q.t[1][0] = q.t[1][5] = 0u;       // (not fetched for a quad of centre columns: their weights are exactly 0 there)
+    if (edges) {
+        const size_t xl = (size_t)max(px0 - 1, 0) * 4u, xr = (size_t)min(px0 + 4, W - 1) * 4u;
+        q.t[0][0] = *reinterpret_cast<const uint32_t *>(a + xl); q.t[0][5] = *reinterpret_cast<const uint32_t *>(a + xr);
+        q.t[1][0] = *reinterpret_cast<const uint32_t *>(b + xl); q.t[1][5] = *reinterpret_cast<const uint32_t *>(b + xr);
+    }
+    q.t[0][1] = qa.x; q.t[0][2] = qa.y; q.t[0][3] = qa.z; q.t[0][4] = qa.w;
+    q.t[1][1] = qb.x; q.t[1][2] = qb.y; q.t[1][3] = qb.z; q.t[1][4] = qb.w;
+    return q;
+}
+
+// The generic path, one pixel at a time: both samples' addresses and weights first, then their eight texel loads, then the
+// arithmetic (csrc/lfg_interp.hpp: sample_taps / sample_load / sample_finish -- interpolate.comp:15-22, 34-38 in two steps; round
+// 3's per-sample branches put up to four memory round trips per pixel in a row).  Pixel by pixel rather than all 32 loads of a
+// quad at once: that took 126 registers and halved the occupancy of the fast path beside it.  A pixel neither of whose samples
+// lies inside the image -- the literal semantics under any motion, F5 -- loads nothing and is (0,0,0,0).
+template <bool INTENDED>
+__device__ __forceinline__ bool pixel_taps(const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
+                                           int W, int H, int8_t mxi, int8_t myi, float uvx, float uvy, float t, SampleTaps &sp, SampleTaps &sc) {
+    float mx = (float)mxi, my = (float)myi;
+    if (INTENDED) { mx = mx / (float)W; my = my / (float)H; }
+    // (the range tests first, on their own: under the literal semantics any motion puts both samples outside, and the pixel is
+    //  done after a dozen instructions)
+    if (!sample_inside(uvx, uvy, mx, my, -t) && !sample_inside(uvx, uvy, mx, my, 1.0f - t)) return false;
+    sp = sample_taps(prev, W, H, prevPitch, uvx, uvy, mx, my, -t);
+    sc = sample_taps(curr, W, H, currPitch, uvx, uvy, mx, my, 1.0f - t);
+    return sp.inside || sc.inside;
+}
+
+__device__ __forceinline__ uint32_t pixel_finish(const SampleTaps &sp, const SampleTexels &tp, const SampleTaps &sc, const SampleTexels &tc, float t) {
+    const V4 p = sample_finish(sp, tp);
+    const V4 c = sample_finish(sc, tc);
+    return pack_rgba8_unorm(mixf(p.x, c.x, t), mixf(p.y, c.y, t), mixf(p.z, c.z, t), mixf(p.w, c.w, t));
+}
+
+// tb.centreY[py] for a row that is the same for the whole wave: a scalar load of the aligned word around it.
+__device__ __forceinline__ bool row_is_centre(const InterpTables &tb, int py) {
+    const int row = __builtin_amdgcn_readfirstlane(py);
+    const uint32_t w = reinterpret_cast<const uint32_t *>(tb.centreY)[row >> 2];
+    return ((w >> (8 * (row & 3))) & 1u) != 0u;
 }
 
 // The host's verdict on whether the fast path may be used for these frames at all (launch_interpolate*): every row pitch and
@@ -66,62 +150,129 @@ static bool fast_frames(const lfg_frame &prev, const lfg_frame &curr, const lfg_
 }
 static bool fast_output(const lfg_frame &o) { return o.pitch % 16u == 0 && (uintptr_t)o.data % 16u == 0; }
 
+#ifndef LFG_INTERP_WAVES
+#define LFG_INTERP_WAVES 6            // waves per SIMD the register allocation aims for (hipcc: the second argument of __launch_bounds__)
+#endif
+#ifndef LFG_INTERP_WAVES_MULTI
+#define LFG_INTERP_WAVES_MULTI 6      // ... with several factors (at 8 both kinds spill; 5 to 7 measured alike)
+#endif
 // INTENDED = false: interpolate.comp as written.  INTENDED = true (opt-in, lfg_set_semantics):
 // the motion vector is divided by the image size before it is added to uv, so it displaces by pixels.
-template <bool INTENDED>
-__global__ __launch_bounds__(256) void interpolate_kernel(
+// N = 1: lfg_interpolate.  N > 1 (BASELINE config 5, 60 -> 240 fps: t = 1/4, 1/2, 3/4 from ONE motion field): one thread reads
+// its four vectors once and produces the pixels of all N frames -- 10 + 4 N B/pixel instead of 14 N; where the vector is (0,0)
+// the texels are fetched once and only mix() is repeated.  Every output byte is computed by the same functions, in the same
+// order, whatever N: the frames are identical to N separate calls (tests/test_gpu_parity.py).
+constexpr int kMaxMulti = 4;
+struct MultiTargets {
+    uint8_t *out[kMaxMulti];
+    int pitch[kMaxMulti];
+    float t[kMaxMulti];
+};
+
+template <int N, bool INTENDED>
+__global__ __launch_bounds__(256, N == 1 ? LFG_INTERP_WAVES : LFG_INTERP_WAVES_MULTI) void interpolate_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
-    const int8_t *__restrict__ mv, int mvPitch, uint8_t *__restrict__ out, int outPitch,
-    int W, int H, float t, InterpTables tb, int fast) {
-    const int slot = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int8_t *__restrict__ mv, int mvPitch, MultiTargets tg, int W, int H, bool wideStores,
+    InterpTables tb, int fast) {
+    const int lane = threadIdx.x & 63;
     const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (py >= H) return;
-    const int qx = quad_of_slot(tb, slot);                       // group of four pixels
-    const int px0 = qx * 4;
+    const int px0 = (blockIdx.x * 64 + lane) * 4;              // a group of four pixels
     if (px0 >= W) return;
+#ifdef LFG_DIAG_INTERP_ROWS_CENTRE      // (timing experiment, wrong pixels: every row a centre row)
+    const bool rowCentre = fast;
+#else
+    const bool rowCentre = fast && row_is_centre(tb, py);
+#endif
     const int8_t *mrow = mv + (size_t)py * (size_t)mvPitch;
-    uint8_t *orow = out + (size_t)py * (size_t)outPitch;
-    const bool full = (px0 + 3 < W) && ((mvPitch & 7) == 0) && ((outPitch & 15) == 0);
+    const bool full = (px0 + 3 < W) && ((mvPitch & 7) == 0) && wideStores;
 
     int8_t m[8];
-    uint2 mm = uint2{1u, 1u};
-#ifdef LFG_DIAG_MV_UNIFORM             // (timing experiment, DESIGN.md 4.4: what reading the vectors costs -- every pixel takes the
-                                       //  vector of the frame's centre, one scalar load; right for the benchmark's pan but for its rim)
-    if (true) {
-        const int8_t *centre = mv + (size_t)(H / 2) * (size_t)mvPitch + (size_t)(W / 2) * 2u;
-        const int8_t cx = centre[0], cy = centre[1];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { m[2 * i] = cx; m[2 * i + 1] = cy; }
-    } else
-#endif
+    uint32_t o[N][4];
+    bool zero = false;                    // four zero vectors: the sample positions do not depend on t
     if (full) {
-        mm = *reinterpret_cast<const uint2 *>(mrow + (size_t)px0 * 2u);
-        if (fast && (mm.x | mm.y) == 0u && tb.centreY[py]) {
-            // four zero vectors in a row whose own uv is a texel centre: the quad fast path (see above)
-            const QuadTexels q = load_quad_texels(prev, prevPitch, curr, currPitch, H, px0, py);
-            uint32_t centres = 0x01010101u;
-            if ((int)blockIdx.x * 64 >= tb.goodSlots) centres = *reinterpret_cast<const uint32_t *>(tb.centreX + px0);
-            uint32_t o[4];
+        const uint2 mm = *reinterpret_cast<const uint2 *>(mrow + (size_t)px0 * 2u);
+        zero = (mm.x | mm.y) == 0u;
+        if (rowCentre && zero) {
+            // the quad fast path: four texels of each frame -- as floats, byte / 255.0f, from the texture-address unit: format-
+            // converting loads through an 8_8_8_8 UNORM descriptor (bit for bit the oracle's conversion,
+            // test_interpolate_all_byte_values_round_trip; the unpacking was a fifth of the wave's VALU work) -- and N blends
+            const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(prev), 0, H * prevPitch, kRsrcRgba8Unorm);
+            const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(curr), 0, H * currPitch, kRsrcRgba8Unorm);
+            const int offP = py * prevPitch + px0 * 4, offC = py * currPitch + px0 * 4;
+            f32x4 tp[6], tc[6];                  // [left neighbour, the quad, right neighbour]
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = mix_pack(q.p[i], q.c[i], t);
-            if (centres != 0x01010101u) {                         // (the row's last waves only)
-                const float uvy = tb.uvy[py];
+            for (int i = 0; i < 4; ++i) tp[i + 1] = buffer_load_rgba8_format(rP, offP + 4 * i, 0);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (((centres >> (8 * i)) & 1u) == 0u) {
-                        const float uvx = tb.uvx[px0 + i];
-                        const V4 p = sample_with_motion(prev, W, H, prevPitch, uvx, uvy, 0.0f, 0.0f, -t);
-                        const V4 c = sample_with_motion(curr, W, H, currPitch, uvx, uvy, 0.0f, 0.0f, 1.0f - t);
-                        o[i] = pack_rgba8_unorm(mixf(p.x, c.x, t), mixf(p.y, c.y, t), mixf(p.z, c.z, t), mixf(p.w, c.w, t));
-                    }
+            for (int i = 0; i < 4; ++i) tc[i + 1] = buffer_load_rgba8_format(rC, offC + 4 * i, 0);
+#ifdef LFG_DIAG_INTERP_NO_PATCH         // (timing experiment, wrong pixels: every column a centre column)
+            const bool laneGood = true;
+#else
+            const bool laneGood = ((tb.goodMask[blockIdx.x] >> lane) & 1ull) != 0ull;            // (one scalar load per wave)
+#endif
+            V4 fp[4], fc[4];
+            if (laneGood) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { fp[i] = V4{tp[i + 1].x, tp[i + 1].y, tp[i + 1].z, tp[i + 1].w}; fc[i] = V4{tc[i + 1].x, tc[i + 1].y, tc[i + 1].z, tc[i + 1].w}; }
+            } else {
+                // a quad with columns that miss (see row_taps): its two neighbours in the row as well (asked for before anything
+                // waits for the quad's own texels), and every pixel of it as the blend it is
+                const int xl = max(px0 - 1, 0) * 4, xr = min(px0 + 4, W - 1) * 4;
+                tp[0] = buffer_load_rgba8_format(rP, py * prevPitch + xl, 0); tp[5] = buffer_load_rgba8_format(rP, py * prevPitch + xr, 0);
+                tc[0] = buffer_load_rgba8_format(rC, py * currPitch + xl, 0); tc[5] = buffer_load_rgba8_format(rC, py * currPitch + xr, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const RowTaps t = row_taps(px0 + i, W, uv_div(px0 + i, W));
+                    fp[i] = row_blend(t, tp[i], tp[i + 1], tp[i + 2]);
+                    fc[i] = row_blend(t, tc[i], tc[i + 1], tc[i + 2]);
+                }
             }
-            *reinterpret_cast<uint4 *>(orow + (size_t)px0 * 4u) = uint4{o[0], o[1], o[2], o[3]};
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[k][i] = mix_pack(fp[i], fc[i], tg.t[k]);
+                *reinterpret_cast<uint4 *>(tg.out[k] + (size_t)py * (size_t)tg.pitch[k] + (size_t)px0 * 4u) = uint4{o[k][0], o[k][1], o[k][2], o[k][3]};
+            }
+            return;
+        }
+        if (fast && zero) {
+            // a row that misses (the whole wave): the same with two texel rows
+            const bool laneGood = ((tb.goodMask[blockIdx.x] >> lane) & 1ull) != 0ull;
+            const RowTaps ty = row_taps(py, H, uv_div(py, H));
+            const int j0 = ty.below ? py - 1 : py;
+            const int r0 = clampi(j0, 0, H - 1), r1 = clampi(j0 + 1, 0, H - 1);
+            const QuadRows qp = load_quad_rows(prev, prevPitch, W, r0, r1, px0, !laneGood);
+            const QuadRows qc = load_quad_rows(curr, currPitch, W, r0, r1, px0, !laneGood);
+            V4 fp[4], fc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                RowTaps tx = RowTaps{false, 1.0f, 0.0f};
+                if (!laneGood) tx = row_taps(px0 + i, W, uv_div(px0 + i, W));
+                fp[i] = cell_blend(tx, ty, qp, i);
+                fc[i] = cell_blend(tx, ty, qc, i);
+            }
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[k][i] = mix_pack(fp[i], fc[i], tg.t[k]);
+                *reinterpret_cast<uint4 *>(tg.out[k] + (size_t)py * (size_t)tg.pitch[k] + (size_t)px0 * 4u) = uint4{o[k][0], o[k][1], o[k][2], o[k][3]};
+            }
             return;
         }
         m[0] = (int8_t)(mm.x & 0xff); m[1] = (int8_t)((mm.x >> 8) & 0xff);
         m[2] = (int8_t)((mm.x >> 16) & 0xff); m[3] = (int8_t)(mm.x >> 24);
         m[4] = (int8_t)(mm.y & 0xff); m[5] = (int8_t)((mm.y >> 8) & 0xff);
         m[6] = (int8_t)((mm.y >> 16) & 0xff); m[7] = (int8_t)(mm.y >> 24);
+#ifdef LFG_DIAG_MV_UNIFORM             // (timing experiment, DESIGN.md 4.4: what reading the vectors costs -- every pixel takes the
+                                       //  vector of the frame's centre, one scalar load; right for the benchmark's pan but for its rim)
+        {
+            const int8_t *centre = mv + (size_t)(H / 2) * (size_t)mvPitch + (size_t)(W / 2) * 2u;
+            const int8_t cx = centre[0], cy = centre[1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { m[2 * i] = cx; m[2 * i + 1] = cy; }
+            zero = (cx | cy) == 0;
+        }
+#endif
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -132,149 +283,24 @@ __global__ __launch_bounds__(256) void interpolate_kernel(
 
     // ((float)p + 0.5f) / (float)size, interpolate.comp:30, from the host's tables (lfg_internal.hpp: UvTable; the tables are
     // padded to whole groups of four)
-    const float uvy = tb.uvy[py];
-    const float4 uvx4 = *reinterpret_cast<const float4 *>(tb.uvx + px0);
-    const float uvxOf[4] = {uvx4.x, uvx4.y, uvx4.z, uvx4.w};
-    uint32_t o[4];
+    const float uvy = uv_of(py, H, tb.rcpH, tb.rcpExact, tb.uvy);
+    float uvxOf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) uvxOf[i] = uv_of(min(px0 + i, W - 1), W, tb.rcpW, tb.rcpExact, tb.uvx);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float uvx = uvxOf[i];
-        float mx = (float)m[2 * i], my = (float)m[2 * i + 1];
-        if (INTENDED) { mx = mx / (float)W; my = my / (float)H; }
-        const V4 p = sample_with_motion(prev, W, H, prevPitch, uvx, uvy, mx, my, -t);
-        const V4 c = sample_with_motion(curr, W, H, currPitch, uvx, uvy, mx, my, 1.0f - t);
-        o[i] = pack_rgba8_unorm(mixf(p.x, c.x, t), mixf(p.y, c.y, t), mixf(p.z, c.z, t), mixf(p.w, c.w, t));
-    }
-    if (full) {
-        *reinterpret_cast<uint4 *>(orow + (size_t)px0 * 4u) = uint4{o[0], o[1], o[2], o[3]};
-    } else {
-        for (int i = 0; i < 4 && px0 + i < W; ++i)
-            *reinterpret_cast<uint32_t *>(orow + (size_t)(px0 + i) * 4u) = o[i];
-    }
-}
-
-static dim3 interpolate_grid(const InterpTables &tb, int W, int H) {
-    const int quads = (W + 3) / 4;
-    return dim3(tb.quads ? tb.quadSlots / 64 : (quads + 63) / 64, (H + 3) / 4);
-}
-
-hipError_t launch_interpolate(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
-                              const lfg_frame &mv, const lfg_frame &out, float factor, bool intended, const InterpTables &tb) {
-    const dim3 grid = interpolate_grid(tb, (int)out.width, (int)out.height);
-    const int fast = fast_frames(prev, curr, mv) && fast_output(out) ? 1 : 0;
-    if (intended)
-        hipLaunchKernelGGL(interpolate_kernel<true>, grid, dim3(256), 0, s,
-                           (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
-                           (const int8_t *)mv.data, (int)mv.pitch, (uint8_t *)out.data, (int)out.pitch,
-                           (int)out.width, (int)out.height, factor, tb, fast);
-    else
-        hipLaunchKernelGGL(interpolate_kernel<false>, grid, dim3(256), 0, s,
-                           (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
-                           (const int8_t *)mv.data, (int)mv.pitch, (uint8_t *)out.data, (int)out.pitch,
-                           (int)out.width, (int)out.height, factor, tb, fast);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------ several factors per pair
-//
-// BASELINE config 5 (60 -> 240 fps) generates three frames per pair, t = 1/4, 1/2, 3/4, from ONE motion field.  Run
-// as three dispatches of the kernel above, prev, curr and the vectors are read three times: 3 x 14 = 42 B/pixel.
-// Here one thread reads its four vectors once and produces the pixels of all N frames: 10 + 4N B/pixel (22 for N = 3).
-// Where the vector is (0,0) -- static content, and under the literal semantics the only case in which both sources
-// are sampled inside the image for every t -- the two texels are fetched once and only mix() is repeated (the quad fast
-// path above where it applies).
-// Every output byte is computed by the same functions, in the same order, as interpolate_kernel computes it: the
-// frames are identical to N separate calls (tests/test_gpu_parity.py).
-constexpr int kMaxMulti = 4;
-struct MultiTargets {
-    uint8_t *out[kMaxMulti];
-    int pitch[kMaxMulti];
-    float t[kMaxMulti];
-};
-
-template <int N, bool INTENDED>
-__global__ __launch_bounds__(256) void interpolate_multi_kernel(
-    const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
-    const int8_t *__restrict__ mv, int mvPitch, MultiTargets tg, int W, int H, bool wideStores,
-    InterpTables tb, int fast) {
-    const int slot = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (py >= H) return;
-    const int qx = quad_of_slot(tb, slot);
-    const int px0 = qx * 4;
-    if (px0 >= W) return;
-    const int8_t *mrow = mv + (size_t)py * (size_t)mvPitch;
-    const bool full = (px0 + 3 < W) && ((mvPitch & 7) == 0) && wideStores;
-
-    int8_t m[8];
-    if (full) {
-        const uint2 mm = *reinterpret_cast<const uint2 *>(mrow + (size_t)px0 * 2u);
-        if (fast && (mm.x | mm.y) == 0u && tb.centreY[py]) {
-            const QuadTexels q = load_quad_texels(prev, prevPitch, curr, currPitch, H, px0, py);
-            uint32_t centres = 0x01010101u;
-            if ((int)blockIdx.x * 64 >= tb.goodSlots) centres = *reinterpret_cast<const uint32_t *>(tb.centreX + px0);
-            uint32_t o[N][4];
+        const bool still = m[2 * i] == 0 && m[2 * i + 1] == 0;       // uv + 0 * scale is uv whatever the factor: one set of texels for all N
+        SampleTaps sp, sc;
+        SampleTexels tp, tc;
 #pragma unroll
-            for (int k = 0; k < N; ++k)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[k][i] = mix_pack(q.p[i], q.c[i], tg.t[k]);
-            if (centres != 0x01010101u) {
-                const float uvy = tb.uvy[py];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (((centres >> (8 * i)) & 1u) == 0u) {
-                        const float uvx = tb.uvx[px0 + i];
-                        const V4 p = sample_with_motion(prev, W, H, prevPitch, uvx, uvy, 0.0f, 0.0f, 0.0f);
-                        const V4 c = sample_with_motion(curr, W, H, currPitch, uvx, uvy, 0.0f, 0.0f, 0.0f);
-#pragma unroll
-                        for (int k = 0; k < N; ++k) {
-                            const float t = tg.t[k];
-                            o[k][i] = pack_rgba8_unorm(mixf(p.x, c.x, t), mixf(p.y, c.y, t), mixf(p.z, c.z, t), mixf(p.w, c.w, t));
-                        }
-                    }
+        for (int k = 0; k < N; ++k) {
+            const float t = tg.t[k];
+            if (k == 0 || !still) {
+                o[k][i] = 0u;
+                if (!pixel_taps<INTENDED>(prev, prevPitch, curr, currPitch, W, H, m[2 * i], m[2 * i + 1], uvxOf[i], uvy, t, sp, sc)) continue;
+                tp = sample_load(sp); tc = sample_load(sc);
             }
-#pragma unroll
-            for (int k = 0; k < N; ++k)
-                *reinterpret_cast<uint4 *>(tg.out[k] + (size_t)py * (size_t)tg.pitch[k] + (size_t)px0 * 4u) = uint4{o[k][0], o[k][1], o[k][2], o[k][3]};
-            return;
-        }
-        m[0] = (int8_t)(mm.x & 0xff); m[1] = (int8_t)((mm.x >> 8) & 0xff);
-        m[2] = (int8_t)((mm.x >> 16) & 0xff); m[3] = (int8_t)(mm.x >> 24);
-        m[4] = (int8_t)(mm.y & 0xff); m[5] = (int8_t)((mm.y >> 8) & 0xff);
-        m[6] = (int8_t)((mm.y >> 16) & 0xff); m[7] = (int8_t)(mm.y >> 24);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int px = min(px0 + i, W - 1);
-            m[2 * i] = mrow[(size_t)px * 2u]; m[2 * i + 1] = mrow[(size_t)px * 2u + 1];
-        }
-    }
-
-    const float uvy = tb.uvy[py];
-    const float4 uvx4 = *reinterpret_cast<const float4 *>(tb.uvx + px0);
-    const float uvxOf[4] = {uvx4.x, uvx4.y, uvx4.z, uvx4.w};
-    uint32_t o[N][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float uvx = uvxOf[i];
-        float mx = (float)m[2 * i], my = (float)m[2 * i + 1];
-        if (INTENDED) { mx = mx / (float)W; my = my / (float)H; }
-        if (mx == 0.0f && my == 0.0f) {                   // the sample positions do not depend on t
-            const V4 p = sample_with_motion(prev, W, H, prevPitch, uvx, uvy, 0.0f, 0.0f, 0.0f);
-            const V4 c = sample_with_motion(curr, W, H, currPitch, uvx, uvy, 0.0f, 0.0f, 0.0f);
-#pragma unroll
-            for (int k = 0; k < N; ++k) {
-                const float t = tg.t[k];
-                o[k][i] = pack_rgba8_unorm(mixf(p.x, c.x, t), mixf(p.y, c.y, t), mixf(p.z, c.z, t), mixf(p.w, c.w, t));
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < N; ++k) {
-                const float t = tg.t[k];
-                const V4 p = sample_with_motion(prev, W, H, prevPitch, uvx, uvy, mx, my, -t);
-                const V4 c = sample_with_motion(curr, W, H, currPitch, uvx, uvy, mx, my, 1.0f - t);
-                o[k][i] = pack_rgba8_unorm(mixf(p.x, c.x, t), mixf(p.y, c.y, t), mixf(p.z, c.z, t), mixf(p.w, c.w, t));
-            }
+            o[k][i] = pixel_finish(sp, tp, sc, tc, t);
         }
     }
 #pragma unroll
@@ -290,48 +316,51 @@ __global__ __launch_bounds__(256) void interpolate_multi_kernel(
 }
 
 template <int N>
-static void launch_multi_n(hipStream_t s, dim3 grid, const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv,
-                           const MultiTargets &tg, int W, int H, bool wide, bool intended, const InterpTables &tb, int fast) {
+static void launch_n(hipStream_t s, dim3 grid, const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv,
+                     const MultiTargets &tg, int W, int H, bool wide, bool intended, const InterpTables &tb, int fast) {
     if (intended)
-        hipLaunchKernelGGL((interpolate_multi_kernel<N, true>), grid, dim3(256), 0, s,
+        hipLaunchKernelGGL((interpolate_kernel<N, true>), grid, dim3(256), 0, s,
                            (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
                            (const int8_t *)mv.data, (int)mv.pitch, tg, W, H, wide, tb, fast);
     else
-        hipLaunchKernelGGL((interpolate_multi_kernel<N, false>), grid, dim3(256), 0, s,
+        hipLaunchKernelGGL((interpolate_kernel<N, false>), grid, dim3(256), 0, s,
                            (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
                            (const int8_t *)mv.data, (int)mv.pitch, tg, W, H, wide, tb, fast);
 }
 
-// `count` frames from one pass per group of up to kMaxMulti factors (a single factor takes interpolate_kernel).
+// `count` frames from one pass per group of up to kMaxMulti factors.
 hipError_t launch_interpolate_multi(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv,
                                     const lfg_frame *const *outs, const float *factors, int count, bool intended,
                                     const InterpTables &tb) {
     const int W = (int)curr.width, H = (int)curr.height;
-    const dim3 grid = interpolate_grid(tb, W, H);
+    const int quads = (W + 3) / 4;
+    const dim3 grid((quads + 63) / 64, (H + 3) / 4);
     for (int first = 0; first < count; first += kMaxMulti) {
         const int n = count - first < kMaxMulti ? count - first : kMaxMulti;
-        if (n == 1) {
-            hipError_t e = launch_interpolate(s, prev, curr, mv, *outs[first], factors[first], intended, tb);
-            if (e != hipSuccess) return e;
-            continue;
-        }
         MultiTargets tg{};
         bool wide = true;
         for (int k = 0; k < kMaxMulti; ++k) {
             const lfg_frame &o = *outs[first + (k < n ? k : 0)];
             tg.out[k] = (uint8_t *)o.data; tg.pitch[k] = (int)o.pitch; tg.t[k] = factors[first + (k < n ? k : 0)];
-            wide = wide && (o.pitch % 16u == 0) && ((uintptr_t)o.data % 16u == 0);
+            wide = wide && fast_output(o);
         }
-        const int fast = fast_frames(prev, curr, mv) && wide ? 1 : 0;
+        const int fast = fast_frames(prev, curr, mv) && wide && tb.goodMask && W < (1 << 20) && H < (1 << 20) ? 1 : 0;
         switch (n) {
-            case 2: launch_multi_n<2>(s, grid, prev, curr, mv, tg, W, H, wide, intended, tb, fast); break;
-            case 3: launch_multi_n<3>(s, grid, prev, curr, mv, tg, W, H, wide, intended, tb, fast); break;
-            default: launch_multi_n<4>(s, grid, prev, curr, mv, tg, W, H, wide, intended, tb, fast); break;
+            case 1: launch_n<1>(s, grid, prev, curr, mv, tg, W, H, wide, intended, tb, fast); break;
+            case 2: launch_n<2>(s, grid, prev, curr, mv, tg, W, H, wide, intended, tb, fast); break;
+            case 3: launch_n<3>(s, grid, prev, curr, mv, tg, W, H, wide, intended, tb, fast); break;
+            default: launch_n<4>(s, grid, prev, curr, mv, tg, W, H, wide, intended, tb, fast); break;
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+hipError_t launch_interpolate(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
+                              const lfg_frame &mv, const lfg_frame &out, float factor, bool intended, const InterpTables &tb) {
+    const lfg_frame *outs[1] = {&out};
+    return launch_interpolate_multi(s, prev, curr, mv, outs, &factor, 1, intended, tb);
 }
 
 // vec4(best, 0, 1) per pixel, as shaders/motion.comp:56 stores it.

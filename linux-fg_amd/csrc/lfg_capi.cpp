@@ -163,32 +163,30 @@ int build_uv_table(lfg_context *ctx, int size, const lfg::UvTable **out) {
     t.size = size;
     t.blocks = (int)((quads + 63u) / 64u);
     std::vector<uint64_t> good((size_t)t.blocks, 0ull);
-    std::vector<uint16_t> bad;
-    const bool indexable = quads < 0xFFFFu;
-    for (size_t q = 0; q < quads; ++q) {
-        const bool all = 4 * q + 3 < (size_t)size && centre[4 * q] && centre[4 * q + 1] && centre[4 * q + 2] && centre[4 * q + 3];
-        if (all && indexable) good[q / 64u] |= 1ull << (q % 64u);
-        else if (indexable) bad.push_back((uint16_t)q);
+    for (size_t q = 0; q < quads; ++q)
+        if (4 * q + 3 < (size_t)size && centre[4 * q] && centre[4 * q + 1] && centre[4 * q + 2] && centre[4 * q + 3])
+            good[q / 64u] |= 1ull << (q % 64u);
+    // the three-instruction uv of the kernels (lfg_internal.hpp: UvTable::rcp): exact for every p of this axis?
+    t.rcp = 1.0f / (float)size;
+    t.rcpExact = true;
+    for (int p = 0; p < size && t.rcpExact; ++p) {
+        const float x = (float)p + 0.5f, q0 = x * t.rcp;
+        t.rcpExact = fmaf(fmaf(-q0, (float)size, x), t.rcp, q0) == uv[(size_t)p];
     }
-    bad.resize((bad.size() + 63u) / 64u * 64u, (uint16_t)0xFFFFu);
-    t.badSlots = (int)bad.size();
     const size_t c64 = ((size_t)size + 63u) & ~(size_t)63u;
     const size_t offCentre = n4 * sizeof(float), offGood = (offCentre + c64 + 15u) & ~(size_t)15u;
-    const size_t offBad = offGood + good.size() * sizeof(uint64_t);
-    const size_t bytes = offBad + bad.size() * sizeof(uint16_t) + 16u;
+    const size_t bytes = offGood + good.size() * sizeof(uint64_t) + 16u;
     std::vector<uint8_t> host(bytes, 0);
     memcpy(host.data(), uv.data(), n4 * sizeof(float));
     memcpy(host.data() + offCentre, centre.data(), n4);
     memcpy(host.data() + offGood, good.data(), good.size() * sizeof(uint64_t));
-    if (!bad.empty()) memcpy(host.data() + offBad, bad.data(), bad.size() * sizeof(uint16_t));
     uint8_t *d = nullptr;
     LFG_HIP(ctx, hipMalloc((void **)&d, bytes));
     const hipError_t e = hipMemcpy(d, host.data(), bytes, hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(d); return fail_hip(ctx, e, "hipMemcpy(uv table)"); }
     t.d_uv = reinterpret_cast<float *>(d);
     t.d_centre = d + offCentre;
-    t.d_goodMask = indexable ? reinterpret_cast<uint64_t *>(d + offGood) : nullptr;
-    t.d_badQuads = indexable ? reinterpret_cast<uint16_t *>(d + offBad) : nullptr;
+    t.d_goodMask = reinterpret_cast<uint64_t *>(d + offGood);
     ctx->uv_tables.push_back(t);
     *out = &ctx->uv_tables.back();
     return LFG_OK;
@@ -205,7 +203,8 @@ int interp_tables(lfg_context *ctx, int width, int height, lfg::InterpTables *tb
     if (rc != LFG_OK) return rc;
     tb->uvx = tx->d_uv; tb->uvy = ty->d_uv;
     tb->centreX = tx->d_centre; tb->centreY = ty->d_centre;
-    tb->goodMask = tx->d_goodMask; tb->badQuads = tx->d_badQuads; tb->blocks = tx->blocks; tb->badSlots = tx->badSlots;
+    tb->goodMask = tx->d_goodMask;
+    tb->rcpW = tx->rcp; tb->rcpH = ty->rcp; tb->rcpExact = tx->rcpExact && ty->rcpExact ? 1 : 0;
     return LFG_OK;
 }
 

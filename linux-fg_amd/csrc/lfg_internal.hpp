@@ -42,18 +42,19 @@ struct AxisTable {
 // stay inside the image) texture() is asked for uv[p] itself, and fl(uv[p] * size - 0.5) is texel p with fraction 0
 // for most p but not for all: in fp32 102 of 3840 columns and 85 of 2160 rows miss by an ulp and get real bilinear weights.
 // `centre` marks the p that hit (the sample IS texel p: no coordinate arithmetic, no weights).  For the x axis the groups of four
-// pixels a thread works on ("quads") are split in two: `goodMask` has one bit per quad, set where all four pixels are centres --
-// a wave of the kernel's normal blocks covers 64 consecutive quads and switches the others' lanes off with one scalar load --
-// and `badQuads` lists the others, which the kernel's extra blocks work on, so that no lane of a normal wave ever needs the
-// bilinear code (interpolate.hip).
+// pixels a thread works on ("quads") have one bit each in `goodMask`, set where all four pixels are centres: a wave covers 64
+// consecutive quads and learns with one scalar load which of its lanes need the two-texel blends of interpolate.hip.
 struct UvTable {
     int size = 0;
     float *d_uv = nullptr;          // [size rounded up to 4]; the base of ONE allocation that also holds the arrays below
     uint8_t *d_centre = nullptr;    // [size rounded up to 64]: 1 where the undisplaced sample of p is exactly texel p
     uint64_t *d_goodMask = nullptr; // [blocks]: bit l of word b: quad 64 b + l lies inside the axis and is all centres
-    uint16_t *d_badQuads = nullptr; // [badSlots]: the other quads, ascending; padded with 0xFFFF.  nullptr: the axis is too long for 16-bit indices
     int blocks = 0;                 // ceil(quads / 64)
-    int badSlots = 0;               // a multiple of 64
+    // uv[p] without the table and without an IEEE division: q = (p + 0.5) * rcp, then one correction step,
+    // q + fma(-q, size, p + 0.5) * rcp -- three instructions.  rcpExact: the host has checked that this reproduces uv[p] bit for bit
+    // for EVERY p of this axis (it does for all the benchmark's sizes); otherwise the kernels read the table.
+    float rcp = 0.0f;
+    bool rcpExact = false;
 };
 
 // What the interpolate kernels take besides the frames (interpolate.hip).
@@ -61,8 +62,8 @@ struct InterpTables {
     const float *uvx = nullptr, *uvy = nullptr;
     const uint8_t *centreX = nullptr, *centreY = nullptr;
     const uint64_t *goodMask = nullptr;        // of the x axis
-    const uint16_t *badQuads = nullptr;
-    int blocks = 0, badSlots = 0;
+    float rcpW = 0.0f, rcpH = 0.0f;            // UvTable::rcp of the two axes
+    int rcpExact = 0;                          // both axes' three-instruction uv is exact (UvTable::rcpExact)
 };
 
 // lfg_interpolate_frames in the north-star order (the reference: motion dispatch, then interpolate

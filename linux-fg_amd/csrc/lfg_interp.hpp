@@ -52,6 +52,69 @@ __device__ __forceinline__ V4 sample_with_motion(const uint8_t *__restrict__ img
 
 __device__ __forceinline__ float mixf(float x, float y, float a) { return x * (1.0f - a) + y * a; }
 
+// ---- the same sample, in two steps, for code that wants all of a thread's loads in flight before it uses any of them
+// (interpolate.hip's generic path: round 3's per-sample branches -- outside [0,1]?  fractions zero? -- put up to sixteen memory
+// round trips in a row into one wave, and the few waves that needed them set the kernel's duration).  No shortcut for zero
+// fractions: with a = b = 0 the weights are 1, 0, 0, 0 and the sum below is t00 + 0 + 0 + 0, the same float.
+struct SampleTaps {
+    const uint8_t *r0, *r1;      // the two texel rows (clamped), at column 0
+    int i0, i1;                  // the two texel columns (clamped)
+    float w00, w10, w01, w11;
+    bool inside;                 // interpolate.comp:17-20: outside [0,1] the sample is vec4(0)
+};
+
+__device__ __forceinline__ SampleTaps sample_taps(const uint8_t *__restrict__ img, int W, int H, int pitch,
+                                                  float uvx, float uvy, float mx, float my, float scale) {
+    const float sx = uvx + mx * scale, sy = uvy + my * scale;
+    SampleTaps s;
+    s.inside = !(sx < 0.0f || sy < 0.0f || sx > 1.0f || sy > 1.0f);
+    const float u = sx * (float)W - 0.5f;
+    const float v = sy * (float)H - 0.5f;
+    const float fu = __builtin_floorf(u), fv = __builtin_floorf(v);
+    const float a = u - fu, b = v - fv;
+    // (a sample far outside the image may not fit an int: it is not used, only its addresses have to be valid)
+    const int i0 = (int)__builtin_fminf(__builtin_fmaxf(fu, -2.0f), (float)W);
+    const int j0 = (int)__builtin_fminf(__builtin_fmaxf(fv, -2.0f), (float)H);
+    s.i0 = clampi(i0, 0, W - 1); s.i1 = clampi(i0 + 1, 0, W - 1);
+    s.r0 = img + (size_t)clampi(j0, 0, H - 1) * (size_t)pitch;
+    s.r1 = img + (size_t)clampi(j0 + 1, 0, H - 1) * (size_t)pitch;
+    s.w00 = (1.0f - a) * (1.0f - b); s.w10 = a * (1.0f - b);
+    s.w01 = (1.0f - a) * b; s.w11 = a * b;
+    return s;
+}
+
+// interpolate.comp:16-20 alone: does the displaced sample lie inside [0,1] x [0,1]?  (The same two sums as sample_taps.)
+__device__ __forceinline__ bool sample_inside(float uvx, float uvy, float mx, float my, float scale) {
+    const float sx = uvx + mx * scale, sy = uvy + my * scale;
+    return !(sx < 0.0f || sy < 0.0f || sx > 1.0f || sy > 1.0f);
+}
+
+struct SampleTexels { uint32_t t00, t10, t01, t11; };
+
+__device__ __forceinline__ SampleTexels sample_load(const SampleTaps &s) {
+    SampleTexels t;
+    t.t00 = *reinterpret_cast<const uint32_t *>(s.r0 + (size_t)s.i0 * 4u);
+    t.t10 = *reinterpret_cast<const uint32_t *>(s.r0 + (size_t)s.i1 * 4u);
+    t.t01 = *reinterpret_cast<const uint32_t *>(s.r1 + (size_t)s.i0 * 4u);
+    t.t11 = *reinterpret_cast<const uint32_t *>(s.r1 + (size_t)s.i1 * 4u);
+    return t;
+}
+
+__device__ __forceinline__ V4 unorm4(uint32_t p) {
+    return V4{unorm8_to_float(byte0(p)), unorm8_to_float(byte1(p)), unorm8_to_float(byte2(p)), unorm8_to_float(byte3(p))};
+}
+
+__device__ __forceinline__ V4 sample_finish(const SampleTaps &s, const SampleTexels &t) {
+    const V4 t00 = unorm4(t.t00), t10 = unorm4(t.t10), t01 = unorm4(t.t01), t11 = unorm4(t.t11);
+    V4 r;
+    r.x = ((s.w00 * t00.x + s.w10 * t10.x) + s.w01 * t01.x) + s.w11 * t11.x;
+    r.y = ((s.w00 * t00.y + s.w10 * t10.y) + s.w01 * t01.y) + s.w11 * t11.y;
+    r.z = ((s.w00 * t00.z + s.w10 * t10.z) + s.w01 * t01.z) + s.w11 * t11.z;
+    r.w = ((s.w00 * t00.w + s.w10 * t10.w) + s.w01 * t01.w) + s.w11 * t11.w;
+    if (!s.inside) r = V4{0.f, 0.f, 0.f, 0.f};
+    return r;
+}
+
 // One interpolated pixel as packed RGBA8: mix(S(prev, uv - mv t), S(curr, uv + mv (1 - t)), t), clamped, x 255,
 // round half to even (interpolate.comp:30-39).  mx, my: the motion vector in pixels (already divided by the image
 // size under the opt-in intended semantics).

@@ -790,6 +790,31 @@ def test_interpolate_4k_exact_rois(ctx, oracle):
     assert (run_interpolate(ctx, prev, prev, np.zeros((H, W, 2), np.int8), 0.5) == prev).all()
 
 
+@pytest.mark.parametrize("wh", [(3840, 2160), (1920, 1080), (7680, 4320), (1000, 333)])
+def test_interpolate_every_pixel_where_it_samples(ctx, oracle, wh):
+    """Content on which the stage really samples both frames (round 3 timed it on a pan, where the literal semantics reject
+    every sample): zero vectors nearly everywhere -- the quad fast path, its row blends in the columns whose uv misses a texel
+    centre in fp32 (102 of 3840, in runs) and the generic path in the rows that miss (85 of 2160) -- with islands of small
+    non-zero vectors, at every benchmark size and a ragged one, EVERY pixel against the oracle, one factor and three."""
+    W, H = wh
+    rng = np.random.default_rng(W * 7 + H)
+    prev = rng.integers(0, 256, size=(H, W, 4), dtype=np.uint8)
+    curr = rng.integers(0, 256, size=(H, W, 4), dtype=np.uint8)
+    mv = np.zeros((H, W, 2), np.int8)
+    for _ in range(12):
+        x0, y0 = int(rng.integers(0, W - 40)), int(rng.integers(0, H - 40))
+        mv[y0:y0 + int(rng.integers(1, 40)), x0:x0 + int(rng.integers(1, 40))] = rng.integers(-1, 2, size=2)
+    mvf = mv.astype(np.float32)
+    for t in (0.5, 0.3):
+        got = run_interpolate(ctx, prev, curr, mv, t)
+        want = oracle.interpolate(prev, curr, mvf, t)
+        assert (got == want).all(), f"t = {t}: {(got != want).any(-1).sum()} pixels differ, first at {np.argwhere((got != want).any(-1))[:4].tolist()}"
+    factors = [0.25, 0.5, 0.75]
+    for f, got in zip(factors, _run_interpolate_multi(ctx, prev, curr, mv, factors)):
+        want = oracle.interpolate(prev, curr, mvf, f)
+        assert (got == want).all(), f"one pass, t = {f}: {(got != want).any(-1).sum()} pixels differ"
+
+
 # ------------------------------------------------------------------------------ whole path
 
 def _run_interpolate_multi(ctx, prev, curr, mv_i8, factors):
@@ -1330,6 +1355,24 @@ def test_intended_interpolate_matches_oracle(intended, oracle, t):
     assert (d != 0).mean() < 1e-3                                         # in practice identical
     lit = oracle.interpolate(prev, curr, mv.astype(np.float32), t)
     assert (want != lit).any()
+
+
+def test_intended_interpolate_full_hd_every_pixel(intended, oracle):
+    """The same at 1920x1080 with a smooth field of vectors plus zero areas: under the intended semantics every pixel samples
+    displaced, mostly fractional positions -- the generic path is the whole frame here."""
+    W, H = 1920, 1080
+    rng = np.random.default_rng(77)
+    prev = rng.integers(0, 256, size=(H, W, 4), dtype=np.uint8)
+    curr = rng.integers(0, 256, size=(H, W, 4), dtype=np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W]
+    mv = np.stack([np.rint(9 * np.sin(xx / 211.0 + yy / 97.0)), np.rint(7 * np.cos(xx / 131.0 - yy / 173.0))], -1).astype(np.int8)
+    mv[300:500, 600:900] = 0
+    for t in (0.5, 0.25):
+        got = run_interpolate(intended, prev, curr, mv, t)
+        want = oracle.interpolate(prev, curr, mv.astype(np.float32), t, semantics=oracle.INTENDED)
+        d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+        assert d.max() <= 1, f"max diff {d.max()}"
+        assert (d != 0).mean() < 1e-3
 
 
 def test_lanes_keep_frames_in_flight_apart():
