@@ -140,6 +140,28 @@ def algorithmic_bytes(stage: str, w_in: int, h_in: int, w: int, h: int) -> int:
     raise ValueError(stage)
 
 
+def interpolate_bytes_moved(mv: np.ndarray, factors, intended: bool = False) -> int:
+    """Bytes the interpolate stage has to move for THIS vector field (literal semantics): the vectors in
+    (2 B/px) and one frame out per factor (4 B/px) always; 4 B of prev and 4 B of curr only for the pixels whose displaced
+    sample lies inside [0,1]^2 for some factor (interpolate.comp:17-20 returns vec4(0) without a fetch otherwise) -- the same
+    fp32 sums as the shader.  On the benchmark's pan no sample does and the stage moves 6 of its 14 algorithmic B/px; a
+    fraction of the roofline has to be computed from THESE bytes."""
+    h, w = mv.shape[:2]
+    f = np.float32
+    uvx = ((np.arange(w, dtype=np.float32) + f(0.5)) / f(w))[None, :]
+    uvy = ((np.arange(h, dtype=np.float32) + f(0.5)) / f(h))[:, None]
+    mx, my = mv[..., 0].astype(np.float32), mv[..., 1].astype(np.float32)
+    if intended:
+        mx, my = mx / f(w), my / f(h)
+    need_p = np.zeros((h, w), bool)
+    need_c = np.zeros((h, w), bool)
+    for t in factors:
+        for need, scale in ((need_p, f(-t)), (need_c, f(1.0) - f(t))):
+            sx, sy = uvx + mx * scale, uvy + my * scale
+            need |= ~((sx < 0) | (sy < 0) | (sx > 1) | (sy > 1))
+    return int(2 * w * h + 4 * w * h * len(factors) + 4 * int(need_p.sum()) + 4 * int(need_c.sum()))
+
+
 def library_sha16():
     """First 16 hex digits of the sha256 of the HIP library this process loaded: profiles record it, and a profile
     taken with another build is not quoted."""
@@ -304,9 +326,10 @@ def spawn_ranks(args, argv) -> int:
     return subprocess.run(launch_command(args.gpus, argv, free_port()), env=env).returncode
 
 
-def measure_config5(torch, capi, dev, dev_index, n_lanes, steps=24):
+def measure_config5(torch, capi, dev, dev_index, n_lanes, steps=24, contents=("noisy", "objects")):
     """BASELINE config 5 on this GPU, short: 4K -> 8K, t = 1/4, 1/2, 3/4 (three generated 8K frames per pair: scale, motion ONCE,
-    one pass of lfg_interpolate_multi), the benchmark's pan.  A context of its own; frames in flight as the headline run."""
+    one pass of lfg_interpolate_multi), the benchmark's pan -- and, shorter still, the contents of `contents` (the pan is the
+    motion stage's best case but `static`).  A context of its own; frames in flight as the headline run."""
     w_in, h_in = SIZES["4k"]
     w, h = 2 * w_in, 2 * h_in
     factors = [0.25, 0.5, 0.75]
@@ -363,8 +386,161 @@ def measure_config5(torch, capi, dev, dev_index, n_lanes, steps=24):
            "stage_ms_one_call_at_a_time": per, "motion_workspace_bytes_per_lane": ws, "motion_plan_rim_split": rim,
            "prefilter_workgroups": groups, "fallback_tiles": st[1], "algorithmic_bytes_per_pair": algo,
            "hbm_frac": round(algo * steps / t / 1e9 / HBM_PEAK_GBS, 5)}
+    by_content = {}
+    for name in contents:
+        p_in, c_in = make_content(name, w_in, h_in, 0, 0)
+        t_pin.copy_(torch.from_numpy(p_in)); t_cin.copy_(torch.from_numpy(c_in))
+        if n_lanes > 1:
+            ctx.lane_select(0)
+        ctx.scale(f_pin, f_p8)
+        ctx.sync()
+        timed(2 * n_lanes, n_lanes)
+        tt = timed(steps, n_lanes)
+        if n_lanes > 1:
+            ctx.lane_select(0)
+        ctx.profile_reset(); ctx.profile_enable(True)
+        timed(max(4, steps // 3), 1)
+        ms, cnt = ctx.profile_get(capi.STAGE_MOTION)
+        ctx.profile_enable(False)
+        by_content[name] = {"interpolated_frames_per_s": round(steps * len(factors) / tt, 1), "ms_per_pair": round(tt / steps * 1e3, 4),
+                            "motion_ms_one_call_at_a_time": round(ms / max(cnt, 1), 4), "fallback_tiles": ctx.motion_last_stats()[1], "steps": steps}
+    out["other_contents"] = by_content
     ctx.close()
     return out
+
+
+def gather_ranks(dist, world, dev_index, rccl_ranks, verified):
+    """What rank 0 needs from the other ranks for the line, over the control plane (gloo): which card every rank drove, the size of
+    the RCCL communicator every rank joined (the driver checks its N against these), and every rank's check of its own frames."""
+    if world <= 1 or dist is None:
+        return [dev_index], rccl_ranks, verified
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (dev_index, rccl_ranks, verified))
+    devices = [g[0] for g in gathered]
+    ranks = min(g[1] for g in gathered)                       # (every rank must report the same communicator size)
+    if verified is not None:
+        oks = [bool(g[2] is not None and g[2].get("ok")) for g in gathered]
+        verified = dict(verified, ok=all(oks), per_rank_ok=oks)
+    return devices, ranks, verified
+
+
+def assemble_line(r):
+    """The ONE JSON line rank 0 prints, from plain values (`r`: a namespace filled by main(); no GPU, no torch in here, so that
+    tests/test_bench_helpers.py can build the line of an N > 1 run on CPU ranks and hold its keys)."""
+    args, world, stage_ms, factors = r.args, r.world, r.stage_ms, r.factors
+    w_in, h_in, w, h, mw, mh, in_res, share_input = r.w_in, r.h_in, r.w, r.h, r.mw, r.mh, r.in_res, r.share_input
+    steps, warmup, elapsed, regions, value = r.steps, r.warmup, r.elapsed, r.regions, r.value
+    exact_only, motion_stats, n_lanes, devices, rccl_ranks = r.exact_only, r.motion_stats, r.n_lanes, r.devices, r.rccl_ranks
+    fused_mi, extras, stage_pass = r.fused_mi, r.extras, r.stage_pass
+    stages = {}
+    for name, avg in stage_ms.items():
+        b = algorithmic_bytes(name, w_in, h_in, w if name == "scale" else mw, h if name == "scale" else mh)
+        if name == "interpolate" and len(factors) > 1 and not in_res:
+            b += 4 * mw * mh * (len(factors) - 1)               # one pass: inputs once, one frame per factor
+        entry = {"avg_ms": round(avg, 5), "algorithmic_bytes": b}
+        if name == "interpolate":
+            # the stage moves its algorithmic bytes only where it samples (interpolate_bytes_moved): the fraction is of the bytes
+            # it moved on THIS content's vectors (the pan: 6 of 14 B/px); `interpolate_alone.static` has the stage where it samples
+            if r.interp_moved is not None:
+                b = r.interp_moved
+                entry["bytes_moved"] = b
+        gbs = b / (avg * 1e-3) / 1e9
+        entry.update({"hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)})
+        stages[name] = entry
+    dominant = max(stage_ms, key=stage_ms.get)
+
+    def launches(n):        # per step
+        if n == "interpolate":
+            return len(factors) if in_res else 1
+        if n == "scale":            # curr (+ the generated frames of the input-resolution variant) (+ the shared previous frame)
+            return 1 + (len(factors) if in_res else 0) + (1 if share_input and args.workload == "pipeline" else 0)
+        return 1
+    total_bytes = sum(stages[n]["algorithmic_bytes"] * launches(n) for n in stage_ms)
+    path_gbs = total_bytes * steps / elapsed / 1e9
+
+    # `roofline`: the PATH against the HBM roofline -- algorithmic bytes of every stage of a step / ms_per_step.
+    # It follows from this line alone and is a fraction.  The dominant kernel's own figures sit beside it.
+    roofline = {"kernel": ("scale_2x_kernel" if args.workload == "scale" else
+                           f"whole step: scale_2x_kernel -> lfg_motion's kernels -> interpolate kernel (dominant stage: {dominant})"),
+                "bound": "hbm", "achieved": round(path_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(path_gbs / HBM_PEAK_GBS, 5), "traffic": None,
+                "algorithmic_bytes_per_step": total_bytes,
+                "how": "algorithmic bytes of a step (SURVEY.md 8(d): every stage reads each input once and writes each output once) "
+                       "/ ms_per_step, against the 8 TB/s spec peak"}
+    if args.workload != "scale" and "motion" in stage_ms:
+        fl = motion_flops(mw, mh)
+        md = {"kernel": ("motion_tiled_8_16_kernel" if exact_only else "the kernels of one lfg_motion call"),
+              "avg_ms": stages["motion"]["avg_ms"], "hbm_frac": stages["motion"]["hbm_frac"],
+              "work_disposed_tflops": round(fl / (stage_ms["motion"] * 1e-3) / 1e12, 2), "algorithmic_flops": fl,
+              "note": ("motion.comp is fp32-VALU bound, not HBM bound (SURVEY.md F7): 1089 candidates x 64 block positions per "
+                       "pixel.  work_disposed_tflops = the shader's algorithmic flops (W*H*1089*(64 adds + 12 per distance)) / "
+                       "the duration of the lfg_motion call: the rate at which that work is DISPOSED OF, not executed -- an exact "
+                       "bracket on the cost rules out all but ~1 candidate per pixel and a partial-distortion test drops most "
+                       "candidates of a segment after 14 of their 1449 distances (DESIGN.md, motion) -- so it may exceed the "
+                       "157.3 TFLOP/s fp32 peak and is NOT a utilisation; `executed` (when a counter profile of this very "
+                       "library is committed) is.  LFG_MOTION_MODE=1 runs the literal kernel alone.")}
+        if not exact_only and args.input == "1080p" and not in_res:
+            ex = pmc_executed("lfg::motion_prefilter_kernel")           # the dominant KERNEL of the dominant stage
+            if ex is not None:
+                md["executed"] = ex
+                ex_all = pmc_executed("lfg::motion_")
+                if ex_all is not None:
+                    md["executed_all_motion_kernels"] = {k: ex_all[k] for k in ("kernels", "kernel_us_per_step_in_that_pass", "valu_issue_utilisation")}
+        if motion_stats is not None:
+            md["motion_mode"] = "prefiltered"
+            md["fallback_tiles"] = {"of": motion_stats[0], "exact_kernel": motion_stats[1]}
+            md["candidates_recorded_per_pixel"] = round(motion_stats[2], 2)
+        else:
+            md["motion_mode"] = "exact kernel only"
+        roofline["dominant_stage"] = md
+    size_name = {"540p": "540p->1080p", "1080p": "1080p->4K", "4k": "4K->8K", "8k": "8K->16K"}[args.input]
+    if args.input == "1080p" and not in_res and len(factors) == 1:
+        t, src = pmc_traffic("lfg::scale_2x" if args.workload == "scale" else "lfg::")
+        if t is not None:
+            roofline["traffic"] = t
+            roofline["traffic_source"] = (f"{src}: FETCH_SIZE + WRITE_SIZE of every kernel of a step, two separate rocprofv3 "
+                                          "--pmc passes with this very library; FETCH_SIZE raw (uncalibrated for 4-byte-per-lane loads)")
+        else:
+            roofline["traffic_note"] = src
+    line = {
+        "metric": (f"interpolated frames/s, {size_name} RGBA8" if args.workload == "pipeline"
+                   else f"interpolated frames/s, {size_name} RGBA8 (variant: motion + interpolate at input resolution)" if in_res
+                   else f"upscaled frames/s, {size_name} RGBA8 (Lanczos only)"),
+        "value": round(value, 3),
+        "unit": "frames/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 arithmetic on u8 RGBA (u8 in, u8 out; int8 motion vectors)",
+        "data": "synthetic",
+        "config": {"workload": (f"{args.input}->{2 * h_in}p " + ("scale+motion(8,16)+interpolate" if args.workload == "pipeline"
+                                                                else "motion(8,16)+interpolate at input resolution, then scale real and generated frame" if in_res
+                                                                else "scale only")),
+                   "input": [w_in, h_in], "output": [w, h], "factors": factors if args.workload != "scale" else [],
+                   "order": ("north-star, fused: lfg_interpolate_frames with lfg_set_fused_motion_interpolate -- the motion kernels write the generated frame, "
+                             "no interpolate dispatch, no motion-vector frame (a labelled variant)" if fused_mi else "one call per stage"),
+                   "frames_in_flight": n_lanes,       # lanes of the C-ABI (DESIGN.md 4.5); 1 = strictly one frame at a time
+                   "devices": devices,                # HIP device ordinal of every rank, in rank order
+                   "content": args.content + (" (the motion stage's best case but `static`; see content_sweep)" if args.content == "translated" and args.workload != "scale" else ""),
+                   "parallelism": f"one frame pair per GPU x{world}" + (", lfg_broadcast_frame (RCCL) of the shared previous input frame per step, upscaled on every rank" if world > 1 else "")},
+        "rccl_ranks": rccl_ranks,              # lfg_comm_ranks(): the size of the RCCL communicator every rank joined (0: one GPU, none)
+        "repeats": {"regions": len(regions), "steps_per_region": steps, "median_ms_per_step": round(elapsed / steps * 1e3, 5),
+                    "min_ms_per_step": round(min(regions) / steps * 1e3, 5), "max_ms_per_step": round(max(regions) / steps * 1e3, 5),
+                    "first_region_ms_per_step": round(regions[0] / steps * 1e3, 5),
+                    "how": "every region is exactly `steps` steps between its own barrier + device-synchronisation pairs (max over ranks); "
+                           "a region shorter than 0.25 s is repeated until 0.25 s have been timed (25 regions at most) and `value` / "
+                           "`ms_per_step` are the MEDIAN region's"},
+        "roofline": roofline,
+        "stages": stages,
+        "stages_how": stage_pass,
+        "library_sha16": library_sha16(),
+    }
+    line["verified"] = r.verified          # what the timed kernels produced, checked after the timed regions (every rank's; None: not applicable)
+    line.update(extras)
+    # the CPU baseline is timed on rank 0 at N = 1 only (the driver's contract); the key is there at every N
+    line["cpu_baseline"] = r.cpu_baseline() if (world == 1 and r.cpu_baseline is not None) else None
+    return line
+
 
 
 def main():
@@ -378,7 +554,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        args.gpus = world                  # (launched by torch.distributed.run: its world size is the number of GPUs)
+        if args.gpus != 1:                 # --gpus given and contradicted by the launcher: refuse, rather than print another N's figure
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; they have to agree")
+        args.gpus = world                  # (launched by torch.distributed.run without --gpus: its world size is the number of GPUs)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # One rank per GPU.  torch.distributed (gloo, CPU tensors) is the CONTROL plane only: it carries the 128-byte
@@ -457,6 +635,7 @@ def main():
     # broadcast slot the next shared frame is about to land in.
     n_lanes = max(1, min(args.in_flight, capi.MAX_LANES)) if args.workload == "pipeline" else 1
     lane_bufs = [(f_curr4, f_mv, f_outs, f_prev4)]
+    lane_tensors = [(t_mv, [t for t, _ in outs])]      # (the same buffers as torch tensors: `verified` reads them back)
     keep_alive = []
     if n_lanes > 1:
         ctx.lanes(n_lanes)
@@ -468,6 +647,7 @@ def main():
                 fp4 = bufs[-1][1]
             keep_alive.append(bufs)
             lane_bufs.append((bufs[0][1], bufs[1][1], [f for _, f in bufs[2:2 + len(factors)]], fp4))
+            lane_tensors.append((bufs[1][0], [t for t, _ in bufs[2:2 + len(factors)]]))
 
     fused_mi = bool(args.fused_motion_interpolate) and args.workload == "pipeline" and len(factors) == 1
     if fused_mi:
@@ -480,15 +660,15 @@ def main():
         else:
             ctx.interpolate_multi(fp, fc, fm, fouts, factors)        # one pass over prev / curr / mv, every factor
 
-    def pipeline_step(k, fc_in, lanes, shared=None):
+    def pipeline_step(k, fc_in, lanes, shared=None, bufs=None, slots=None):
         """scale -> motion -> interpolate of step k on lane k % lanes (shared: the step's shared previous INPUT frame)"""
         j = k % lanes
-        fc4, fmv, fouts, fp4 = lane_bufs[j]
+        fc4, fmv, fouts, fp4 = (lane_bufs if bufs is None else bufs)[j]
         if lanes > 1:
             ctx.lane_select(j)
             ctx.lane_wait((k - 1) % lanes)
         if shared is not None:
-            f_shared = prev_slots[shared.acquire(k)][1]             # (waits for its broadcast, issues the next one)
+            f_shared = (prev_slots if slots is None else slots)[shared.acquire(k)][1]             # (waits for its broadcast, issues the next one)
             ctx.scale(f_shared, fp4)
         ctx.scale(fc_in, fc4)
         if lanes > 1:
@@ -559,6 +739,49 @@ def main():
     shared_prev.drain()
     torch.cuda.synchronize(dev)
 
+    # ---- what the timed kernels produced, looked at (no oracle: the HIP path against itself and against what the content
+    # implies).  The LAST timed step's vectors and generated frame, as they lie in its lane's buffers, must equal -- byte for
+    # byte, the whole frame -- an un-timed run of the same step with the literal motion kernel alone (lfg_set_motion_mode:
+    # every (pixel, candidate) through the shader's own 64-term chain); and on the benchmark's pan the vectors away from the
+    # rim must be minus the translation.
+    verified = None
+    if args.workload == "pipeline" and not fused_mi and os.environ.get("LFG_MOTION_MODE", "0") != "1":
+        last = warmup + len(regions) * steps - 1
+        t_mv_last, t_outs_last = lane_tensors[last % n_lanes]
+        got_mv = t_mv_last.cpu().numpy().view(np.int8).copy()
+        got_out = [t.cpu().numpy().copy() for t in t_outs_last]
+        chk_mv_t, chk_mv = empty_frame(w, h, capi.FORMAT_MV_S8X2)
+        chk_outs = [empty_frame(w, h) for _ in factors]
+        fc4_last, _, _, fp4_last = lane_bufs[last % n_lanes]
+        if n_lanes > 1:
+            ctx.lane_select(0)
+        ctx.set_motion_mode(capi.MOTION_EXACT_ONLY)
+        ctx.motion(fp4_last, fc4_last, chk_mv, 8, 16.0)
+        interpolate_all(fp4_last, fc4_last, chk_mv, [f for _, f in chk_outs])
+        ctx.set_motion_mode(capi.MOTION_PREFILTERED)
+        torch.cuda.synchronize(dev)
+        want_mv = chk_mv_t.cpu().numpy().view(np.int8)
+        mv_diff = int((got_mv != want_mv).any(-1).sum())
+        out_diff = int(sum((g != t.cpu().numpy()).any(-1).sum() for g, (t, _) in zip(got_out, chk_outs)))
+        verified = {"step": last, "lane": last % n_lanes,
+                    "vectors_vs_literal_kernel": {"pixels": w * h, "differing": mv_diff},
+                    "generated_frames_vs_literal_kernel": {"pixels": w * h * len(factors), "differing": out_diff},
+                    "how": "the last timed step's motion vectors and generated frame(s), read back from its lane's buffers, against an un-timed "
+                           "run of the same step through the literal motion kernel alone (LFG_MOTION_EXACT_ONLY), whole frames, byte for byte"}
+        ok = mv_diff == 0 and out_diff == 0
+        if args.content == "translated":
+            sx, sy = rank_motion(content_rank)
+            inner = got_mv[64:h - 64, 64:w - 64]
+            off = int(((inner[..., 0] != -2 * sx) | (inner[..., 1] != -2 * sy)).sum())
+            verified["translation_property"] = {"expected_vector": [-2 * sx, -2 * sy], "interior_pixels": int(inner.shape[0] * inner.shape[1]), "differing": off}
+            ok = ok and off == 0
+        if args.content == "static":
+            still = int((got_mv != 0).any(-1).sum())
+            verified["static_property"] = {"expected_vector": [0, 0], "differing": still}
+            ok = ok and still == 0
+        verified["ok"] = bool(ok)
+        del chk_mv_t, chk_outs
+
     if n_lanes > 1:
         # stage durations from a second pass on ONE lane, event-bracketed: with frames in flight the stages of two steps
         # overlap and an event pair around one of them times both
@@ -594,13 +817,7 @@ def main():
     ctx.profile_enable(False)
 
     # what RCCL saw, and which card every rank drove (the driver checks its N against these)
-    rccl_ranks = ctx.comm_ranks()
-    devices = [dev_index]
-    if world > 1:
-        gathered = [None] * world
-        dist.all_gather_object(gathered, (dev_index, rccl_ranks, ctx.comm_rank()))
-        devices = [g[0] for g in gathered]
-        rccl_ranks = min(g[1] for g in gathered)                  # (every rank must report the same communicator size)
+    devices, rccl_ranks, verified = gather_ranks(dist if world > 1 else None, world, dev_index, ctx.comm_ranks(), verified)
 
     units_per_step = 1 if args.workload == "scale" else len(factors)
     in_res = args.workload == "pipeline_input_res"
@@ -614,19 +831,61 @@ def main():
         b_scale = algorithmic_bytes("scale", w_in, h_in, w, h)
         b_interp = algorithmic_bytes("interpolate", w_in, h_in, w, h) + 4 * w * h * (len(factors) - 1)
         t_s = timed(lambda k: ctx.scale(f_curr_in, f_curr4), n2)
-        def scale_interp(k):
+        # scale + interpolate is measured on content where interpolate really SAMPLES: static frames (curr = prev, zero vectors:
+        # every pixel fetches both frames -- 14 B/px moved).  Under the benchmark's pan the literal semantics
+        # reject both samples of every pixel, the stage reads 16.6 MB of vectors, writes 33.2 MB of zeros, and a fraction
+        # computed from its 116 MB of ALGORITHMIC bytes would flatter it by 2.3x: that figure is printed beside, on bytes moved.
+        t_mv0 = torch.zeros((h, w, 2), dtype=torch.uint8, device=dev)
+        f_mv0 = capi.Context.wrap(t_mv0.data_ptr(), w, h, capi.FORMAT_MV_S8X2)
+        mv_pan = t_mv.cpu().numpy().view(np.int8)
+        moved_pan = interpolate_bytes_moved(mv_pan, factors)
+        def scale_interp_static(k):
+            ctx.scale(f_prev_in, f_curr4)                             # curr = prev: the same pixels as f_prev4, in a buffer of their own
+            interpolate_all(f_prev4, f_curr4, f_mv0)
+        def scale_interp_pan(k):
             ctx.scale(f_curr_in, f_curr4)
             interpolate_all(f_prev4, f_curr4, f_mv)
-        t_si = timed(scale_interp, n2)
+        timed(scale_interp_static, 50)
+        t_si = timed(scale_interp_static, n2)
+        timed(scale_interp_pan, 50)
+        t_sip = timed(scale_interp_pan, n2)
+        # the interpolate call alone on both contents, event-bracketed on one lane (HIP events around the launch)
+        def interp_alone(fm):
+            ctx.profile_reset(); ctx.profile_enable(True)
+            timed(lambda k: interpolate_all(f_prev4, f_curr4, fm), 400)
+            ms, cnt = ctx.profile_get(capi.STAGE_INTERPOLATE)
+            ctx.profile_enable(False)
+            return ms / max(cnt, 1)
+        if n_lanes > 1:
+            ctx.lane_select(0)
+        ctx.scale(f_prev_in, f_curr4)
+        ms_i_static = interp_alone(f_mv0)
+        ctx.scale(f_curr_in, f_curr4)
+        ms_i_pan = interp_alone(f_mv)
         extras["scale_only"] = {"workload": "BASELINE config 2: 1080p->4K Lanczos only", "steps": n2, "frames_per_s": round(n2 / t_s, 1),
                                 "us_per_step": round(t_s / n2 * 1e6, 3), "algorithmic_bytes": b_scale,
                                 "hbm_gbs": round(b_scale * n2 / t_s / 1e9, 1), "hbm_frac": round(b_scale * n2 / t_s / 1e9 / HBM_PEAK_GBS, 4),
                                 "how": "wall clock over back-to-back launches (includes the ~1.5 us between dependent kernels); "
                                        "rocprof's GPU-side duration of the kernel is in profiles/"}
-        extras["scale_interpolate"] = {"workload": "scale + interpolate (motion vectors given)", "steps": n2, "frames_per_s": round(n2 / t_si, 1),
-                                       "us_per_step": round(t_si / n2 * 1e6, 3), "algorithmic_bytes": b_scale + b_interp,
+        def frac(nbytes, seconds, n):
+            return round(nbytes * n / seconds / 1e9 / HBM_PEAK_GBS, 4)
+        extras["scale_interpolate"] = {"workload": "scale + interpolate (motion vectors given)",
+                                       "content": "static: curr = prev, zero vectors -- every pixel samples both frames, bytes moved = algorithmic bytes",
+                                       "steps": n2, "frames_per_s": round(n2 / t_si, 1),
+                                       "us_per_step": round(t_si / n2 * 1e6, 3), "algorithmic_bytes": b_scale + b_interp, "bytes_moved": b_scale + b_interp,
                                        "hbm_gbs": round((b_scale + b_interp) * n2 / t_si / 1e9, 1),
-                                       "hbm_frac": round((b_scale + b_interp) * n2 / t_si / 1e9 / HBM_PEAK_GBS, 4)}
+                                       "hbm_frac": frac(b_scale + b_interp, t_si, n2),
+                                       "on_the_headline_content": {"content": args.content, "us_per_step": round(t_sip / n2 * 1e6, 3), "algorithmic_bytes": b_scale + b_interp,
+                                                                "bytes_moved": b_scale + moved_pan, "hbm_frac": frac(b_scale + moved_pan, t_sip, n2),
+                                                                "note": "on the pan both samples of every pixel are rejected (SURVEY.md F5): interpolate reads the vectors and writes "
+                                                                        "zeros; the fraction is of the bytes it MOVES, not of its 116 MB of algorithmic bytes"}}
+        extras["interpolate_alone"] = {
+            "how": "HIP events around 400 lfg_interpolate launches, one at a time on one lane; inputs warm (the same buffers every launch)",
+            "static": {"avg_us": round(ms_i_static * 1e3, 3), "bytes_moved": b_interp, "hbm_frac": round(b_interp / (ms_i_static * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                       "note": "every pixel samples both frames"},
+            "headline_content": {"content": args.content, "avg_us": round(ms_i_pan * 1e3, 3), "algorithmic_bytes": b_interp, "bytes_moved": moved_pan,
+                              "hbm_frac": round(moved_pan / (ms_i_pan * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "note": "on the pan both samples are rejected (F5): fraction of the bytes moved"}}
         # ---- the same two configurations on TWO lanes of a second context (launch k + 1's dispatch and first-row wait overlap
         # launch k's tail: a throughput figure, labelled) and cache-COLD (every buffer of a step was last touched more than a
         # gigabyte of traffic ago, far beyond the 256 MiB Infinity Cache -- except the upscaled frame interpolate reads, which
@@ -649,7 +908,8 @@ def main():
             tin = t_curr_in.clone()
             sets.append((tin, capi.Context.wrap(tin.data_ptr(), w_in, h_in, capi.FORMAT_RGBA8), empty_frame(w, h), empty_frame(w, h),
                          empty_frame(w, h, capi.FORMAT_MV_S8X2), [empty_frame(w, h) for _ in factors]))
-            sets[-1][3][0].copy_(t_prev4); sets[-1][4][0].copy_(t_mv)
+            sets[-1][3][0].copy_(t_prev4); sets[-1][4][0].zero_()          # (static content: the input is the previous frame's, zero vectors)
+            sets[-1][0].copy_(t_prev_in)
         set_bytes = w_in * h_in * 4 + (2 + len(factors)) * w * h * 4 + w * h * 2
         def scale_cold(k):
             st = sets[k % n_sets]
@@ -667,7 +927,7 @@ def main():
                                               "how": f"{n_sets} distinct input and output frames in rotation ({n_sets * (w_in * h_in + w * h) * 4 >> 20} MiB between two uses of a buffer)"}
         extras["scale_only"]["cache"] = "warm: one input frame, resident in the Infinity Cache between launches (cache_cold beside it)"
         extras["scale_interpolate"]["cache_cold"] = {"frames_per_s": round(n2 / t_sic, 1), "us_per_step": round(t_sic / n2 * 1e6, 3),
-                                                     "hbm_frac": round((b_scale + b_interp) * n2 / t_sic / 1e9 / HBM_PEAK_GBS, 4),
+                                                     "bytes_moved": b_scale + b_interp, "hbm_frac": round((b_scale + b_interp) * n2 / t_sic / 1e9 / HBM_PEAK_GBS, 4),
                                                      "how": f"{n_sets} distinct sets of input / upscaled / previous / vector / output frames in rotation "
                                                             f"({n_sets * set_bytes >> 20} MiB between two uses of a buffer); the upscaled frame interpolate "
                                                             "reads was written by the step's own scale"}
@@ -703,6 +963,23 @@ def main():
             ctx.set_motion_mode(capi.MOTION_PREFILTERED)
             ctx.scale(f_prev_in, f_prev4)
         worst = min((v["frames_per_s"] for k, v in sweep.items() if not k.startswith("literal")), default=None)
+        # ---- the N > 1 step on this one GPU: with several GPUs the batch shares its previous frame, which arrives as an INPUT
+        # frame per step and is upscaled by every rank -- two scales per step instead of one.  A scaling curve's N = 1 point has
+        # to be THIS data flow (no collective: there is nobody to send to), not `value`.
+        if not share_input:
+            slots2 = [dev_frame(prev_in) for _ in range(2)]
+            bufs2 = [(fc4, fmv, fouts, empty_frame(w, h)) for (fc4, fmv, fouts, _) in lane_bufs]
+            bufs2f = [(a, b, c, d[1]) for (a, b, c, d) in bufs2]
+            sh2 = sharding.SharedFrameBroadcaster(2, None, world_size=1, is_source=True)
+            n3 = 400
+            timed(lambda k: pipeline_step(k, f_curr_in, n_lanes, sh2, bufs2f, slots2), 4 * n_lanes)
+            t_same = timed(lambda k: pipeline_step(k + 4 * n_lanes, f_curr_in, n_lanes, sh2, bufs2f, slots2), n3)
+            if n_lanes > 1:
+                ctx.lane_select(0)
+            extras["same_dataflow_as_n_gt_1"] = {"frames_per_s": round(n3 * len(factors) / t_same, 1), "ms_per_step": round(t_same / n3 * 1e3, 5), "steps": n3,
+                                                 "how": "the step every rank runs at N > 1 -- scale(shared previous INPUT frame) + scale(curr) + motion + interpolate -- "
+                                                        "on this GPU, without the broadcast: the denominator a scaling curve over N should use"}
+            del slots2, bufs2
         extras["config5"] = measure_config5(torch, capi, dev, dev_index, n_lanes)
         extras["content_sweep"] = {"frames_per_s_by_content": sweep, "worst_case_frames_per_s": worst,
                                    "note": "same kernels, same results discipline (bit-exact vectors on every content); the motion "
@@ -710,105 +987,16 @@ def main():
                                            "search range: `value` is on the SURVEY-prescribed pure pan, its best case bar `static`"}
 
     if rank == 0:
-        stages = {}
-        for name, avg in stage_ms.items():
-            b = algorithmic_bytes(name, w_in, h_in, w if name == "scale" else mw, h if name == "scale" else mh)
-            if name == "interpolate" and len(factors) > 1 and not in_res:
-                b += 4 * mw * mh * (len(factors) - 1)               # one pass: inputs once, one frame per factor
-            gbs = b / (avg * 1e-3) / 1e9
-            stages[name] = {"avg_ms": round(avg, 5), "algorithmic_bytes": b, "hbm_gbs": round(gbs, 1),
-                            "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
-        dominant = max(stage_ms, key=stage_ms.get)
-
-        def launches(n):        # per step
-            if n == "interpolate":
-                return len(factors) if in_res else 1
-            if n == "scale":            # curr (+ the generated frames of the input-resolution variant) (+ the shared previous frame)
-                return 1 + (len(factors) if in_res else 0) + (1 if share_input and args.workload == "pipeline" else 0)
-            return 1
-        total_bytes = sum(stages[n]["algorithmic_bytes"] * launches(n) for n in stage_ms)
-        path_gbs = total_bytes * steps / elapsed / 1e9
-
-        # `roofline`: the PATH against the HBM roofline -- algorithmic bytes of every stage of a step / ms_per_step.
-        # It follows from this line alone and is a fraction.  The dominant kernel's own figures sit beside it.
-        roofline = {"kernel": ("scale_2x_kernel" if args.workload == "scale" else
-                               f"whole step: scale_2x_kernel -> lfg_motion's kernels -> interpolate kernel (dominant stage: {dominant})"),
-                    "bound": "hbm", "achieved": round(path_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(path_gbs / HBM_PEAK_GBS, 5), "traffic": None,
-                    "algorithmic_bytes_per_step": total_bytes,
-                    "how": "algorithmic bytes of a step (SURVEY.md 8(d): every stage reads each input once and writes each output once) "
-                           "/ ms_per_step, against the 8 TB/s spec peak"}
-        if args.workload != "scale" and "motion" in stage_ms:
-            fl = motion_flops(mw, mh)
-            md = {"kernel": ("motion_tiled_8_16_kernel" if exact_only else "the kernels of one lfg_motion call"),
-                  "avg_ms": stages["motion"]["avg_ms"], "hbm_frac": stages["motion"]["hbm_frac"],
-                  "work_disposed_tflops": round(fl / (stage_ms["motion"] * 1e-3) / 1e12, 2), "algorithmic_flops": fl,
-                  "note": ("motion.comp is fp32-VALU bound, not HBM bound (SURVEY.md F7): 1089 candidates x 64 block positions per "
-                           "pixel.  work_disposed_tflops = the shader's algorithmic flops (W*H*1089*(64 adds + 12 per distance)) / "
-                           "the duration of the lfg_motion call: the rate at which that work is DISPOSED OF, not executed -- an exact "
-                           "bracket on the cost rules out all but ~1 candidate per pixel and a partial-distortion test drops most "
-                           "candidates of a segment after 14 of their 1449 distances (DESIGN.md, motion) -- so it may exceed the "
-                           "157.3 TFLOP/s fp32 peak and is NOT a utilisation; `executed` (when a counter profile of this very "
-                           "library is committed) is.  LFG_MOTION_MODE=1 runs the literal kernel alone.")}
-            if not exact_only and args.input == "1080p" and not in_res:
-                ex = pmc_executed("lfg::motion_prefilter_kernel")           # the dominant KERNEL of the dominant stage
-                if ex is not None:
-                    md["executed"] = ex
-                    ex_all = pmc_executed("lfg::motion_")
-                    if ex_all is not None:
-                        md["executed_all_motion_kernels"] = {k: ex_all[k] for k in ("kernels", "kernel_us_per_step_in_that_pass", "valu_issue_utilisation")}
-            if motion_stats is not None:
-                md["motion_mode"] = "prefiltered"
-                md["fallback_tiles"] = {"of": motion_stats[0], "exact_kernel": motion_stats[1]}
-                md["candidates_recorded_per_pixel"] = round(motion_stats[2], 2)
-            else:
-                md["motion_mode"] = "exact kernel only"
-            roofline["dominant_stage"] = md
-        size_name = {"540p": "540p->1080p", "1080p": "1080p->4K", "4k": "4K->8K", "8k": "8K->16K"}[args.input]
-        if args.input == "1080p" and not in_res and len(factors) == 1:
-            t, src = pmc_traffic("lfg::scale_2x" if args.workload == "scale" else "lfg::")
-            if t is not None:
-                roofline["traffic"] = t
-                roofline["traffic_source"] = (f"{src}: FETCH_SIZE + WRITE_SIZE of every kernel of a step, two separate rocprofv3 "
-                                              "--pmc passes with this very library; FETCH_SIZE raw (uncalibrated for 4-byte-per-lane loads)")
-            else:
-                roofline["traffic_note"] = src
-        line = {
-            "metric": (f"interpolated frames/s, {size_name} RGBA8" if args.workload == "pipeline"
-                       else f"interpolated frames/s, {size_name} RGBA8 (variant: motion + interpolate at input resolution)" if in_res
-                       else f"upscaled frames/s, {size_name} RGBA8 (Lanczos only)"),
-            "value": round(value, 3),
-            "unit": "frames/s",
-            "n_gpus": world, "steps": steps, "warmup": warmup,
-            "ms_per_step": round(elapsed / steps * 1e3, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 arithmetic on u8 RGBA (u8 in, u8 out; int8 motion vectors)",
-            "data": "synthetic",
-            "config": {"workload": (f"{args.input}->{2 * h_in}p " + ("scale+motion(8,16)+interpolate" if args.workload == "pipeline"
-                                                                    else "motion(8,16)+interpolate at input resolution, then scale real and generated frame" if in_res
-                                                                    else "scale only")),
-                       "input": [w_in, h_in], "output": [w, h], "factors": factors if args.workload != "scale" else [],
-                       "order": ("north-star, fused: lfg_interpolate_frames with lfg_set_fused_motion_interpolate -- the motion kernels write the generated frame, "
-                                 "no interpolate dispatch, no motion-vector frame (a labelled variant)" if fused_mi else "one call per stage"),
-                       "frames_in_flight": n_lanes,       # lanes of the C-ABI; 1 = strictly one frame at a time
-                       "devices": devices,                # HIP device ordinal of every rank, in rank order
-                       "content": args.content + (" (the motion stage's best case but `static`; see content_sweep)" if args.content == "translated" and args.workload != "scale" else ""),
-                       "parallelism": f"one frame pair per GPU x{world}" + (", lfg_broadcast_frame (RCCL) of the shared previous input frame per step, upscaled on every rank" if world > 1 else "")},
-            "rccl_ranks": rccl_ranks,              # lfg_comm_ranks(): the size of the RCCL communicator every rank joined (0: one GPU, none)
-            "repeats": {"regions": len(regions), "steps_per_region": steps, "median_ms_per_step": round(elapsed / steps * 1e3, 5),
-                        "min_ms_per_step": round(min(regions) / steps * 1e3, 5), "max_ms_per_step": round(max(regions) / steps * 1e3, 5),
-                        "first_region_ms_per_step": round(regions[0] / steps * 1e3, 5),
-                        "how": "every region is exactly `steps` steps between its own barrier + device-synchronisation pairs (max over ranks); "
-                               "a region shorter than 0.25 s is repeated until 0.25 s have been timed (25 regions at most) and `value` / "
-                               "`ms_per_step` are the MEDIAN region's"},
-            "roofline": roofline,
-            "stages": stages,
-            "stages_how": stage_pass,
-            "library_sha16": library_sha16(),
-        }
-        line.update(extras)
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(w_in, h_in, w, h, factors, args.workload)
+        from types import SimpleNamespace
+        interp_moved = None
+        if "interpolate" in stage_ms:
+            interp_moved = interpolate_bytes_moved((t_mv_in if in_res else t_mv).cpu().numpy().view(np.int8), factors)
+        line = assemble_line(SimpleNamespace(
+            args=args, world=world, stage_ms=stage_ms, factors=factors, w_in=w_in, h_in=h_in, w=w, h=h, mw=mw, mh=mh, in_res=in_res,
+            share_input=share_input, steps=steps, warmup=warmup, elapsed=elapsed, regions=regions, value=value, exact_only=exact_only,
+            motion_stats=motion_stats, n_lanes=n_lanes, devices=devices, rccl_ranks=rccl_ranks, fused_mi=fused_mi, extras=extras,
+            stage_pass=stage_pass, interp_moved=interp_moved, verified=verified,
+            cpu_baseline=(None if args.no_cpu_baseline else (lambda: cpu_baseline(w_in, h_in, w, h, factors, args.workload)))))
         print(json.dumps(line), flush=True)
 
     ctx.close()

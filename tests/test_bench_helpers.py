@@ -125,3 +125,82 @@ def test_main_spawns_before_it_imports_torch(monkeypatch):
     with pytest.raises(SystemExit) as e:
         b.main()
     assert e.value.code == 5 and seen == {"gpus": 2, "argv": ["--gpus", "2", "--steps", "3"]}
+
+
+def test_interpolate_bytes_moved_counts_only_the_samples_taken():
+    """Under the literal semantics a displaced sample outside [0,1]^2 is vec4(0) without a fetch: the bytes the
+    stage moves depend on the vectors.  Zero vectors: 14 B/px; the benchmark's pan: 6 B/px; half and half in between."""
+    import numpy as np
+    b = _bench()
+    w, h = 64, 32
+    zero = np.zeros((h, w, 2), np.int8)
+    assert b.interpolate_bytes_moved(zero, [0.5]) == 14 * w * h
+    assert b.interpolate_bytes_moved(zero, [0.25, 0.5, 0.75]) == (2 + 8 + 12) * w * h
+    pan = np.zeros((h, w, 2), np.int8); pan[...] = (-6, 4)
+    assert b.interpolate_bytes_moved(pan, [0.5]) == 6 * w * h
+    half = pan.copy(); half[:, : w // 2] = 0
+    assert b.interpolate_bytes_moved(half, [0.5]) == 6 * w * h + 8 * (w // 2) * h
+    one = np.zeros((h, w, 2), np.int8); one[..., 0] = 1        # uv + 0.5: curr's sample stays inside for the left half, prev's for the right
+    assert b.interpolate_bytes_moved(one, [0.5]) == 6 * w * h + 4 * w * h
+
+
+def _line_worker(rank, world, port, q):
+    import types
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        b = _bench()
+        verified = {"ok": rank == 0 or True, "step": 44, "vectors_vs_literal_kernel": {"pixels": 10, "differing": 0}}
+        devices, rccl, verified = b.gather_ranks(dist, world, rank, world, verified)
+        if rank == 0:
+            args = types.SimpleNamespace(workload="pipeline", input="1080p", content="translated", no_cpu_baseline=False)
+            r = types.SimpleNamespace(
+                args=args, world=world, stage_ms={"scale": 0.012, "motion": 0.33, "interpolate": 0.017}, factors=[0.5],
+                w_in=1920, h_in=1080, w=3840, h=2160, mw=3840, mh=2160, in_res=False, share_input=True, steps=20, warmup=5,
+                elapsed=0.0066, regions=[0.0066, 0.0067, 0.0065], value=world * 20 / 0.0066, exact_only=False,
+                motion_stats=(2040, 0, 0.0), n_lanes=3, devices=devices, rccl_ranks=rccl, fused_mi=False, extras={},
+                stage_pass={"how": "stub"}, interp_moved=6 * 3840 * 2160, verified=verified,
+                cpu_baseline=lambda: (_ for _ in ()).throw(AssertionError("the CPU baseline is an N = 1 matter")))
+            q.put(b.assemble_line(r))
+        else:
+            q.put(None)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_the_line_of_an_n_gt_1_run_has_every_key():
+    """The line rank 0 prints at N > 1, assembled on two CPU ranks over gloo from stub measurements: the contract's keys, the
+    `roofline` object, `cpu_baseline: null` (it is timed at N = 1 only), every rank's device and check gathered in rank order."""
+    import json
+    import socket
+    import torch.multiprocessing as mp
+    world = 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_line_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    line = next(g for g in got if g is not None)
+    json.dumps(line)                                         # serialisable as it stands
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "stages", "verified", "rccl_ranks", "library_sha16"):
+        assert key in line, key
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["cpu_baseline"] is None
+    assert line["config"]["devices"] == [0, 1] and line["rccl_ranks"] == 2
+    rf = line["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in rf, key
+    assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1
+    # two scales per step at N > 1 (the shared previous frame is upscaled by every rank): the path's bytes say so
+    assert rf["algorithmic_bytes_per_step"] == 2 * 41472000 + 82944000 + 116121600
+    assert line["stages"]["interpolate"]["bytes_moved"] == 6 * 3840 * 2160
+    assert line["verified"]["ok"] is True and line["verified"]["per_rank_ok"] == [True, True]
