@@ -84,6 +84,9 @@ def parse_args():
     ap.add_argument("--fused-motion-interpolate", action="store_true",
                     help="pipeline workload, one factor: lfg_interpolate_frames in the north-star order (lfg_set_fused_motion_interpolate: the motion "
                          "kernels write the generated frame themselves, no interpolate dispatch, no motion-vector frame); a labelled variant, not the default")
+    ap.add_argument("--semantics", choices=["reference", "intended"], default="reference",
+                    help="reference (default): the shaders as written, the parity contract; intended: the opt-in lfg_set_semantics mode (vectors displace by "
+                         "pixels, ties resolve to the shortest vector) -- a labelled variant, never the headline")
     ap.add_argument("--no-extras", action="store_true", help="skip scale_only / scale_interpolate / content_sweep (profiling runs)")
     return ap.parse_args()
 
@@ -519,6 +522,7 @@ def assemble_line(r):
                    "input": [w_in, h_in], "output": [w, h], "factors": factors if args.workload != "scale" else [],
                    "order": ("north-star, fused: lfg_interpolate_frames with lfg_set_fused_motion_interpolate -- the motion kernels write the generated frame, "
                              "no interpolate dispatch, no motion-vector frame (a labelled variant)" if fused_mi else "one call per stage"),
+                   "semantics": args.semantics,       # "reference": the shaders as written; "intended": the opt-in lfg_set_semantics mode (a labelled variant)
                    "frames_in_flight": n_lanes,       # lanes of the C-ABI; 1 = strictly one frame at a time
                    "devices": devices,                # HIP device ordinal of every rank, in rank order
                    "content": args.content + (" (the motion stage's best case but `static`; see content_sweep)" if args.content == "translated" and args.workload != "scale" else ""),
@@ -650,6 +654,8 @@ def main():
             lane_tensors.append((bufs[1][0], [t for t, _ in bufs[2:2 + len(factors)]]))
 
     fused_mi = bool(args.fused_motion_interpolate) and args.workload == "pipeline" and len(factors) == 1
+    if args.semantics == "intended":
+        ctx.set_semantics(capi.SEMANTICS_INTENDED)
     if fused_mi:
         ctx.set_fused_motion_interpolate(True)
 
@@ -826,7 +832,7 @@ def main():
 
     # ---- the same run, rank 0, one GPU: the two HBM-bound configurations and the other contents
     extras = {}
-    if rank == 0 and world == 1 and not args.no_extras and args.workload == "pipeline" and args.input == "1080p":
+    if rank == 0 and world == 1 and not args.no_extras and args.workload == "pipeline" and args.input == "1080p" and args.semantics == "reference":
         n2 = 4000
         b_scale = algorithmic_bytes("scale", w_in, h_in, w, h)
         b_interp = algorithmic_bytes("interpolate", w_in, h_in, w, h) + 4 * w * h * (len(factors) - 1)
@@ -990,7 +996,7 @@ def main():
         from types import SimpleNamespace
         interp_moved = None
         if "interpolate" in stage_ms:
-            interp_moved = interpolate_bytes_moved((t_mv_in if in_res else t_mv).cpu().numpy().view(np.int8), factors)
+            interp_moved = interpolate_bytes_moved((t_mv_in if in_res else t_mv).cpu().numpy().view(np.int8), factors, intended=args.semantics == "intended")
         line = assemble_line(SimpleNamespace(
             args=args, world=world, stage_ms=stage_ms, factors=factors, w_in=w_in, h_in=h_in, w=w, h=h, mw=mw, mh=mh, in_res=in_res,
             share_input=share_input, steps=steps, warmup=warmup, elapsed=elapsed, regions=regions, value=value, exact_only=exact_only,
