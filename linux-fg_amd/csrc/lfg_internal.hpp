@@ -79,7 +79,7 @@ struct FusedOut {
 };
 
 struct MotionWorkspaceLayout { size_t list, umin, count, tileFlags, segDone, segMap, queueCount, ctrl, order, plan, auxList, auxUmin, auxCount,
-                               queue, dynList, dynUmin, dynCount, dynInit, openList, merge, mergeBytes, total; int queueCap, slots, rimSplit, listMain, listAux, listDyn; };
+                               queue, dynList, dynUmin, dynCount, dynInit, openList, merge, mergeBytes, leanTiles, plan2, total; int queueCap, slots, rimSplit, listMain, listAux, listDyn, leanCount, rimSplit2, units, units2, tiles, lastLean /* the lane's last call went by the second plan */; };
 // Work units of the motion prefilter (motion.hip: prefilter_plan).  A unit is a 56 x 64 tile, or one of nChunks
 // contiguous parts of a tile's candidate order, or one 16-row segment of a tile with its four waves on four parts of
 // the order; parts have private lists in the aux arrays (merged by the resolve kernel).
@@ -107,6 +107,7 @@ struct PrefilterPlan {               // passed by value to the kernels
 struct PrefilterPlanHost {
     int tilesX = 0, tiles = 0, units = 0, auxUnits = 0;
     std::vector<uint32_t> unitMap, unitAux, tileMap;
+    std::vector<uint32_t> leanTiles;     // the whole tiles the lean kernel may take first (motion_lean.hip: lean_tile_ok)
 };
 
 struct ProfileSlot {
@@ -129,6 +130,10 @@ struct lfg_lane_state {
     int motion_units = 0;
     hipEvent_t mark = nullptr;
     bool marked = false;
+    uint32_t *lean_flag = nullptr;             // pinned: the order kernel's verdict on the lane's last call ("content for the lean kernel")
+    hipEvent_t lean_ev = nullptr;              // ... recorded behind its copy
+    bool lean_ev_pending = false;
+    int lean_predict = 0;                      // the verdict the next call goes by
 };
 
 struct lfg_context {
@@ -137,6 +142,10 @@ struct lfg_context {
     int lane = 0;
     hipEvent_t mark = nullptr;                 // the selected lane's (see lfg_lane_state)
     bool marked = false;
+    uint32_t *lean_flag = nullptr;             // likewise
+    hipEvent_t lean_ev = nullptr;
+    bool lean_ev_pending = false;
+    int lean_predict = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::string error;
@@ -158,6 +167,7 @@ struct lfg_context {
     bool fuse_interpolate_scale = false;       // lfg_interpolate_scale: one fused kernel instead of the two stages (measured slower)
     bool fuse_motion_interpolate = false;      // lfg_interpolate_frames: the motion kernels write the generated frame themselves
     bool motion_hints = true;                  // per-call visiting order from sample-block hints (LFG_MOTION_HINTS=0: off)
+    bool motion_lean = true;                   // whole interior tiles go through the lean kernel first (LFG_MOTION_LEAN=0: off)
     // the one exchange of the path (lfg_comm.cpp): an RCCL communicator, its stream and two events
     void *comm = nullptr;                      // ncclComm_t
     int comm_ranks = 0, comm_rank = 0;
@@ -192,14 +202,20 @@ hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const 
 constexpr int kMotionTableWords = 1092;     // 33 * 33 candidates + the sentinel, padded to a multiple of 4
 void motion_tables(bool intended, uint32_t *rank2scan, uint32_t *order32, uint32_t *entryOfScan, uint32_t *baseScan);
 // Prefiltered motion path (motion.hip): MotionWorkspaceLayout = byte offsets of its scratch arrays.
-size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, int rimSplit, MotionWorkspaceLayout *layout);
+size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, int rimSplit, int rimSplit2, MotionWorkspaceLayout *layout);   // rimSplit2: the plan used beside the lean kernel (0: none)
 PrefilterPlanHost prefilter_plan(uint32_t width, uint32_t height, int slots, int rimSplit);   // rimSplit: 4 or 8 parts of the order per rim segment
 int prefilter_slots();      // workgroups of the prefilter kernel the current device holds at once
 hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                           const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &layout, int units,
                                           const uint32_t *rank2scan, const uint32_t *order32,
                                           const uint32_t *entryOfScan, const uint32_t *baseScan, bool useHints, bool framesInFlight,
-                                          const FusedOut &fused = FusedOut());
+                                          const FusedOut &fused = FusedOut(), bool lean = false, uint32_t *leanFlagHost = nullptr);
+// The lean kernel for whole interior tiles (motion_lean.hip): runs between the order kernel and the generic prefilter, marks the
+// segments it settles in segDone; the generic kernel skips those.
+bool lean_tile_ok(int tile, int tilesX, int W, int H);
+bool lean_frames_ok(const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv);
+hipError_t launch_motion_lean(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv,
+                              const uint32_t *order32, const uint32_t *leanTiles, int nTiles, int tilesX, uint32_t *segDone, uint32_t *stats);
 hipError_t launch_motion_generic(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                  const lfg_frame &mv, int block_size, int radius, bool intended);
 hipError_t launch_interpolate(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,

@@ -33,6 +33,7 @@
 #include "lfg_device.hpp"
 #include "lfg_internal.hpp"
 #include "lfg_interp.hpp"
+#include "lfg_motion_tile.hpp"
 
 #include <algorithm>
 #include <cstring>
@@ -82,7 +83,6 @@ __device__ __forceinline__ float dist4(const float (&c)[4], f32x4 p) {
 
 // ------------------------------------------------------------------------------ tiled, B = 8, R = 16
 
-constexpr int kB = 8, kR = 16;
 constexpr int kTW = 64, kTH = 64;                 // pixel tile
 constexpr int kNT = 512;                          // threads per workgroup: one per 8x1 pixel patch
 constexpr int kDW = kTW + kB - 1;                 // 71 block positions across
@@ -98,8 +98,6 @@ constexpr int kMainRows = 9;
 constexpr int kExtraCols = kDW - 64;              // 7
 constexpr int kExtra = kExtraCols * kDH;          // 497 entries
 constexpr int kPos = kMainRows + 1;               // 10
-constexpr int kSide = 2 * kR + 1;
-constexpr int kCand = kSide * kSide;
 static_assert(kTW / 8 * kTH == kNT, "one thread per 8x1 pixel patch");
 static_assert(kNT / 64 * kMainRows >= kDH && kExtra <= kNT, "phase-A map covers the plane");
 
@@ -407,14 +405,6 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
 //   per surviving candidate e: window reads(e+1) issued | row sums + test(e) | column sums(e+1) | slab
 //   write/read(e+1); the slab round trip is the one exposed latency, covered by the other wave of the SIMD.
 
-constexpr int kPTW = 56, kPTH = 64;               // prefilter tile (pixels): 56 + 7 = 63 position columns <= 64 lanes
-constexpr int kPNT = 256;
-constexpr int kSeg = 16;                          // pixel rows per wave
-constexpr int kSegD = kSeg + kB - 1;              // 23 distances per thread and candidate
-constexpr int kWinW = 95;                         // window columns: 63 positions + 2R
-constexpr int kWinH = kPTH + kB - 1 + 2 * kR;     // 103 rows; the window is stored COLUMN-major (pitch kWinH, odd), so
-                                                  // a thread's 23 texels are consecutive words (ds_read2_b32 pairs) and
-                                                  // the 64 lanes of a read still fall into distinct banks
 constexpr int kSlabP = 132;                       // slab pitch of a ROW PAIR (floats): rows r, r + 8 interleaved per column,
                                                   // so a thread writes two rows with one ds_write_b64 and the row sums read
                                                   // both with one ds_read_b64.  8-byte accesses are served sixteen lanes at a
@@ -424,15 +414,6 @@ constexpr int kSlabP = 132;                       // slab pitch of a ROW PAIR (f
                                                   // for the other.  (136 put rows r and r + 4 on the same slots: 5.7e8
                                                   // conflict cycles per launch on a frame that searches in full, measured.)
 static_assert((kSlabP / 2) % 16 == 2 && kSlabP / 2 >= 64, "conflict-free transposed 8-byte reads");
-// The one-point lattice of interior segments: block positions (kLatC0 + 8 i, kLatR0 + 8 j).  A pixel's block is the 8 x 8
-// positions that start at its own column and row, so rows 7 | 15 put exactly one lattice row into the block of each of a
-// segment's 16 pixel rows, and columns 7, 15 .. 55 one lattice column into the block of each of its 56 pixel columns:
-// 2 x 7 = 14 points.  (Rows 3 | 11 | 19 and columns 3 .. 59 did the same with 3 x 8 = 24 until late in round 2.)
-constexpr int kLatC0 = 7, kLatCols = 7, kLatR0 = 7, kLatRows = 2;
-static_assert(kLatC0 + 8 * (kLatCols - 1) == kPTW - 1 && kLatR0 + 8 * (kLatRows - 1) == kSeg - 1 && kLatC0 == kB - 1 && kLatR0 == kB - 1,
-              "one lattice point in every pixel's block: the first at the far end of pixel 0's, the last at the near end of the last pixel's");
-constexpr int kRun = 7;                           // pixels per row-sum run: 8 runs x 7 = 56
-constexpr int kRunIn = kRun + kB - 1;             // 13
 #ifndef LFG_SIXTEEN
 #define LFG_SIXTEEN 1
 #endif
@@ -511,13 +492,9 @@ constexpr int kHintGrid = LFG_HINT_GRID, kHints = kHintGrid * kHintGrid;      //
 // tile for the literal kernel as before.  Depth 10 everywhere (one slot of it a spare: see listsOverflowed).
 constexpr int kListK = LFG_LIST_MAIN, kListAux = LFG_LIST_AUX, kListDyn = LFG_LIST_DYN;
 static_assert(kListK >= 4 && kListAux >= 4 && kListDyn >= 4 && kListK <= 64 && kListAux <= 64 && kListDyn <= 64, "list depths");
-constexpr float kRatio = 1.00008f;      // >= (1 + 3.6e-5) / (1 - 3.6e-5) with room for the product's rounding ("Bracket")
-constexpr float kRestart = 0.9997f;     // S~ < thr kRestart: every earlier record of the pixel is dead ((1 - 2^-13) / kRatio^2 = 1 - 2.8e-4, with room)
-static_assert(kRestart < (1.0 - 1.0 / 8192.0) / (1.00008 * 1.00008) - 1e-5, "restart rule");
 static_assert((kHints & (kHints - 1)) == 0 && kHints >= 256 && kHints <= 1024, "one hint per thread of the order kernel, scrambled by an odd multiplier");
 static_assert(kPNT / 64 * kSeg == kPTH && 8 * kRun == kPTW && kPTH == kTH, "stage maps cover the tile");
 
-static_assert(kPTW + kB - 1 <= 64 && kWinW >= kPTW + kB - 1 + 2 * kR, "one lane per position column");
 
 // Candidates whose whole shifted block lies outside prev on one axis sample nothing but out-of-image zeros, so for
 // a given pixel they all cost exactly the same (the same sequence of |curr texel| distances): a plateau of up to a few
@@ -540,7 +517,6 @@ typedef uint32_t Rec;
 __device__ __forceinline__ Rec rec_make(float s, uint32_t cand) { return ((__builtin_bit_cast(uint32_t, s) >> 10) << 11) | cand; }
 __device__ __forceinline__ float rec_cost_low(Rec r) { return __builtin_bit_cast(float, (r >> 11) << 10); }
 __device__ __forceinline__ uint32_t rec_cand(Rec r) { return r & 0x7FFu; }
-static_assert(kCand < 2048, "a rank fits eleven bits");
 
 typedef const __attribute__((address_space(3))) uint32_t *lds_ro_u32_ptr;
 typedef const __attribute__((address_space(3))) float *lds_ro_f32_ptr;
@@ -602,6 +578,12 @@ __device__ __forceinline__ void prefilter_unit(
     const int tileY = tile / sp.tilesX, tileX = tile - tileY * sp.tilesX;
     const int tx0 = tileX * kPTW, ty0 = tileY * kPTH;                  // tile origin (pixels)
     const int bx0 = tx0 - kB / 2, by0 = ty0 - kB / 2;                  // image coords of block position (0,0)
+    // Segments the lean kernel has settled already (motion_lean.hip; whole tiles only): a tile whose four are done is skipped
+    // before anything is staged, a done segment's wave leaves behind the staging barrier.
+    if (whole && !fromQueue) {
+        const uint32_t *const d = segDone + tile * (kPTH / kSeg);
+        if (__builtin_amdgcn_readfirstlane((int)(d[0] & d[1] & d[2] & d[3])) != 0) return;
+    }
     if (tid == 0) sGiveUp = 0u;
     // (the two flags of this call's order, requested here: read where they are used -- behind the staging barrier -- each
     //  was a scalar load from memory with nothing to hide its latency, two microseconds per unit)
@@ -760,6 +742,7 @@ __device__ __forceinline__ void prefilter_unit(
     stampStaged = __builtin_amdgcn_s_memrealtime();
 #endif
     if (ty0 + kSeg * seg >= H) return;     // this wave's rows lie below the image
+    if (whole && !fromQueue && __builtin_amdgcn_readfirstlane((int)segDone[tile * (kPTH / kSeg) + seg]) != 0) return;     // (settled by the lean kernel)
 
     // (lane 63 has no position column: it re-reads lane 62's texels, its sums are never used)
     const lds_ro_u32_ptr winBase = (lds_ro_u32_ptr)(sWin + min(lane, kPTW + kB - 2) * kWinH + kSeg * seg);
@@ -1713,6 +1696,9 @@ __device__ __forceinline__ void prefilter_unit(
             // (a wave with the whole order turns to the ranks as soon as it can, even where that saves no batch: consecutive
             //  ranks are neighbouring window offsets, so the lattice reads of a batch fall into 64 different LDS banks, while
             //  64 consecutive entries of the visiting order hit the same bank three or four times)
+            // (Round 4 also sent whole-order waves whose thresholds are small but NOT zero-cost words -- 58 % of the interior waves
+            //  under the benchmark's pan -- to the ranks, all 1089 of them: conflict-free reads against the pseudo-random order's
+            //  three to a bank.  Measured 1.3 % slower, 3,100 against 3,145 frames/s: dropped.)
             if (!flushOnly && !byRank && i0 >= max(nHead, LFG_FIRST_BATCH) && zeroBound < (uint32_t)kCand &&
                 ((whole && LFG_RANK_ALWAYS) || (int)zeroBound + 64 <= nEntries - i0)) {
                 byRank = true; rank0 = 0; visited = i0;
@@ -2850,7 +2836,7 @@ hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const 
     return hipGetLastError();
 }
 
-size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, int rimSplit, MotionWorkspaceLayout *layout) {
+size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, int rimSplit, int rimSplit2, MotionWorkspaceLayout *layout) {
     const size_t px = (size_t)width * height;
     const size_t tiles = (size_t)((width + kTW - 1) / kTW) * ((height + kTH - 1) / kTH);
     auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -2876,10 +2862,15 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, int ri
     l.queue = l.ctrl + 8 * sizeof(uint32_t);     // ctrl: [0..2] the prefilter's unit counters, [4] open segments
     l.order = align(l.queue + (size_t)l.queueCap * sizeof(uint32_t));           // this call's hints and visiting order
     // work-unit tables and the auxiliary arrays of the shared tiles (see prefilter_plan): one 56 x 64 block per unit
+    // (two plans side by side where the lean kernel may run -- frames in flight: the one for calls that go through it, rimSplit2,
+    //  and the one for calls that do not; the host picks per call, lfg_capi.cpp: motion_run.  The auxiliary arrays serve either.)
     const PrefilterPlanHost plan = prefilter_plan(width, height, slots, rimSplit);
-    const size_t auxUnits = (size_t)plan.auxUnits;
+    const PrefilterPlanHost plan2 = rimSplit2 ? prefilter_plan(width, height, slots, rimSplit2) : PrefilterPlanHost();
+    const size_t auxUnits = (size_t)std::max(plan.auxUnits, plan2.auxUnits);
     l.plan = align(l.order + (kHints + kCand + 3) * sizeof(uint32_t));
-    l.auxList = align(l.plan + (size_t)(2 * plan.units + plan.tiles) * sizeof(uint32_t));
+    l.plan2 = align(l.plan + (size_t)(2 * plan.units + plan.tiles) * sizeof(uint32_t));
+    l.units = plan.units; l.units2 = plan2.units; l.rimSplit2 = rimSplit2; l.tiles = plan.tiles;
+    l.auxList = align(l.plan2 + (size_t)(2 * plan2.units + plan2.tiles) * sizeof(uint32_t));
     l.auxUmin = align(l.auxList + auxUnits * kPTH * kPTW * kListAux * sizeof(Rec));
     l.auxCount = align(l.auxUmin + auxUnits * kPTH * kPTW * sizeof(float));
     // each queue entry owns four 16-row blocks of private lists (0.92 MB)
@@ -2896,7 +2887,9 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, int ri
     l.openList = align(l.dynInit + (size_t)l.queueCap / (LFG_DYN_PARTS / 4) * kSeg * kPTW * sizeof(uint32_t));
     l.merge = align(l.openList + ptiles * (kPTH / kSeg) * sizeof(uint32_t));
     l.mergeBytes = (size_t)kShareBelow * kTW * kTH * sizeof(unsigned long long);
-    l.total = align(l.merge + l.mergeBytes);
+    l.leanTiles = align(l.merge + l.mergeBytes);
+    l.leanCount = (int)plan2.leanTiles.size();
+    l.total = align(l.leanTiles + (plan2.leanTiles.size() + 1) * sizeof(uint32_t));
     if (layout) *layout = l;
     return l.total;
 }
@@ -2981,6 +2974,22 @@ PrefilterPlanHost prefilter_plan(uint32_t width, uint32_t height, int slots, int
         for (size_t i = 0; i < units.size(); ++i) { p.unitMap[i] = units[i].first; p.unitAux[i] = units[i].second; }
     }
     p.units = (int)p.unitMap.size();
+    // the whole tiles the lean kernel takes first (motion_lean.hip); the generic kernel keeps them in its plan and skips what is done
+    std::vector<uint32_t> lean;
+    for (uint32_t um : p.unitMap)
+        if (((um >> 24) & 0xFu) == 1u && ((um >> 28) & 1u) == 0u && lean_tile_ok((int)(um & 0xFFFFFu), p.tilesX, W, H)) lean.push_back(um & 0xFFFFFu);
+#ifndef LFG_LEAN_XCD_BANDS
+#define LFG_LEAN_XCD_BANDS 1             // workgroup i of that launch lands on XCD i mod 8: give every XCD a contiguous band of tiles, in raster
+#endif                                   // order, so that the windows of neighbouring tiles (they overlap 2.7 x) meet in ONE L2
+    if (LFG_LEAN_XCD_BANDS && lean.size() >= 64) {
+        const size_t n = lean.size(), per = (n + 7) / 8;
+        for (size_t i = 0; i < 8 * per; ++i) {
+            const size_t src = (i % 8) * per + i / 8;
+            if (src < n) p.leanTiles.push_back(lean[src]);
+        }
+    } else {
+        p.leanTiles = lean;
+    }
     return p;
 }
 
@@ -3134,7 +3143,7 @@ __global__ __launch_bounds__(kHints) void motion_order_kernel(
     __shared__ uint32_t sOwner[kCand];
     __shared__ uint32_t sVotes[kCand];
     constexpr int kWaves = kHints / 64;
-    __shared__ uint32_t sWaveSum[kWaves];
+    __shared__ uint32_t sWaveSum[kWaves], sWaveClose[kWaves];
     __shared__ uint32_t sRunning, sTop;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t zero = baseScan[0];               // zero motion
@@ -3150,7 +3159,12 @@ __global__ __launch_bounds__(kHints) void motion_order_kernel(
     // half the sum of its four absolute differences): such a segment would search in full.  Handing segments over
     // (motion_prefilter_kernel) pays when they are the exception; with a quarter of the samples unmatched it is off.
     const uint32_t unmatched = (uint32_t)__popcll(__ballot((hint >> 11) >= 1020u));
-    if (lane == 0) sWaveSum[wv] = unmatched;
+    // (close: a match within the lean kernel's reach; but not where the match is EXACT everywhere -- stills, a pan of frames that were
+    //  not resampled: there every wave of the persistent kernel ends its search after three or four passes over the ranks and its
+    //  units are as short as the lean kernel's, 6,900 against 6,130 frames/s on stills.  Under the benchmark's pan 238 of the 256
+    //  sample blocks match exactly and 58 % of the interior waves do not: a rounding of the upscaler here and there.)
+    const uint32_t close = (uint32_t)__popcll(__ballot((float)(hint >> 11) < 2.0f * kOnePointOnly)) | ((uint32_t)__popcll(__ballot((hint >> 11) == 0u)) << 16);
+    if (lane == 0) { sWaveSum[wv] = unmatched; sWaveClose[wv] = close; }
     if (mine != zero) atomicMin(&sOwner[mine], (uint32_t)tid);
     atomicAdd(&sVotes[mine], 1u);
     __syncthreads();
@@ -3164,6 +3178,14 @@ __global__ __launch_bounds__(kHints) void motion_order_kernel(
         uint32_t unmatchedAll = 0u;
         for (int w = 0; w < kWaves; ++w) unmatchedAll += sWaveSum[w];
         order32[kCand] = unmatchedAll * 4u <= (uint32_t)kHints ? 1u : 0u;
+        // ... and for the lean kernel (motion_lean.hip), which keeps a segment only while its largest threshold stays below
+        // kOnePointOnly: a block whose best SAD is 2 x that or more cannot cost less (a distance is at least half its SAD).  The
+        // kernel and the plan that goes with it pay where nearly EVERY sample matches that closely -- a pan: +6 % -- and cost 2 % where
+        // a twentieth of them do not (the occluded and moving-object frames: 242 and 250 of 256), so that is the bar: 63 in 64.
+        uint32_t closeAll = 0u;
+        for (int w = 0; w < kWaves; ++w) closeAll += sWaveClose[w];
+        // (bit 0: the verdict; above it the two counts, for LFG_DEBUG)
+        order32[kCand + 2] = (((closeAll & 0xFFFFu) * 64u >= 63u * (uint32_t)kHints && (closeAll >> 16) * 64u < 63u * (uint32_t)kHints) ? 1u : 0u) | ((closeAll & 0xFFFFu) << 1) | ((closeAll >> 16) << 12);
         order32[0] = entryOfScan[top];
         if (top != zero) order32[1] = entryOfScan[zero];
         sRunning = top != zero ? 2u : 1u;
@@ -3199,8 +3221,10 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
                                           const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &l, int units,
                                           const uint32_t *rank2scan, const uint32_t *order,
                                           const uint32_t *entryOfScan, const uint32_t *baseScan, bool useHints, bool framesInFlight,
-                                          const FusedOut &fused) {
+                                          const FusedOut &fused, bool lean, uint32_t *leanFlagHost) {
     const int tilesX = ((int)curr.width + kTW - 1) / kTW;
+    lean = lean && useHints && !fused.data && l.units2 > 0 && l.leanCount > 0 && curr.width >= 64u && curr.height >= 64u && lean_frames_ok(prev, curr, mv);
+    if (lean) units = l.units2;          // the plan that goes with the lean kernel
     Rec *list = reinterpret_cast<Rec *>(workspace + l.list);
     float *umin = reinterpret_cast<float *>(workspace + l.umin);
     uint32_t *count = reinterpret_cast<uint32_t *>(workspace + l.count);
@@ -3209,7 +3233,7 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
     PrefilterPlan sp{};
     sp.tilesX = ((int)curr.width + kPTW - 1) / kPTW;
     sp.units = units;
-    sp.unitMap = reinterpret_cast<const uint32_t *>(workspace + l.plan);
+    sp.unitMap = reinterpret_cast<const uint32_t *>(workspace + (lean ? l.plan2 : l.plan));
     sp.unitAux = sp.unitMap + units;
     sp.tileMap = sp.unitAux + units;
     sp.auxList = reinterpret_cast<uint32_t *>(workspace + l.auxList);
@@ -3247,11 +3271,18 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         order = callOrder;
+        // the whole interior tiles, through the lean kernel first (motion_lean.hip): what it settles it marks in segDone -- cleared by
+        // the hint kernel above -- and the generic kernel below skips
+        if (lean) {
+            e = launch_motion_lean(s, prev, curr, mv, order, reinterpret_cast<const uint32_t *>(workspace + l.leanTiles), l.leanCount, sp.tilesX, segDone, ctrl + 6);      // (ctrl[6], [7]: segments it settled, segments it left)
+            if (e != hipSuccess) return e;
+        }
     } else {
         e = hipMemsetAsync(flags, 0, l.order - l.tileFlags, s);         // (no hints: the fixed order; the area is cleared by a memset)
         if (e != hipSuccess) return e;
     }
-    const int groups = std::max(1, std::min(sp.units, l.slots > 0 ? l.slots : sp.units));
+    int groups = std::max(1, std::min(sp.units, l.slots > 0 ? l.slots : sp.units));
+    if (const char *g = getenv("LFG_PREF_GROUPS")) groups = std::max(1, std::min(groups, atoi(g)));      // (experiment: a smaller persistent grid)
     if (fused.data)
         hipLaunchKernelGGL(motion_prefilter_kernel<true>, dim3(groups), dim3(kPNT), 0, s,
                            (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
@@ -3415,8 +3446,13 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
 #ifdef LFG_DIAG_NO_FALLBACK             // (timing experiment: what the launch that usually finds nothing to do costs)
     return hipSuccess;
 #endif
-    return launch_motion_tiled_8_16(s, prev, curr, mv, flags, rank2scan, reinterpret_cast<unsigned long long *>(workspace + l.merge),
-                                    sp.queueCount + 1, fused);
+    e = launch_motion_tiled_8_16(s, prev, curr, mv, flags, rank2scan, reinterpret_cast<unsigned long long *>(workspace + l.merge),
+                                 sp.queueCount + 1, fused);
+    // the order kernel's verdict on this call's content (order32[kCand + 2]) for the host, which decides with it whether the lane's
+    // NEXT call goes through the lean kernel: four bytes into pinned memory, behind everything else of the call
+    if (e == hipSuccess && leanFlagHost && useHints && curr.width >= 64u && curr.height >= 64u)
+        e = hipMemcpyAsync(leanFlagHost, order + kCand + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    return e;
 }
 
 // Diagnostic: compares exact_sqrt with __builtin_sqrtf for every float whose bit pattern lies in

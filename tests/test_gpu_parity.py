@@ -1166,7 +1166,9 @@ def test_motion_workspace_size_and_list_depths_on_pure_noise(ctx):
     other = capi.Context(0)
     try:
         other.lanes(2)
-        assert other.motion_workspace_size(3840, 2160) < min(n4k, 0.95e9)      # every rim segment in four parts
+        # (frames in flight: two plans side by side since round 4 -- rim segments in four parts, and the plan of the calls that go
+        #  through the lean kernel, whose top and bottom strips are searched in eight; the auxiliary lists serve either)
+        assert other.motion_workspace_size(3840, 2160) <= n4k + (1 << 20)      # (+ the second plan's tables and the lean kernel's tile list)
     finally:
         other.close()
     assert ctx.motion_workspace_size(1920, 1080) < n4k
