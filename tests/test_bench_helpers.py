@@ -155,7 +155,7 @@ def _line_worker(rank, world, port, q):
         verified = {"ok": rank == 0 or True, "step": 44, "vectors_vs_literal_kernel": {"pixels": 10, "differing": 0}}
         devices, rccl, verified = b.gather_ranks(dist, world, rank, world, verified)
         if rank == 0:
-            args = types.SimpleNamespace(workload="pipeline", input="1080p", content="translated", no_cpu_baseline=False)
+            args = types.SimpleNamespace(workload="pipeline", input="1080p", content="translated", no_cpu_baseline=False, semantics="reference")
             r = types.SimpleNamespace(
                 args=args, world=world, stage_ms={"scale": 0.012, "motion": 0.33, "interpolate": 0.017}, factors=[0.5],
                 w_in=1920, h_in=1080, w=3840, h=2160, mw=3840, mh=2160, in_res=False, share_input=True, steps=20, warmup=5,
@@ -185,7 +185,7 @@ def test_the_line_of_an_n_gt_1_run_has_every_key():
     procs = [ctx.Process(target=_line_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=120) for _ in range(world)]
+    got = [q.get(timeout=60) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
