@@ -79,7 +79,7 @@ struct FusedOut {
 };
 
 struct MotionWorkspaceLayout { size_t list, umin, count, tileFlags, segDone, segMap, queueCount, ctrl, order, plan, auxList, auxUmin, auxCount,
-                               queue, dynList, dynUmin, dynCount, dynInit, openList, merge, mergeBytes, leanTiles, plan2, total; int queueCap, slots, rimSplit, listMain, listAux, listDyn, leanCount, rimSplit2, units, units2, tiles, lastLean /* the lane's last call went by the second plan */; };
+                               queue, dynList, dynUmin, dynCount, dynInit, openList, merge, mergeBytes, leanTiles, hardTiles, plan2, total; int queueCap, slots, rimSplit, listMain, listAux, listDyn, leanCount, rimSplit2, units, units2, units2Static /* the second plan's units without the lean kernel's tiles, which come last in its table */, tiles, lastLean /* the lane's last call went by the second plan */; };
 // Work units of the motion prefilter (motion.hip: prefilter_plan).  A unit is a 56 x 64 tile, or one of nChunks
 // contiguous parts of a tile's candidate order, or one 16-row segment of a tile with its four waves on four parts of
 // the order; parts have private lists in the aux arrays (merged by the resolve kernel).
@@ -102,6 +102,10 @@ struct PrefilterPlan {               // passed by value to the kernels
     uint32_t *dynCount;
     uint32_t *dynInit;               // per handed-over segment: the 16 x 56 thresholds of the wave that handed it over
     uint32_t *openList, *openCount;  // the segments left to the resolve kernel (tile * 4 + segment), appended as units end
+    // Calls that went through the lean kernel first (motion_lean.hip): the table's last units -- that kernel's tiles -- are not drawn
+    // from the table; instead the tiles in which it LEFT a segment come from the list it wrote (hardCount: nullptr = no such call).
+    int unitsStatic;
+    const uint32_t *hardTiles, *hardCount;
     FusedOut fused;                  // the generated frame, written where the vectors are decided (off: data == nullptr)
 };
 struct PrefilterPlanHost {
@@ -215,7 +219,8 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
 bool lean_tile_ok(int tile, int tilesX, int W, int H);
 bool lean_frames_ok(const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv);
 hipError_t launch_motion_lean(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv,
-                              const uint32_t *order32, const uint32_t *leanTiles, int nTiles, int tilesX, uint32_t *segDone, uint32_t *stats);
+                              const uint32_t *order32, const uint32_t *leanTiles, int nTiles, int tilesX, uint32_t *segDone,
+                              uint32_t *hardTiles, uint32_t *hardCount, uint32_t *stats);
 hipError_t launch_motion_generic(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                  const lfg_frame &mv, int block_size, int radius, bool intended);
 hipError_t launch_interpolate(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,

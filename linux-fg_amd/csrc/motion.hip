@@ -2445,6 +2445,9 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
     // next slot, also fetch-and-add -- a compare-and-swap loop collapses when hundreds of workgroups run out of plan
     // units together -- so a workgroup can come to OWN a slot that no segment has been pushed into yet.  It keeps the
     // slot (`owned`) through whatever else it does and does not leave while somebody could still fill it.
+    // the units of this launch: the plan's table -- or, behind the lean kernel, the table without that kernel's tiles plus the tiles
+    // in which it left a segment (its list is complete: that kernel has finished)
+    const uint32_t planUnits = sp.hardCount ? (uint32_t)sp.unitsStatic + *sp.hardCount : (uint32_t)sp.units;
     uint32_t owned = kNoUnit;
     for (;;) {
         __syncthreads();                   // the previous unit is over for all four waves: its LDS may be reused
@@ -2467,7 +2470,7 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
             if (next == kNoUnit) {        // (drawn when needed, not ahead: a workgroup holding two of the long units in a row
                                           //  would run them one after the other while others idle)
                 const uint32_t u = atomicAdd(&ctrl[0], 1u);
-                if (u < (uint32_t)sp.units) { next = u; entry = sp.unitMap[u]; }
+                if (u < planUnits) { next = u; entry = u < (uint32_t)sp.unitsStatic ? sp.unitMap[u] : (sp.hardTiles[u - (uint32_t)sp.unitsStatic] | (1u << 24)); }
             }
             if (next == kNoUnit) {
                 // Out of plan units: wait for my slot to be filled, or for the last plan unit to finish (only a running
@@ -2481,7 +2484,7 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
                 while (owned != kNoUnit) {
                     const bool hard = (++n & 31u) == 0u;
                     if ((entry = hard ? peek_hard(&sp.queue[owned]) : peek(&sp.queue[owned])) != 0u) { next = 0x80000000u | owned; owned = kNoUnit; break; }
-                    if ((hard ? peek_hard(&ctrl[1]) : peek(&ctrl[1])) >= (uint32_t)sp.units) {
+                    if ((hard ? peek_hard(&ctrl[1]) : peek(&ctrl[1])) >= planUnits) {
                         if (owned < min(peek_hard(sp.queueCount), cap)) { entry = wait_entry(owned); next = 0x80000000u | owned; }
                         owned = kNoUnit;
                         break;
@@ -2869,7 +2872,7 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, int ri
     const size_t auxUnits = (size_t)std::max(plan.auxUnits, plan2.auxUnits);
     l.plan = align(l.order + (kHints + kCand + 3) * sizeof(uint32_t));
     l.plan2 = align(l.plan + (size_t)(2 * plan.units + plan.tiles) * sizeof(uint32_t));
-    l.units = plan.units; l.units2 = plan2.units; l.rimSplit2 = rimSplit2; l.tiles = plan.tiles;
+    l.units = plan.units; l.units2 = plan2.units; l.units2Static = plan2.units - (int)plan2.leanTiles.size(); l.rimSplit2 = rimSplit2; l.tiles = plan.tiles;
     l.auxList = align(l.plan2 + (size_t)(2 * plan2.units + plan2.tiles) * sizeof(uint32_t));
     l.auxUmin = align(l.auxList + auxUnits * kPTH * kPTW * kListAux * sizeof(Rec));
     l.auxCount = align(l.auxUmin + auxUnits * kPTH * kPTW * sizeof(float));
@@ -2889,7 +2892,8 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, int ri
     l.mergeBytes = (size_t)kShareBelow * kTW * kTH * sizeof(unsigned long long);
     l.leanTiles = align(l.merge + l.mergeBytes);
     l.leanCount = (int)plan2.leanTiles.size();
-    l.total = align(l.leanTiles + (plan2.leanTiles.size() + 1) * sizeof(uint32_t));
+    l.hardTiles = align(l.leanTiles + (plan2.leanTiles.size() + 1) * sizeof(uint32_t));
+    l.total = align(l.hardTiles + (plan2.leanTiles.size() + 1) * sizeof(uint32_t));
     if (layout) *layout = l;
     return l.total;
 }
@@ -2974,10 +2978,17 @@ PrefilterPlanHost prefilter_plan(uint32_t width, uint32_t height, int slots, int
         for (size_t i = 0; i < units.size(); ++i) { p.unitMap[i] = units[i].first; p.unitAux[i] = units[i].second; }
     }
     p.units = (int)p.unitMap.size();
-    // the whole tiles the lean kernel takes first (motion_lean.hip); the generic kernel keeps them in its plan and skips what is done
+    // the whole tiles the lean kernel takes first (motion_lean.hip): their units go to the END of the table -- a call that went
+    // through that kernel draws the table without them and takes the tiles it left from the kernel's list instead
     std::vector<uint32_t> lean;
-    for (uint32_t um : p.unitMap)
-        if (((um >> 24) & 0xFu) == 1u && ((um >> 28) & 1u) == 0u && lean_tile_ok((int)(um & 0xFFFFFu), p.tilesX, W, H)) lean.push_back(um & 0xFFFFFu);
+    {
+        auto isLean = [&](uint32_t um) { return ((um >> 24) & 0xFu) == 1u && ((um >> 28) & 1u) == 0u && lean_tile_ok((int)(um & 0xFFFFFu), p.tilesX, W, H); };
+        std::vector<std::pair<uint32_t, uint32_t>> units(p.unitMap.size());
+        for (size_t i = 0; i < units.size(); ++i) units[i] = {p.unitMap[i], p.unitAux[i]};
+        std::stable_partition(units.begin(), units.end(), [&](const std::pair<uint32_t, uint32_t> &u) { return !isLean(u.first); });
+        for (size_t i = 0; i < units.size(); ++i) { p.unitMap[i] = units[i].first; p.unitAux[i] = units[i].second; }
+        for (uint32_t um : p.unitMap) if (isLean(um)) lean.push_back(um & 0xFFFFFu);
+    }
 #ifndef LFG_LEAN_XCD_BANDS
 #define LFG_LEAN_XCD_BANDS 1             // workgroup i of that launch lands on XCD i mod 8: give every XCD a contiguous band of tiles, in raster
 #endif                                   // order, so that the windows of neighbouring tiles (they overlap 2.7 x) meet in ONE L2
@@ -3250,6 +3261,9 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
     sp.openList = reinterpret_cast<uint32_t *>(workspace + l.openList);
     sp.openCount = reinterpret_cast<uint32_t *>(workspace + l.ctrl) + 4;
     sp.fused = fused;
+    sp.unitsStatic = lean ? l.units2Static : units;
+    sp.hardTiles = lean ? reinterpret_cast<const uint32_t *>(workspace + l.hardTiles) : nullptr;
+    sp.hardCount = lean ? reinterpret_cast<const uint32_t *>(workspace + l.ctrl) + 5 : nullptr;          // (ctrl[5]: cleared by the hint kernel with the rest)
     uint32_t *segDone = reinterpret_cast<uint32_t *>(workspace + l.segDone);
     uint32_t *const ctrl = reinterpret_cast<uint32_t *>(workspace + l.ctrl);
     hipError_t e = hipSuccess;
@@ -3276,7 +3290,8 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
         if (lean) {
             // (beside the persistent kernel on a stream of its own, with that kernel's grid cut to 448 .. 320 workgroups to leave it room:
             //  measured for a context that runs one frame at a time, 2,160 - 2,430 frames/s against 2,610 without the kernel: not done)
-            e = launch_motion_lean(s, prev, curr, mv, order, reinterpret_cast<const uint32_t *>(workspace + l.leanTiles), l.leanCount, sp.tilesX, segDone, ctrl + 6);      // (ctrl[6], [7]: segments it settled, segments it left)
+            e = launch_motion_lean(s, prev, curr, mv, order, reinterpret_cast<const uint32_t *>(workspace + l.leanTiles), l.leanCount, sp.tilesX, segDone,
+                                   reinterpret_cast<uint32_t *>(workspace + l.hardTiles), ctrl + 5, ctrl + 6);      // (ctrl[5]: tiles it left; ctrl[6], [7]: segments it settled, segments it left -- counted in diagnostic builds)
             if (e != hipSuccess) return e;
         }
     } else {

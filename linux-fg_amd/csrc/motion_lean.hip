@@ -110,10 +110,12 @@ template <int kDummy>
 __global__ __launch_bounds__(kPNT, 3) void motion_lean_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch, int W, int H,
     const uint32_t *__restrict__ order32, const uint32_t *__restrict__ leanTiles, int tilesX,
-    int8_t *__restrict__ mv, int mvPitch, uint32_t *__restrict__ segDone, uint32_t *__restrict__ leanStats) {
+    int8_t *__restrict__ mv, int mvPitch, uint32_t *__restrict__ segDone, uint32_t *__restrict__ hardTiles, uint32_t *__restrict__ hardCount,
+    uint32_t *__restrict__ leanStats) {
     __shared__ uint32_t sWin[kWinH * kWinW];                           // 38.2 KB packed RGBA8 search window, column-major
     __shared__ __attribute__((aligned(8))) float sSlab[kPNT / 64][kLeanSlab];
     __shared__ uint32_t sVisited[(kCand + 31) / 32];                   // the ranks the hints hold (they are not looked at twice)
+    __shared__ uint32_t sLeft;                                         // some wave of the workgroup left its segment to the generic kernel
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), seg = wave;
@@ -124,7 +126,12 @@ __global__ __launch_bounds__(kPNT, 3) void motion_lean_kernel(
     // this call's order: entry = rank | window offset << 16 (motion.hip: motion_order_kernel); [kCand + 1]: entries in front that are hints
     // [kCand + 2]: most of the call's sample blocks have a near-exact match (motion_order_kernel) -- otherwise this is not the
     // content the kernel is for, and every workgroup leaves before it has staged anything
-    if ((order32[kCand + 2] & 1u) == 0u) return;
+    // (a tile in which anything is left goes onto the list the generic kernel draws from behind its own table: here, all of them)
+    if ((order32[kCand + 2] & 1u) == 0u) {
+        if (tid == 0) hardTiles[atomicAdd(hardCount, 1u)] = (uint32_t)tile;
+        return;
+    }
+    if (tid == 0) sLeft = 0u;
     const int nHints = min((int)order32[kCand + 1], kLeanHintsMax);
     // (the hints themselves, one per lane, asked for here: in flight with the window, not a memory latency each further down)
     const uint32_t hintL = order32[lane];
@@ -415,6 +422,9 @@ __global__ __launch_bounds__(kPNT, 3) void motion_lean_kernel(
         }
         if (lane == 0) segDone[tile * (kPTH / kSeg) + seg] = 1u;
     }
+    if (__builtin_amdgcn_readfirstlane(__ballot(open) != 0ull) && lane == 0) sLeft = 1u;
+    __syncthreads();
+    if (tid == 0 && sLeft != 0u) hardTiles[atomicAdd(hardCount, 1u)] = (uint32_t)tile;
 #ifdef LFG_LEAN_STATS                       // (diagnostic build only: 8,576 device-scope atomics on two words are 120 us of a 70 us launch)
     if (leanStats && lane == 0) atomicAdd(&leanStats[__builtin_amdgcn_readfirstlane(__ballot(open) == 0ull) ? 0 : 1], 1u);
 #endif
@@ -435,11 +445,12 @@ bool lean_frames_ok(const lfg_frame &prev, const lfg_frame &curr, const lfg_fram
 }
 
 hipError_t launch_motion_lean(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv,
-                              const uint32_t *order32, const uint32_t *leanTiles, int nTiles, int tilesX, uint32_t *segDone, uint32_t *stats) {
+                              const uint32_t *order32, const uint32_t *leanTiles, int nTiles, int tilesX, uint32_t *segDone,
+                              uint32_t *hardTiles, uint32_t *hardCount, uint32_t *stats) {
     if (nTiles <= 0) return hipSuccess;
     hipLaunchKernelGGL(motion_lean_kernel<0>, dim3((unsigned)nTiles), dim3(kPNT), 0, s,
                        (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch, (int)curr.width, (int)curr.height,
-                       order32, leanTiles, tilesX, (int8_t *)mv.data, (int)mv.pitch, segDone, stats);
+                       order32, leanTiles, tilesX, (int8_t *)mv.data, (int)mv.pitch, segDone, hardTiles, hardCount, stats);
     return hipGetLastError();
 }
 
