@@ -38,6 +38,10 @@ constexpr int kLeanSlabP = 68;                     // slab row pitch (floats): =
                                                   // (address r8 * 68 + 7 q + i) fall into 32 distinct banks; the writes are consecutive
 constexpr int kLeanSlab = 8 * kLeanSlabP;          // eight rows at a time: 2,176 bytes per wave
 static_assert((kCand + 31) / 32 <= 64 && kLeanSlabP % 32 == 4 && kLeanSlabP >= kPTW + kB - 1 && kLeanSlab * 4 >= kSeg * kPTW * 2, "conflict-free, and room for a segment's vectors");
+#ifndef LFG_LEAN_AHEAD
+#define LFG_LEAN_AHEAD 3                          // candidates per lane and pass over the ranks
+#endif
+constexpr int kLeanAhead = LFG_LEAN_AHEAD;
 constexpr int kLeanHintsMax = 64;                  // entries of the call's order taken as hints (the generic kernel's limit): one per lane
 #ifndef LFG_LEAN_EVALS_MAX
 #define LFG_LEAN_EVALS_MAX 24                      // full evaluations after which a segment is not the easy kind: left to the generic kernel
@@ -267,10 +271,10 @@ __global__ __launch_bounds__(kPNT, 3) void motion_lean_kernel(
     // come within the wave's largest threshold of the current frame's texel there?  By exact compare while the thresholds stand
     // for zero costs, by sums of absolute differences while they are small (a distance is at least half its SAD), by the
     // squared distance otherwise.
-    auto latticeKeep = [&](const uint32_t (&off)[3], bool (&keep)[3]) {
-        uint32_t tex[3][kLatCols][kLatRows];
+    auto latticeKeep = [&](const uint32_t (&off)[kLeanAhead], bool (&keep)[kLeanAhead]) {
+        uint32_t tex[kLeanAhead][kLatCols][kLatRows];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
+        for (int a = 0; a < kLeanAhead; ++a) {
             const lean_lds_u32 w = winSeg + off[a];
 #pragma unroll
             for (int ci = 0; ci < kLatCols; ++ci) {
@@ -282,45 +286,51 @@ __global__ __launch_bounds__(kPNT, 3) void motion_lean_kernel(
         // (three loops, not one with the choice inside: the choice is wave-uniform, and inside the loop it was three scalar
         //  branches per lattice point)
         if (waveThr < 0.5f) {
-            uint32_t acc[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};              // the smallest XOR is 0: VALU only
+            uint32_t acc[kLeanAhead];                                              // the smallest XOR is 0: VALU only
+#pragma unroll
+            for (int a = 0; a < kLeanAhead; ++a) acc[a] = 0xFFFFFFFFu;
 #pragma unroll
             for (int ci = 0; ci < kLatCols; ++ci) {
 #pragma unroll
                 for (int t = 0; t < kLatRows; ++t) {
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) acc[a] = min(acc[a], tex[a][ci][t] ^ cLat[ci][t]);
+                    for (int a = 0; a < kLeanAhead; ++a) acc[a] = min(acc[a], tex[a][ci][t] ^ cLat[ci][t]);
                 }
             }
 #pragma unroll
-            for (int a = 0; a < 3; ++a) keep[a] = acc[a] == 0u;
+            for (int a = 0; a < kLeanAhead; ++a) keep[a] = acc[a] == 0u;
         } else if (waveThr < kSadTestMax) {
-            uint32_t acc[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            uint32_t acc[kLeanAhead];
+#pragma unroll
+            for (int a = 0; a < kLeanAhead; ++a) acc[a] = 0xFFFFFFFFu;
 #pragma unroll
             for (int ci = 0; ci < kLatCols; ++ci) {
 #pragma unroll
                 for (int t = 0; t < kLatRows; ++t) {
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) acc[a] = min(acc[a], __builtin_amdgcn_sad_u8(cLat[ci][t], tex[a][ci][t], 0u));
+                    for (int a = 0; a < kLeanAhead; ++a) acc[a] = min(acc[a], __builtin_amdgcn_sad_u8(cLat[ci][t], tex[a][ci][t], 0u));
                 }
             }
             const float sadMax = (2.0f * waveThr) * 1.00001f;                       // SAD > 2 thr => distance > thr
 #pragma unroll
-            for (int a = 0; a < 3; ++a) keep[a] = (float)acc[a] <= sadMax;
+            for (int a = 0; a < kLeanAhead; ++a) keep[a] = (float)acc[a] <= sadMax;
         } else {
-            uint32_t acc[3] = {0x7F800000u, 0x7F800000u, 0x7F800000u};
+            uint32_t acc[kLeanAhead];
+#pragma unroll
+            for (int a = 0; a < kLeanAhead; ++a) acc[a] = 0x7F800000u;
 #pragma unroll
             for (int ci = 0; ci < kLatCols; ++ci) {
 #pragma unroll
                 for (int t = 0; t < kLatRows; ++t) {
                     const uint32_t ccT = __builtin_amdgcn_udot4(cLat[ci][t], cLat[ci][t], 0x4B000000u, false);
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) acc[a] = min(acc[a], __builtin_bit_cast(uint32_t, lean_sqdist(cLat[ci][t], ccT, tex[a][ci][t])));
+                    for (int a = 0; a < kLeanAhead; ++a) acc[a] = min(acc[a], __builtin_bit_cast(uint32_t, lean_sqdist(cLat[ci][t], ccT, tex[a][ci][t])));
                 }
             }
             // n > thr^2 (1 + 2^-20) => sqrt(n) exceeds thr beyond v_sqrt_f32's ulp
             const uint32_t thrSqBits = __builtin_bit_cast(uint32_t, (waveThr * waveThr) * 1.000001f);
 #pragma unroll
-            for (int a = 0; a < 3; ++a) keep[a] = !(acc[a] > thrSqBits);
+            for (int a = 0; a < kLeanAhead; ++a) keep[a] = !(acc[a] > thrSqBits);
         }
     };
 
@@ -332,8 +342,10 @@ __global__ __launch_bounds__(kPNT, 3) void motion_lean_kernel(
     // A step yields up to three masks of lanes whose candidate has to be evaluated in full; after them the thresholds are reduced.
     int phase = 0, h = 0, r0 = 0;
     for (;;) {
-        unsigned long long m[3] = {0ull, 0ull, 0ull};
-        uint32_t ordA[3] = {0u, 0u, 0u};
+        unsigned long long m[kLeanAhead];
+        uint32_t ordA[kLeanAhead];
+#pragma unroll
+        for (int a = 0; a < kLeanAhead; ++a) { m[a] = 0ull; ordA[a] = 0u; }
         if (phase == 0) {
             if (h >= nHints || (h > 0 && waveThr < kOnePointOnly) || evals > LFG_LEAN_EVALS_MAX) { phase = 1; continue; }
             ordA[0] = (uint32_t)__builtin_amdgcn_readlane((int)hintL, h);
@@ -345,8 +357,10 @@ __global__ __launch_bounds__(kPNT, 3) void motion_lean_kernel(
             if (left) break;
             if (h >= nHints) continue;
             ordA[0] = hintL;                            // lane l takes hint l
-            const uint32_t off[3] = {hintL >> 16, hintL >> 16, hintL >> 16};
-            bool keep[3];
+            uint32_t off[kLeanAhead];
+            bool keep[kLeanAhead];
+#pragma unroll
+            for (int a = 0; a < kLeanAhead; ++a) off[a] = hintL >> 16;      // (the one test, several times over: once per unit)
             latticeKeep(off, keep);
             m[0] = __ballot(keep[0] && lane >= h && lane < nHints && (hintL & 0xFFFFu) < zeroBound);
             h = nHints;
@@ -357,10 +371,10 @@ __global__ __launch_bounds__(kPNT, 3) void motion_lean_kernel(
 #ifdef LFG_LEAN_DIAG_NO_RANKS            // (timing experiment, wrong vectors possible: no pass over the ranks)
             break;
 #endif
-            uint32_t off[3];
-            bool need[3], keep[3];
+            uint32_t off[kLeanAhead];
+            bool need[kLeanAhead], keep[kLeanAhead];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
+            for (int a = 0; a < kLeanAhead; ++a) {
                 const int r = r0 + 64 * a + lane, rc = min(r, kCand - 1);
                 const uint32_t dyi = ((uint32_t)rc * 1986u) >> 16, dxi = (uint32_t)rc - 33u * dyi;     // rc / 33, rc % 33 for rc < 1089
                 off[a] = dxi * (uint32_t)kWinH + dyi;
@@ -368,20 +382,29 @@ __global__ __launch_bounds__(kPNT, 3) void motion_lean_kernel(
                 need[a] = r < bound && ((sVisited[rc >> 5] >> (rc & 31)) & 1u) == 0u;
             }
             latticeKeep(off, keep);
+            unsigned long long anyM = 0ull;
 #pragma unroll
-            for (int a = 0; a < 3; ++a) m[a] = __ballot(need[a] && keep[a]);
-            r0 += 192;
-            if ((m[0] | m[1] | m[2]) == 0ull) continue;
+            for (int a = 0; a < kLeanAhead; ++a) { m[a] = __ballot(need[a] && keep[a]); anyM |= m[a]; }
+            r0 += 64 * kLeanAhead;
+            if (anyM == 0ull) continue;
         }
-        // the survivors, one after the other
-        while ((m[0] | m[1] | m[2]) != 0ull) {
-            const int a = m[0] ? 0 : m[1] ? 1 : 2;
-            const unsigned long long ma = a == 0 ? m[0] : a == 1 ? m[1] : m[2];
+        // the survivors, one after the other (slot by slot; the slot's index is wave-uniform, the selects are scalar)
+        for (;;) {
+            int a = -1;
+#pragma unroll
+            for (int k = kLeanAhead - 1; k >= 0; --k) a = m[k] != 0ull ? k : a;
+            if (a < 0) break;
+            unsigned long long ma = 0ull;
+#pragma unroll
+            for (int k = 0; k < kLeanAhead; ++k) ma = a == k ? m[k] : ma;
             const int b = __builtin_ctzll(ma);
-            if (a == 0) m[0] &= m[0] - 1ull; else if (a == 1) m[1] &= m[1] - 1ull; else m[2] &= m[2] - 1ull;
-            const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)ordA[0], b), o1 = (uint32_t)__builtin_amdgcn_readlane((int)ordA[1], b),
-                           o2 = (uint32_t)__builtin_amdgcn_readlane((int)ordA[2], b);
-            const uint32_t ord = a == 0 ? o0 : a == 1 ? o1 : o2;
+            uint32_t ord = 0u;
+#pragma unroll
+            for (int k = 0; k < kLeanAhead; ++k) {
+                const uint32_t ok = (uint32_t)__builtin_amdgcn_readlane((int)ordA[k], b);
+                ord = a == k ? ok : ord;
+                m[k] = a == k ? (m[k] & (m[k] - 1ull)) : m[k];
+            }
             if ((ord & 0xFFFFu) < zeroBound) evaluate(ord);
         }
         refresh();

@@ -2,7 +2,7 @@
 # Runs on the MI355X box (gpurun): regenerates every file profiles/README.md lists into gpurun_out/profiles_new/.
 # usage: tools/collect_profiles.sh rNN
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/profiles_new
 rm -rf $OUT && mkdir -p $OUT
@@ -14,7 +14,8 @@ stats() {   # $1 = name, rest = bench args [env prefix via LFG_MOTION_MODE]
       > $OUT/${TAG}_${name}_bench_under_rocprof.json 2> /tmp/prof_$name.err
   cp $(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${name}_kernel_stats.csv
 }
-N=10
+N=30
+export LFG_STAGE_LANES=3      # the counter passes run the step as the headline does: three frames in flight (the lean kernel runs only there)
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 $R/tools/run_stage.py pipeline $N > /dev/null 2>&1
@@ -24,10 +25,17 @@ rm -rf /tmp/pmc_sq
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT \
     --output-format csv -d /tmp/pmc_sq -- python3 $R/tools/run_stage.py pipeline $N > /dev/null 2>&1
 python3 $R/tools/pmc_per_step.py $N /tmp/pmc_sq > $OUT/${TAG}_sq_counters.txt
+unset LFG_STAGE_LANES
 cp $OUT/${TAG}_hbm_traffic_pmc.txt $OUT/${TAG}_sq_counters.txt $R/profiles/    # (this box's copy of the tree: the bench lines below quote the tables of the library they ran)
 stats pipeline --steps 300 --warmup 6                      # the default command: three frames in flight (kernels of neighbouring steps overlap)
 stats pipeline_one_lane --steps 200 --warmup 5 --in-flight 1   # one frame at a time: the durations bench.py's stages / dominant_stage quote
 stats scale --workload scale --steps 2000 --warmup 50
+# the interpolate stage alone on content where it samples (static: zero vectors, 116 MB moved) and on the pan (both samples rejected: 49.8 MB)
+for c in static translated; do
+  rm -rf /tmp/prof_interp_$c
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_interp_$c -- python3 $R/tools/run_stage.py interpolate 400 $c > /dev/null 2>&1
+  cp $(find /tmp/prof_interp_$c -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_interpolate_${c}_kernel_stats.csv
+done
 LFG_MOTION_MODE=1 stats pipeline_exact_only --steps 5 --warmup 1
 stats config5_one_lane --input 4k --factors 0.25,0.5,0.75 --in-flight 1 --steps 40 --warmup 4     # BASELINE config 5 on one GPU: 4K -> 8K, three generated frames per pair
 stats config5 --input 4k --factors 0.25,0.5,0.75 --steps 60 --warmup 6

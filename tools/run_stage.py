@@ -16,6 +16,9 @@ content = sys.argv[3] if len(sys.argv) > 3 else "translated"
 w, h = (int(v) for v in os.environ.get("LFG_STAGE_INPUT", "1920x1080").split("x"))
 W, H = 2 * w, 2 * h
 ctx = capi.Context(0)
+lanes = int(os.environ.get("LFG_STAGE_LANES", "1"))       # frames in flight (lanes of the C-ABI): the pipeline stage only
+if lanes > 1:
+    ctx.lanes(lanes)
 import importlib.util  # noqa: E402
 _spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
 _bench = importlib.util.module_from_spec(_spec)
@@ -28,12 +31,25 @@ ctx.scale(p_in, P)
 ctx.scale(c_in, C)
 ctx.motion(P, C, M) if stage in ("interpolate",) else None
 ctx.sync()
-for _ in range(reps):
-    if stage in ("scale", "pipeline"):
-        ctx.scale(c_in, C)
-    if stage in ("motion", "pipeline"):
-        ctx.motion(P, C, M)
-    if stage in ("interpolate", "pipeline"):
-        ctx.interpolate(P, C, M, O, 0.5)
+if lanes > 1 and stage == "pipeline":
+    # step k on lane k % lanes with its own buffers, as bench.py runs them (the previous step's upscale is waited for)
+    bufs = [(C, M, O)] + [(ctx.create_frame(W, H), ctx.create_frame(W, H, capi.FORMAT_MV_S8X2), ctx.create_frame(W, H)) for _ in range(lanes - 1)]
+    for k in range(reps):
+        ctx.lane_select(k % lanes)
+        ctx.lane_wait((k - 1) % lanes)
+        c4, m4, o4 = bufs[k % lanes]
+        ctx.scale(c_in, c4)
+        ctx.lane_mark()
+        ctx.motion(P, c4, m4)
+        ctx.interpolate(P, c4, m4, o4, 0.5)
+    ctx.lane_select(0)
+else:
+    for _ in range(reps):
+        if stage in ("scale", "pipeline"):
+            ctx.scale(c_in, C)
+        if stage in ("motion", "pipeline"):
+            ctx.motion(P, C, M)
+        if stage in ("interpolate", "pipeline"):
+            ctx.interpolate(P, C, M, O, 0.5)
 ctx.sync()
 print("done", stage, reps)
