@@ -202,6 +202,11 @@ int  lfg_motion_last_stats(lfg_context *ctx, uint32_t *out_tiles, uint32_t *out_
  * kernel, and how many the frame has; every open segment is listed exactly once (synchronises; reporting and tests only).
  * No reference counterpart: motion.comp (shaders/motion.comp:27-52) has one pass and no work lists. */
 int  lfg_motion_open_segments(lfg_context *ctx, uint32_t *out_open, uint32_t *out_segments);
+/* With frames in flight (lfg_lanes >= 2) a call whose content suits it sends its whole interior tiles through a lean kernel
+ * before the general one (same vectors; the choice goes by the lane's previous call).  After an lfg_motion: whether the selected
+ * lane's last call did (1/0), how many tiles are listed for that kernel at this frame size, and in how many it left work to the
+ * general kernel (synchronises; reporting and tests only).  No reference counterpart (shaders/motion.comp:27-52 is one pass). */
+int  lfg_motion_lean_stats(lfg_context *ctx, int *out_used, uint32_t *out_tiles, uint32_t *out_tiles_left);
 /* Bytes of device memory the prefiltered lfg_motion keeps for frames of this size (allocated on the first such call, kept
  * until the size changes or the context goes; one per lane).  No reference counterpart -- the reference's motion pass keeps
  * nothing between its two images (src/frame_manager.cpp:262-300); a host budgets lanes with it.  Needs no GPU work.

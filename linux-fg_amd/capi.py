@@ -76,6 +76,7 @@ SIGNATURES = {
     "lfg_set_motion_mode": (_i, [_vp, _i]),
     "lfg_motion_last_stats": (_i, [_vp, ctypes.POINTER(_u32), ctypes.POINTER(_u32), ctypes.POINTER(ctypes.c_double)]),
     "lfg_motion_open_segments": (_i, [_vp, ctypes.POINTER(_u32), ctypes.POINTER(_u32)]),
+    "lfg_motion_lean_stats": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_u32), ctypes.POINTER(_u32)]),
     "lfg_motion_workspace_size": (_i, [_vp, _u32, _u32, ctypes.POINTER(ctypes.c_uint64)]),
     "lfg_motion_plan": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "lfg_set_semantics": (_i, [_vp, _i]),
@@ -280,6 +281,12 @@ class Context:
         a, b = ctypes.c_uint32(), ctypes.c_uint32()
         self._check(self.lib.lfg_motion_open_segments(self.h, ctypes.byref(a), ctypes.byref(b)), "lfg_motion_open_segments")
         return a.value, b.value
+
+    def motion_lean_stats(self):
+        """(the selected lane's last lfg_motion went through the lean kernel, tiles listed for it, tiles in which it left work)."""
+        u, t, l = ctypes.c_int(), ctypes.c_uint32(), ctypes.c_uint32()
+        self._check(self.lib.lfg_motion_lean_stats(self.h, ctypes.byref(u), ctypes.byref(t), ctypes.byref(l)), "lfg_motion_lean_stats")
+        return bool(u.value), t.value, l.value
 
     def motion_workspace_size(self, width: int, height: int) -> int:
         """Bytes the prefiltered motion path keeps for frames of this size (per lane)."""

@@ -823,6 +823,21 @@ LFG_EXPORT int lfg_motion_open_segments(lfg_context *ctx, uint32_t *out_open, ui
     return LFG_OK;
 }
 
+// Reporting only: did the selected lane's last lfg_motion go through the lean kernel (csrc/motion_lean.hip), how many whole
+// interior tiles are listed for it at this frame size, and in how many of them it left a segment to the persistent kernel.
+LFG_EXPORT int lfg_motion_lean_stats(lfg_context *ctx, int *out_used, uint32_t *out_tiles, uint32_t *out_tiles_left) {
+    if (!ctx) return LFG_ERR_INVALID;
+    if (!out_used || !out_tiles || !out_tiles_left) return fail(ctx, LFG_ERR_INVALID, "lfg_motion_lean_stats: NULL argument");
+    if (!ctx->motion_ws || ctx->motion_ws_w == 0) return fail(ctx, LFG_ERR_INVALID, "lfg_motion_lean_stats: the prefiltered path has not run");
+    LFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint32_t left = 0;
+    LFG_HIP(ctx, hipMemcpy(&left, ctx->motion_ws + ctx->motion_ws_layout.ctrl + 5 * sizeof(uint32_t), sizeof(uint32_t), hipMemcpyDeviceToHost));
+    *out_used = ctx->motion_ws_layout.lastLean;
+    *out_tiles = (uint32_t)ctx->motion_ws_layout.leanCount;
+    *out_tiles_left = ctx->motion_ws_layout.lastLean ? left : 0u;
+    return LFG_OK;
+}
+
 LFG_EXPORT int lfg_motion_last_stats(lfg_context *ctx, uint32_t *out_tiles, uint32_t *out_fallback_tiles,
                                      double *out_mean_recorded) {
     if (!ctx) return LFG_ERR_INVALID;

@@ -220,7 +220,7 @@ bool lean_tile_ok(int tile, int tilesX, int W, int H);
 bool lean_frames_ok(const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv);
 hipError_t launch_motion_lean(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv,
                               const uint32_t *order32, const uint32_t *leanTiles, int nTiles, int tilesX, uint32_t *segDone,
-                              uint32_t *hardTiles, uint32_t *hardCount, uint32_t *stats);
+                              uint32_t *hardTiles, uint32_t *hardCount, uint32_t *stats, bool whateverTheVerdict);
 hipError_t launch_motion_generic(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                  const lfg_frame &mv, int block_size, int radius, bool intended);
 hipError_t launch_interpolate(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,

@@ -3174,10 +3174,7 @@ __global__ __launch_bounds__(kHints) void motion_order_kernel(
     // half the sum of its four absolute differences): such a segment would search in full.  Handing segments over
     // (motion_prefilter_kernel) pays when they are the exception; with a quarter of the samples unmatched it is off.
     const uint32_t unmatched = (uint32_t)__popcll(__ballot((hint >> 11) >= 1020u));
-    // (close: a match within the lean kernel's reach; but not where the match is EXACT everywhere -- stills, a pan of frames that were
-    //  not resampled: there every wave of the persistent kernel ends its search after three or four passes over the ranks and its
-    //  units are as short as the lean kernel's, 6,900 against 6,130 frames/s on stills.  Under the benchmark's pan 238 of the 256
-    //  sample blocks match exactly and 58 % of the interior waves do not: a rounding of the upscaler here and there.)
+    // (close: a match within the lean kernel's reach; the count of EXACT matches rides along in the upper half, for LFG_DEBUG)
     const uint32_t close = (uint32_t)__popcll(__ballot((float)(hint >> 11) < 2.0f * kOnePointOnly)) | ((uint32_t)__popcll(__ballot((hint >> 11) == 0u)) << 16);
     if (lane == 0) { sWaveSum[wv] = unmatched; sWaveClose[wv] = close; }
     if (mine != zero) atomicMin(&sOwner[mine], (uint32_t)tid);
@@ -3195,12 +3192,13 @@ __global__ __launch_bounds__(kHints) void motion_order_kernel(
         order32[kCand] = unmatchedAll * 4u <= (uint32_t)kHints ? 1u : 0u;
         // ... and for the lean kernel (motion_lean.hip), which keeps a segment only while its largest threshold stays below
         // kOnePointOnly: a block whose best SAD is 2 x that or more cannot cost less (a distance is at least half its SAD).  The
-        // kernel and the plan that goes with it pay where nearly EVERY sample matches that closely -- a pan: +6 % -- and cost 2 % where
-        // a twentieth of them do not (the occluded and moving-object frames: 242 and 250 of 256), so that is the bar: 63 in 64.
+        // kernel and the plan that goes with it pay where nearly EVERY sample matches that closely -- a pan +9 %, stills +21 % -- are
+        // neutral where a few percent of them do not (moving objects, 250 of 256: +0.7 %; occlusions, 242: -1.3 %) and cost 8 % on
+        // frames with sensor noise (none close): the bar is 63 in 64.
         uint32_t closeAll = 0u;
         for (int w = 0; w < kWaves; ++w) closeAll += sWaveClose[w];
         // (bit 0: the verdict; above it the two counts, for LFG_DEBUG)
-        order32[kCand + 2] = (((closeAll & 0xFFFFu) * 64u >= 63u * (uint32_t)kHints && (closeAll >> 16) * 64u < 63u * (uint32_t)kHints) ? 1u : 0u) | ((closeAll & 0xFFFFu) << 1) | ((closeAll >> 16) << 12);
+        order32[kCand + 2] = (((closeAll & 0xFFFFu) * 64u >= 63u * (uint32_t)kHints) ? 1u : 0u) | ((closeAll & 0xFFFFu) << 1) | ((closeAll >> 16) << 12);
         order32[0] = entryOfScan[top];
         if (top != zero) order32[1] = entryOfScan[zero];
         sRunning = top != zero ? 2u : 1u;
@@ -3295,7 +3293,8 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
             // (beside the persistent kernel on a stream of its own, with that kernel's grid cut to 448 .. 320 workgroups to leave it room:
             //  measured for a context that runs one frame at a time, 2,160 - 2,430 frames/s against 2,610 without the kernel: not done)
             e = launch_motion_lean(s, prev, curr, mv, order, reinterpret_cast<const uint32_t *>(workspace + l.leanTiles), l.leanCount, sp.tilesX, segDone,
-                                   reinterpret_cast<uint32_t *>(workspace + l.hardTiles), ctrl + 5, ctrl + 6);      // (ctrl[5]: tiles it left; ctrl[6], [7]: segments it settled, segments it left -- counted in diagnostic builds)
+                                   reinterpret_cast<uint32_t *>(workspace + l.hardTiles), ctrl + 5, ctrl + 6,
+                                   getenv("LFG_LEAN_FORCE") != nullptr && atoi(getenv("LFG_LEAN_FORCE")) == 1);      // (ctrl[5]: tiles it left; ctrl[6], [7]: segments it settled, segments it left -- counted in diagnostic builds)
             if (e != hipSuccess) return e;
         }
     } else {

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kPNT, 3) void motion_lean_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch, int W, int H,
     const uint32_t *__restrict__ order32, const uint32_t *__restrict__ leanTiles, int tilesX,
     int8_t *__restrict__ mv, int mvPitch, uint32_t *__restrict__ segDone, uint32_t *__restrict__ hardTiles, uint32_t *__restrict__ hardCount,
-    uint32_t *__restrict__ leanStats) {
+    uint32_t *__restrict__ leanStats, int whateverTheVerdict) {
     __shared__ uint32_t sWin[kWinH * kWinW];                           // 38.2 KB packed RGBA8 search window, column-major
     __shared__ __attribute__((aligned(8))) float sSlab[kPNT / 64][kLeanSlab];
     __shared__ uint32_t sVisited[(kCand + 31) / 32];                   // the ranks the hints hold (they are not looked at twice)
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(kPNT, 3) void motion_lean_kernel(
     // [kCand + 2]: most of the call's sample blocks have a near-exact match (motion_order_kernel) -- otherwise this is not the
     // content the kernel is for, and every workgroup leaves before it has staged anything
     // (a tile in which anything is left goes onto the list the generic kernel draws from behind its own table: here, all of them)
-    if ((order32[kCand + 2] & 1u) == 0u) {
+    if ((order32[kCand + 2] & 1u) == 0u && !whateverTheVerdict) {
         if (tid == 0) hardTiles[atomicAdd(hardCount, 1u)] = (uint32_t)tile;
         return;
     }
@@ -469,11 +469,11 @@ bool lean_frames_ok(const lfg_frame &prev, const lfg_frame &curr, const lfg_fram
 
 hipError_t launch_motion_lean(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv,
                               const uint32_t *order32, const uint32_t *leanTiles, int nTiles, int tilesX, uint32_t *segDone,
-                              uint32_t *hardTiles, uint32_t *hardCount, uint32_t *stats) {
+                              uint32_t *hardTiles, uint32_t *hardCount, uint32_t *stats, bool whateverTheVerdict) {
     if (nTiles <= 0) return hipSuccess;
     hipLaunchKernelGGL(motion_lean_kernel<0>, dim3((unsigned)nTiles), dim3(kPNT), 0, s,
                        (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch, (int)curr.width, (int)curr.height,
-                       order32, leanTiles, tilesX, (int8_t *)mv.data, (int)mv.pitch, segDone, hardTiles, hardCount, stats);
+                       order32, leanTiles, tilesX, (int8_t *)mv.data, (int)mv.pitch, segDone, hardTiles, hardCount, stats, whateverTheVerdict ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -1431,6 +1431,109 @@ def test_lanes_keep_frames_in_flight_apart():
         ctx.close()
 
 
+# ------------------------------------------------------------------ the lean kernel (csrc/motion_lean.hip)
+
+@pytest.fixture()
+def lean_ctx(monkeypatch):
+    """A context with frames in flight whose every call goes through the lean kernel (the host's choice per call -- the order
+    kernel's verdict on the lane's previous call -- overridden by LFG_LEAN_FORCE=1), and a second plan beside the first."""
+    from linux_fg_amd import capi
+    monkeypatch.setenv("LFG_LEAN_FORCE", "1")
+    c = capi.Context(0)
+    c.lanes(2)
+    yield c
+    c.close()
+
+
+def _lean_cases():
+    W, H = 1920, 1080
+    base = synth.make_prev(W, H, seed=synth.BASE_SEED + 404)
+    pan = synth.translate(base, (5, -3), synth.BASE_SEED + 404)
+    yield "pan", base, pan
+    yield "stills", base, base.copy()
+    rough = pan.copy()                       # a pan whose match is only nearly exact in a band: small non-zero thresholds, SAD and distance tests
+    rough[200:420] = np.clip(rough[200:420].astype(np.int16) + (synth.noise_bytes(W, 220, 99) % 3).astype(np.int16) - 1, 0, 255).astype(np.uint8)
+    yield "pan with a band one level off", base, rough
+    yield "everything the prefilter treats differently", *_full_hd_mixture()
+    flat = np.full((H, W, 4), 90, np.uint8)  # exact ties everywhere: every pixel ambiguous or zero-cost, the kernel must leave what it cannot decide
+    yield "flat", flat, flat.copy()
+    per = np.tile(synth.make_prev(16, 16, seed=5), (H // 16 + 1, W // 16 + 1, 1))[:H, :W].copy()   # periodic: many exact zero-cost candidates
+    yield "periodic", per, np.roll(per, (3, 5), (0, 1))
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_lean_kernel_agrees_with_the_literal_kernel(lean_ctx, case):
+    """Whole interior tiles go through csrc/motion_lean.hip first when frames are in flight: it settles what is easy and LEAVES
+    the rest to the persistent kernel, so the vectors must be the literal kernel's whatever it decides -- on content it is made
+    for (a pan, stills), on content it must give up on segment by segment (noise bands, occlusions, fades: the mixture), and on
+    exact ties (flat and periodic frames: zero-cost candidates decided by rank, or left)."""
+    from linux_fg_amd import capi
+    name, prev, curr = list(_lean_cases())[case]
+    for lane in (0, 1):                      # both lanes' workspaces and plans
+        lean_ctx.lane_select(lane)
+        a, _ = run_motion_mode(lean_ctx, prev, curr, capi.MOTION_PREFILTERED)
+        used, listed, left = lean_ctx.motion_lean_stats()
+        assert used and listed > 300, (used, listed)          # (the kernel did run: 35 x 17 tiles of which the rim's are not its)
+        if name in ("pan", "stills"):
+            assert left == 0, f"{name}: the lean kernel left work in {left} of {listed} tiles"
+        if name == "everything the prefilter treats differently":
+            assert 0 < left < listed, (left, listed)
+        b, _ = run_motion_mode(lean_ctx, prev, curr, capi.MOTION_EXACT_ONLY)
+        assert (a == b).all(), f"{name}, lane {lane}: {(a != b).any(-1).sum()} pixels differ"
+    lean_ctx.lane_select(0)
+
+
+def test_lean_kernel_at_4k_and_after_a_change_of_content(lean_ctx, oracle):
+    """BASELINE config 3's size: the benchmark's own frames (a 1080p pan, both frames upscaled on the device) and the 4K mixture
+    one after the other on one lane -- the second plan's lists and the tiles the kernel left are reused from call to call --
+    against the literal kernel everywhere and against the ORACLE on regions of the pan."""
+    from linux_fg_amd import capi
+    w, h = 1920, 1080
+    pin = synth.make_prev(w, h, seed=synth.BASE_SEED)
+    cin = synth.translate(pin, (3, -2), synth.BASE_SEED)
+    p, c = lean_ctx.frame_from(pin), lean_ctx.frame_from(cin)
+    P, C = lean_ctx.create_frame(2 * w, 2 * h), lean_ctx.create_frame(2 * w, 2 * h)
+    lean_ctx.scale(p, P); lean_ctx.scale(c, C)
+    Pn, Cn = lean_ctx.download(P), lean_ctx.download(C)
+    for f in (p, c, P, C):
+        lean_ctx.destroy_frame(f)
+    mix_prev, mix_curr = _uhd_mixture()
+    for name, prev, curr in (("pan", Pn, Cn), ("mixture", mix_prev, mix_curr), ("pan again", Pn, Cn)):
+        a, _ = run_motion_mode(lean_ctx, prev, curr, capi.MOTION_PREFILTERED)
+        b, _ = run_motion_mode(lean_ctx, prev, curr, capi.MOTION_EXACT_ONLY)
+        assert (a == b).all(), f"{name}: {(a != b).any(-1).sum()} pixels differ"
+        if name == "pan":
+            inner = a[64:-64, 64:-64]
+            assert (inner[..., 0] == -6).all() and (inner[..., 1] == 4).all()
+            for roi in [(1000, 1000, 1100, 1024), (60, 60, 150, 90), (3700, 2080, 3800, 2104)]:
+                x0, y0, x1, y1 = roi
+                want = as_int(oracle.motion(Pn, Cn, roi=roi))[y0:y1, x0:x1]
+                assert (a[y0:y1, x0:x1] == want).all(), roi
+
+
+def test_lean_verdict_follows_the_content():
+    """Without the override the host goes by the order kernel's verdict on the lane's previous call: results are the literal
+    kernel's on a stream that changes from a pan to noise and back, whichever calls went through the lean kernel."""
+    from linux_fg_amd import capi
+    W, H = 1920, 1080
+    base = synth.make_prev(W, H, seed=synth.BASE_SEED + 505)
+    pan = synth.translate(base, (-4, 6), synth.BASE_SEED + 505)
+    noise = synth.noise_bytes(W, H, 31337)
+    c = capi.Context(0)
+    try:
+        c.lanes(2)
+        want = {}
+        for name, curr in (("pan", pan), ("noise", noise)):
+            want[name], _ = run_motion_mode(c, base, curr, capi.MOTION_EXACT_ONLY)
+        for k, name in enumerate(["pan", "pan", "pan", "noise", "noise", "pan", "pan"]):
+            c.lane_select(k % 2)
+            got = run_motion(c, base, pan if name == "pan" else noise)
+            assert (got == want[name]).all(), (k, name)
+        c.lane_select(0)
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("seed", [21, 22, 23])
 def test_band_restricted_lattice_tests_agree_with_the_literal_kernel(ctx, seed):
     """Segments in which most pixels own a zero-cost candidate and a few columns only nearly match (costs of a few hundred:
