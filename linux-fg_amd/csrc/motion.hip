@@ -557,6 +557,7 @@ __device__ __forceinline__ void prefilter_unit(
     const unsigned long long stampStart = __builtin_amdgcn_s_memrealtime();
     unsigned stampEvals = 0u, stampBatches = 0u, stampBox = 0u, stampBand = 0u, stampPass = 0u, stampNarrow = 0u, stampThr = 0u, stampThrEnd = 0u, stampFour = 0u;
     unsigned long long stampStaged = 0ull, stampFirst = 0ull, stampLattice = 0ull, stampAhead = 0ull, stampAheadFirst = 0ull, stampPass7 = 0ull;
+    unsigned long long phaseLattice = 0ull, phaseSixteen = 0ull, phaseEval = 0ull;     // (LFG_STAMP_PHASES: time in the batch tests, the sixteen-point test, full evaluations)
 #endif
     // Work units (PrefilterPlan).  A tile is 4 segments of 16 rows, and a workgroup is either
     //   * a whole tile: wave = segment, the entire candidate order;
@@ -1639,6 +1640,257 @@ __device__ __forceinline__ void prefilter_unit(
             }
             return true;
         };
+#ifndef LFG_ROW_BAND
+#define LFG_ROW_BAND 1
+#endif
+        // ---- Row band.  The other shape the unmatched pixels of a segment take: a few ROWS over its whole width -- the strip
+        // a pan exposes at the top or bottom of the frame (four rows for the benchmark's motion and the three above them, whose
+        // blocks reach into it: 134 units of 230 us each, a fifth of a call's workgroup time), the horizontal edge of a moving
+        // object or of an occlusion.  Too wide for the narrow search, so every candidate used to cost a full evaluation of all
+        // 16 x 56 pixels.  If the pixels still above LFG_NARROW_THR after the hints lie within EIGHT rows, the eight rows
+        // rB .. rB + 7 leave the wide machinery as a narrow band's columns do (thresholds parked in LDS, -inf in the registers:
+        // the lattice tests work again for the other eight rows) and are searched after the wide batches, TWO candidates per pass:
+        //   * lane = position column as in the wide code, but 15 position rows instead of 23, and the two candidates side by
+        //     side in the halves of packed registers: one packed subtract / add per position, ONE sliding tree (34 packed adds)
+        //     for both, and the eight rows of column sums leave as eight (candidate A, candidate B) pairs per lane;
+        //   * every wide lane (r8, q) owns exactly one row of the band -- r8 if r8 >= rB, else r8 + 8 -- so the read side keeps the
+        //     wide mapping: thirteen 8-byte reads, ONE packed tree of row sums for both candidates, seven pixels per lane, each
+        //     with its threshold, count and list as in the wide code.
+        // Same distances, same trees, same S~ to the bit as a full evaluation; two thirds of its instructions per candidate.
+        bool rowBand = false;
+        int rB = 0;                                                    // the band: pixel rows rB .. rB + 7 of the segment
+        auto enterRowBand = [&]() {
+            int lo = 99, hi = -1;
+#pragma unroll
+            for (int i = 0; i < kRun; ++i) {
+                const float fx = thr2[i].x, fy = thr2[i].y;            // (-inf: outside the image; +inf: nothing yet)
+                if (fx >= LFG_NARROW_THR) { lo = min(lo, r8); hi = max(hi, r8); }
+                if (fy >= LFG_NARROW_THR) { lo = min(lo, r8 + 8); hi = max(hi, r8 + 8); }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_xor(lo, off)); hi = max(hi, __shfl_xor(hi, off)); }
+            lo = __builtin_amdgcn_readfirstlane(lo); hi = __builtin_amdgcn_readfirstlane(hi);
+            if (hi < lo || hi - lo >= 8) return;
+            rB = min(lo, 8);
+            const bool upper = r8 < rB;                                // this lane's row of the band: r8 + 8 (else r8)
+            wave_lds_sync();
+#pragma unroll
+            for (int i = 0; i < kRun; ++i) {
+                const float fx = thr2[i].x, fy = thr2[i].y;
+                nThr[i * 64 + lane] = __builtin_bit_cast(uint32_t, upper ? fy : fx);
+                thr2[i].x = upper ? fx : -__builtin_inff();
+                thr2[i].y = upper ? -__builtin_inff() : fy;
+            }
+            wave_lds_sync();
+            rowBand = true;
+#ifdef LFG_MOTION_STAMPS
+            stampNarrow = 7u;
+#endif
+        };
+        static_assert(kRun * 64 <= 2 * kSeg * kNarrowMax, "a row band's thresholds fit a wave's narrow-search words");
+        auto rowBandPhase = [&](int iBegin) -> bool {
+            constexpr int kBandD = kB + 7;                             // 15 position rows serve eight pixel rows
+            const int iEnd = nEntries;
+            uint32_t lB;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(lB));
+            const int r8B = (int)(lB & 7u), qB = (int)(lB >> 3);
+            const bool upper = r8B < rB;
+            const int rowInSeg = upper ? r8B + 8 : r8B;                // this lane's pixel row of the segment
+            // read side: the lane's seven pixels of that row
+            float thrB[kRun];
+            uint32_t cntB[kRun], platB;
+#pragma unroll
+            for (int i = 0; i < kRun; ++i) {
+                thrB[i] = __builtin_bit_cast(float, nThr[i * 64 + (int)lB]);
+                cntB[i] = ((upper ? cnt2[1][i >> 1] : cnt2[0][i >> 1]) >> (16 * (i & 1))) & 0xFFFFu;
+            }
+            platB = (plateauSeen >> (upper ? kRun : 0)) & ((1u << kRun) - 1u);
+            const uint32_t bLaneOff = (uint32_t)rowInSeg * (listK * rowStride) + (uint32_t)(kRun * qB);
+            const lds_ro_f32x2_ptr bSlabR = (lds_ro_f32x2_ptr)(sSlab[wave]) + ((r8B - rB) & 7) * (kSlabP / 2) + kRun * qB;
+            f32x2 *const bSlabW = reinterpret_cast<f32x2 *>(sSlab[wave]) + (int)lB;
+            // compute side: position column `lane`, rows rB .. rB + 14 of the segment's 23
+            const int pcol = min((int)lB, kPTW + kB - 2);              // (lane 63 repeats lane 62: sums nobody reads)
+            const lds_ro_u32_ptr bWin = (lds_ro_u32_ptr)(sWin + pcol * kWinH + kSeg * seg + rB);
+            uint32_t cB[kBandD], ccB[kBandD], validB = 0u;
+            {
+                const int gx = bx0 + pcol;
+                const bool okx = gx >= 0 && gx < W;
+                const uint8_t *const column = curr + (size_t)clampi(gx, 0, W - 1) * 4u;
+                int pitchB = currPitch;                                // (through an empty asm: see narrowPhase)
+                asm volatile("" : "+s"(pitchB));
+#pragma unroll
+                for (int j = 0; j < kBandD; ++j) {
+                    const int gy = by0 + kSeg * seg + rB + j;
+                    const bool ok = okx && gy >= 0 && gy < H;
+                    const uint32_t t = *reinterpret_cast<const uint32_t *>(column + (size_t)clampi(gy, 0, H - 1) * (size_t)pitchB);
+                    cB[j] = ok ? t : 0u;
+                    validB |= (ok ? 1u : 0u) << j;
+                }
+#pragma unroll
+                for (int j = 0; j < kBandD; ++j) ccB[j] = __builtin_amdgcn_udot4(cB[j], cB[j], 0x4B000000u, false);
+            }
+            const int allValid = __builtin_amdgcn_readfirstlane((int)((__ballot(validB != (1u << kBandD) - 1u) & 0x7FFFFFFFFFFFFFFFull) == 0ull));
+            const int segY0 = ty0 + kSeg * seg;
+            // the eight column sums of two candidates, (A, B) per row: columnSums' arithmetic, the candidates in the register halves
+            auto bandSums = [&](const uint32_t (&pa)[kBandD], const uint32_t (&pb)[kBandD], f32x2 (&V)[8]) {
+                const f32x2 kBias = {8388608.0f, 8388608.0f};
+                f32x2 D[kBandD];
+#pragma unroll
+                for (int j = 0; j < kBandD; ++j) {
+                    const f32x2 F1 = {__builtin_bit_cast(float, __builtin_amdgcn_udot4(pa[j], pa[j], ccB[j], false)),
+                                      __builtin_bit_cast(float, __builtin_amdgcn_udot4(pb[j], pb[j], ccB[j], false))};
+                    const f32x2 F2 = {__builtin_bit_cast(float, __builtin_amdgcn_udot4(cB[j], pa[j], 0x4B800000u, false)),
+                                      __builtin_bit_cast(float, __builtin_amdgcn_udot4(cB[j], pb[j], 0x4B800000u, false))};
+                    const f32x2 N = (F1 - F2) + kBias;
+                    D[j] = f32x2{__builtin_amdgcn_sqrtf(N.x), __builtin_amdgcn_sqrtf(N.y)};
+                }
+                if (!allValid) {                  // position outside the image: skipped by the shader, adds 0 here
+                    asm volatile("; positions outside the image (row band)");
+#pragma unroll
+                    for (int j = 0; j < kBandD; ++j) {
+                        const bool in = ((validB >> j) & 1u) != 0u;
+                        D[j].x = in ? D[j].x : 0.0f; D[j].y = in ? D[j].y : 0.0f;
+                    }
+                }
+                f32x2 B2[kBandD - 1], G4[kBandD - 3];
+#pragma unroll
+                for (int j = 0; j < kBandD - 1; ++j) B2[j] = D[j] + D[j + 1];
+#pragma unroll
+                for (int j = 0; j < kBandD - 3; ++j) G4[j] = B2[j] + B2[j + 2];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) V[j] = G4[j] + G4[j + 4];
+            };
+            // the rules of rowSumsAndTest for one candidate and the lane's seven pixels
+            // (Without a branch per pixel -- every lane doing the bookkeeping by selects, only the record's store predicated --
+            //  a bottom-strip unit of the benchmark's pan took 261 us instead of 235: each select waits for a lane mask that went
+            //  from the VALU through a scalar AND and back.)
+            auto testCandidate = [&](const float (&s)[kRun], uint32_t ord, uint32_t countIt) {
+                const uint32_t cand = ord & 0xFFFFu;
+                const int candDx = (int)((ord >> 16) / (uint32_t)kWinH) - kR, candDy = (int)((ord >> 16) % (uint32_t)kWinH) - kR;
+                const uint32_t zeroCap = 0x00800000u + cand;
+                const bool candMayLeave = windowLeavesPrev &&
+                    block_leaves_prev_any(tx0, min(tx0 + kPTW - 1, W - 1), segY0 + rB, min(segY0 + rB + 7, H - 1), candDx, candDy, W, H);
+                unsigned long long hit[kRun];
+#pragma unroll
+                for (int i = 0; i < kRun; ++i) hit[i] = __ballot(s[i] <= thrB[i]);
+#pragma unroll
+                for (int i = 0; i < kRun; ++i) {
+                    if (hit[i] != 0ull) {                              // wave-uniform
+                        asm volatile("; some lane records a candidate (row band)");
+                        const float sv = s[i];
+                        if (sv <= thrB[i]) {
+#ifdef LFG_DIAG_BAND_NO_RECORDS        // (timing experiment, wrong results: thresholds follow the minima, nothing is recorded)
+                            thrB[i] = __builtin_fminf(thrB[i], __builtin_fmaxf(sv * kRatio, __builtin_bit_cast(float, zeroCap)));
+#else
+                            const float cap = __builtin_fmaxf(sv * kRatio, __builtin_bit_cast(float, zeroCap));
+                            if (sv < thrB[i] * kRestart) cntB[i] = 0u;  // (`restart`: every earlier record is dead)
+                            thrB[i] = __builtin_fminf(thrB[i], cap);
+                            const uint32_t at = __umul24(min(cntB[i], listK - 1u), rowStride) + bLaneOff + (uint32_t)i;
+                            if (sv != 0.0f) waveList[at] = rec_make(sv, cand);
+                            uint32_t inc = (sv != 0.0f && countIt != 0u) ? 1u : 0u;
+                            if (candMayLeave) {
+                                uint32_t l;
+                                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(l));
+                                const int rl = (int)(l & 7u);
+                                const bool plateau = block_leaves_prev(tx0 + kRun * (int)(l >> 3) + i, segY0 + (rl < rB ? rl + 8 : rl), candDx, candDy, W, H);
+                                inc = (plateau && ((platB >> i) & 1u) != 0u) ? 0u : inc;
+                                platB |= (plateau && inc != 0u) ? (1u << i) : 0u;
+                            }
+                            cntB[i] += inc;
+#endif
+                        }
+                    }
+                }
+            };
+            uint32_t pa[kBandD], pb[kBandD];
+            bool pending = false;
+            int idx0 = iBegin, idxP = 0, started = 0;
+            uint32_t ordPA = 0u, ordPB = 0u;
+            // (the pass's two entries of the order are fetched a pass ahead, and a pass asks the slab for the previous pass's sums
+            //  BEFORE it asks the window for its own texels -- DS operations return in order: fetched where it is needed, each of
+            //  the three was a round trip of its own with nothing behind it to hide it)
+            auto orderAt = [&](int idx) { return ((lds_ro_u32_ptr)sOrder)[entryOf(min(idx, iEnd - 1))]; };
+            uint32_t ordNA = orderAt(idx0), ordNB = orderAt(idx0 + 1);
+            for (;;) {
+                const bool have = idx0 < iEnd && started < 64;
+                if (!have && !pending) {                               // (the pipeline has drained) every 64 entries: give up?
+                    if (idx0 >= iEnd) break;
+                    started = 0;
+                    bool over = false;
+#pragma unroll
+                    for (int i = 0; i < kRun; ++i) over = over || cntB[i] >= listK;     // (the last slot is a spare)
+                    if (__builtin_amdgcn_readfirstlane(__ballot(over) != 0ull)) sGiveUp = 1u;
+                    if (__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)&sGiveUp) != 0) return false;
+                    continue;
+                }
+                f32x2 X[kRunIn];
+                if (pending) {             // the slab holds the previous pass: eight rows of (A, B) column sums
+                    wave_lds_sync();
+#pragma unroll
+                    for (int i = 0; i < kRunIn; ++i) X[i] = bSlabR[i];
+                }
+                uint32_t ordA = 0u, ordB = 0u;
+                if (have) {
+                    ordA = (uint32_t)__builtin_amdgcn_readfirstlane((int)ordNA);
+                    ordB = (uint32_t)__builtin_amdgcn_readfirstlane((int)ordNB);
+                    const lds_ro_u32_ptr wa = bWin + (ordA >> 16), wb = bWin + (ordB >> 16);
+#pragma unroll
+                    for (int j = 0; j < kBandD; ++j) { pa[j] = wa[j]; pb[j] = wb[j]; }
+                    ordNA = orderAt(idx0 + 2); ordNB = orderAt(idx0 + 3);
+                }
+                if (pending) {
+                    f32x2 s2[kRun];
+                    runSums(X, s2);
+                    float top = -__builtin_inff();
+#pragma unroll
+                    for (int i = 0; i < kRun; ++i) {
+                        const f32x2 dm = f32x2{thrB[i], thrB[i]} - s2[i];
+                        top = __builtin_fmaxf(top, __builtin_fmaxf(dm.x, dm.y));
+                    }
+#ifdef LFG_DIAG_BAND_NO_TEST            // (timing experiment, wrong results: what the evaluation alone costs)
+#pragma unroll
+                    for (int i = 0; i < kRun; ++i) thrB[i] = __builtin_fminf(thrB[i], __builtin_fminf(s2[i].x, s2[i].y) * kRatio);
+                    if (false) {
+#else
+                    if (!__builtin_amdgcn_readfirstlane(__ballot(top >= 0.0f) == 0ull)) {
+#endif
+#pragma nounroll                   // (one copy of the test, not one per candidate)
+                        for (int k = 0; k < 2 && idxP + k < iEnd; ++k) {
+                            float s[kRun];
+#pragma unroll
+                            for (int i = 0; i < kRun; ++i) s[i] = k ? s2[i].y : s2[i].x;
+                            testCandidate(s, k ? ordPB : ordPA, (idxP + k) >= nHead ? 1u : 0u);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (have) {
+                    f32x2 V[8];
+                    bandSums(pa, pb, V);
+                    wave_lds_sync();
+#pragma unroll
+                    for (int a = 0; a < 8; ++a) bSlabW[a * (kSlabP / 2)] = V[a];
+                    wave_lds_sync();
+                    started += 2;
+                }
+                idxP = idx0; ordPA = ordA; ordPB = ordB; pending = have;
+                if (have) idx0 += 2;
+            }
+            // the band's final thresholds and counts: back into the wide layout (each lane's own row)
+#pragma unroll
+            for (int i = 0; i < kRun; ++i) {
+                const float fx = thr2[i].x, fy = thr2[i].y;
+                thr2[i].x = upper ? fx : thrB[i];
+                thr2[i].y = upper ? thrB[i] : fy;
+                const uint32_t sh = 16u * (uint32_t)(i & 1);
+                const uint32_t field = min(cntB[i], 0x7FFFu) << sh, keep = ~(0xFFFFu << sh);
+                const uint32_t w0 = cnt2[0][i >> 1], w1 = cnt2[1][i >> 1];
+                cnt2[0][i >> 1] = upper ? w0 : ((w0 & keep) | field);
+                cnt2[1][i >> 1] = upper ? ((w1 & keep) | field) : w1;
+            }
+            plateauSeen |= platB << (upper ? kRun : 0);
+            return true;
+        };
         // Batches: the top hint alone (under a pan its evaluation is all a wave ever evaluates: zero motion, next in the
         // order, then fails the cheap test or is skipped by rank instead of costing a second evaluation); then zero motion
         // and the other hints of this call (at least seven entries, so that units which run the first eight for their
@@ -1758,7 +2010,8 @@ __device__ __forceinline__ void prefilter_unit(
             }
             if (LFG_NARROW && decisionPoint && !narrow && i0 == hintsEnd && !(waveThr < LFG_NARROW_THR)) {
                 enterNarrow();
-                if (narrow) refreshZeroBound();    // the largest threshold of the pixels that stay wide
+                if (LFG_ROW_BAND && !narrow) enterRowBand();
+                if (narrow || rowBand) refreshZeroBound();    // the largest threshold of the pixels that stay wide
             }
             if (LFG_BAND && decisionPoint && i0 == hintsEnd && !(waveThr < kOnePointMax)) computeBand();
 #ifdef LFG_MOTION_STAMPS
@@ -1924,7 +2177,13 @@ __device__ __forceinline__ void prefilter_unit(
 #ifdef LFG_STAMP_LATTICE     // (experiment: o[5] carries the time spent in the lattice tests instead of the first batch's end)
                 const unsigned long long tl0 = __builtin_amdgcn_s_memrealtime();
 #endif
+#ifdef LFG_STAMP_PHASES
+                const unsigned long long tp0 = __builtin_amdgcn_s_memrealtime();
+#endif
                 m = latticeBatch(ordL & 0x7FFFFFFFu, need, byRank || count == 64);
+#ifdef LFG_STAMP_PHASES
+                phaseLattice += __builtin_amdgcn_s_memrealtime() - tp0;
+#endif
 #ifdef LFG_STAMP_LATTICE
                 stampLattice += __builtin_amdgcn_s_memrealtime() - tl0;
 #endif
@@ -1985,7 +2244,13 @@ __device__ __forceinline__ void prefilter_unit(
                     wave_lds_sync();
                     pendCount -= take;
                     m = __ballot((int)l < take && (ordL & 0xFFFFu) < zeroBound);
+#ifdef LFG_STAMP_PHASES
+                    const unsigned long long tp1 = __builtin_amdgcn_s_memrealtime();
+#endif
                     if (sixteenApplies() && __builtin_popcountll(m) > LFG_SIXTEEN_FROM) m = sixteenBatch(ordL & 0x7FFFFFFFu, m, take == 64);
+#ifdef LFG_STAMP_PHASES
+                    phaseSixteen += __builtin_amdgcn_s_memrealtime() - tp1;
+#endif
                     if (flushNow && firstFull) firstBatchSurvivors = __builtin_popcountll(m);
                     flushNow = false;
                 }
@@ -1993,6 +2258,9 @@ __device__ __forceinline__ void prefilter_unit(
                 stampEvals += (unsigned)__builtin_popcountll(m);
 #endif
                 if (m == 0ull) continue;
+#ifdef LFG_STAMP_PHASES
+                const unsigned long long tp2 = __builtin_amdgcn_s_memrealtime();
+#endif
                 // The survivors, software-pipelined: the window reads of one are in flight while the previous one is
                 // finished; a last pass drains the pipeline.
                 bool pending = false;
@@ -2047,6 +2315,9 @@ __device__ __forceinline__ void prefilter_unit(
                     }
                     ordP = ord; cntP = cntIt; pending = evaluate;
                 }
+#ifdef LFG_STAMP_PHASES
+                phaseEval += __builtin_amdgcn_s_memrealtime() - tp2;
+#endif
                 // lists full somewhere in the tile: stop early
                 if (__builtin_amdgcn_readfirstlane(__ballot(listsOverflowed()) != 0ull)) sGiveUp = 1u;
                 if (__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)&sGiveUp) != 0) return 1;
@@ -2067,7 +2338,8 @@ __device__ __forceinline__ void prefilter_unit(
             else { i0 += count; count = i0 == LFG_FIRST_BATCH ? hintsEnd - LFG_FIRST_BATCH : 64; }
         }
         if (narrow && !narrowPhase(hintsEnd)) return 1;
-        if (!narrow) settledAtZero = waveThr < 0.5f;                   // (every pixel of the wave owns a zero-cost candidate)
+        if (rowBand && !rowBandPhase(hintsEnd)) return 1;
+        if (!narrow && !rowBand) settledAtZero = waveThr < 0.5f;       // (every pixel of the wave owns a zero-cost candidate)
         return __builtin_amdgcn_readfirstlane(__ballot(listsOverflowed()) != 0ull) ? 1 : 0;
     };
     const int outcome = run();
@@ -2093,6 +2365,9 @@ __device__ __forceinline__ void prefilter_unit(
 #endif
 #if defined(LFG_STAMP_LATTICE3) || defined(LFG_STAMP_LATTICE4)
         o[7] = stampPass7;
+#endif
+#ifdef LFG_STAMP_PHASES
+        o[5] = (phaseLattice & 0xFFFFFull) | ((phaseSixteen & 0xFFFFFull) << 20) | ((phaseEval & 0xFFFFFull) << 40);
 #endif
     }
 #endif
@@ -3392,6 +3667,7 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
             {   // rim units by where they lie: mean duration, evaluations and batches per wave
                 const char *names[6] = {"top", "bottom, last segment", "bottom, other segments", "left", "right", "corner or other"};
                 double dur[6] = {0}, evs[6] = {0}, bts[6] = {0}, thrA[6] = {0}, thrB[6] = {0}; int nu[6] = {0}, nNarrow[6] = {0}, nWaves[6] = {0}, nZero[6] = {0}, nBand[6] = {0}; double wBand[6] = {0}, srchK[6] = {0}, fstK[6] = {0};
+                double hardDur[6] = {0}, hardEv[6] = {0}, hardBt[6] = {0}, hardPh[6][3] = {{0}};
                 int maxTx = 0, maxTy = 0;
                 for (int u = 0; u < n; ++u) { const unsigned long long *o = &h[(u * 4) * 8]; if (!o[1]) continue; maxTx = std::max(maxTx, (int)((o[6] >> 12) & 0xFF)); maxTy = std::max(maxTy, (int)((o[6] >> 20) & 0xFF)); }
                 for (int u = 0; u < n; ++u) {
@@ -3405,12 +3681,24 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
                     dur[k] += (double)(b - a) / 100.0; evs[k] += (double)evals / nw; bts[k] += (double)batches / nw; ++nu[k]; srchK[k] += se; fstK[k] += fs;
                     for (int w = 0; w < 4; ++w) { const unsigned long long *o = &h[(u * 4 + w) * 8]; if (!o[1]) continue; ++nWaves[k]; if (o[6] & 7u) ++nNarrow[k];
                         const uint32_t ta = (uint32_t)o[7], tb = (uint32_t)(o[7] >> 32); float fa, fb; memcpy(&fa, &ta, 4); memcpy(&fb, &tb, 4);
-                        if (fa < 0.5f) ++nZero[k]; else { thrA[k] += std::min(fa, 1e5f); thrB[k] += std::min(fb, 1e5f); }
+                        if (fa < 0.5f) ++nZero[k]; else { thrA[k] += std::min(fa, 1e5f); thrB[k] += std::min(fb, 1e5f);
+                            hardDur[k] += (double)(o[1] - o[0]) / 100.0; hardEv[k] += (double)(o[2] & 0xFFFFull); hardBt[k] += (double)(o[3] & 0xFFFFFFFFull);
+#ifdef LFG_STAMP_PHASES
+                            hardPh[k][0] += (double)(o[5] & 0xFFFFFull) / 100.0; hardPh[k][1] += (double)((o[5] >> 20) & 0xFFFFFull) / 100.0; hardPh[k][2] += (double)((o[5] >> 40) & 0xFFFFFull) / 100.0;
+#endif
+                        }
                         const unsigned box = (unsigned)(o[6] >> 32); if (((box >> 16) & 0xFF) == 0xEE) { ++nBand[k]; wBand[k] += (double)(((box >> 8) & 0xFF) - (box & 0xFF) + 1); } }
                 }
                 for (int k = 0; k < 6; ++k) if (nu[k]) fprintf(stderr, "rim units, %s: %d, mean %.1f us (first batch done after %.1f, search over after %.1f), evaluations per wave %.1f, batches per wave %.1f; waves %d, narrow %d, all-zero thresholds after the hints %d, others' mean threshold after hints %.0f, at the end %.0f; band known in %d waves, mean width %.1f columns\n", names[k], nu[k], dur[k] / nu[k], fstK[k] / nu[k], srchK[k] / nu[k], evs[k] / nu[k], bts[k] / nu[k],
                                                         nWaves[k], nNarrow[k], nZero[k], thrA[k] / std::max(1, nWaves[k] - nZero[k]), thrB[k] / std::max(1, nWaves[k] - nZero[k]), nBand[k], wBand[k] / std::max(1, nBand[k]));
+                for (int k = 0; k < 6; ++k) if (nWaves[k] - nZero[k] > 0) fprintf(stderr, "  %s, the %d waves that are not settled by the hints: mean %.1f us, %.1f full evaluations, %.1f batches\n", names[k], nWaves[k] - nZero[k],
+                                                        hardDur[k] / (nWaves[k] - nZero[k]), hardEv[k] / (nWaves[k] - nZero[k]), hardBt[k] / (nWaves[k] - nZero[k]));
+#ifdef LFG_STAMP_PHASES
+                for (int k = 0; k < 6; ++k) if (nWaves[k] - nZero[k] > 0) fprintf(stderr, "  %s, those waves: %.1f us in the batch tests, %.1f in the sixteen-point test, %.1f in full evaluations\n", names[k],
+                                                        hardPh[k][0] / (nWaves[k] - nZero[k]), hardPh[k][1] / (nWaves[k] - nZero[k]), hardPh[k][2] / (nWaves[k] - nZero[k]));
+#endif
             }
+            // (inside the block above: the waves whose thresholds are not all zero-cost words after the hints)
             {   // narrow search: waves by candidates per pass, their mean duration
                 double dur[8] = {0}; int nw[8] = {0}; double evs[8] = {0};
                 for (int u = 0; u < 8192; ++u) for (int w = 0; w < 4; ++w) {

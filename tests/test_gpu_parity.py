@@ -161,7 +161,11 @@ def as_int(mv_f32):
 
 
 @pytest.mark.parametrize("wh,shift", [((128, 64), (3, -2)), ((70, 45), (-5, 7)), ((64, 32), (0, 0)),
-                                      ((200, 40), (16, -16)), ((33, 90), (-16, 16))])
+                                      ((200, 40), (16, -16)), ((33, 90), (-16, 16)),
+                                      # purely vertical pans: the strip they expose is a few rows over the whole width -- the row
+                                      # band of the prefilter (motion.hip, "Row band"), at the bottom and at the top, in a segment's
+                                      # upper and lower half (160 rows: the last segment starts at row 144)
+                                      ((224, 160), (0, 6)), ((224, 160), (0, -6)), ((180, 150), (0, -3)), ((180, 150), (1, 5))])
 def test_motion_translation_matches_oracle(ctx, oracle, wh, shift):
     prev = synth.make_prev(*wh, seed=11)
     curr = synth.translate(prev, shift, seed=11)
