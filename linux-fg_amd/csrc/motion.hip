@@ -596,13 +596,20 @@ __device__ __forceinline__ void prefilter_unit(
     //  zero vector the intended order starts with)
     const bool rankIsScan = LFG_RANK_ARITH && rank2scan[0] == 0u;
     const uint32_t unitAuxFirst = (!whole && !fromQueue) ? sp.unitAux[unit] : 0u;      // (likewise: its lists are addressed behind the barrier)
-    // A unit that shares its tile first runs the head of the order -- zero motion and the first hints -- for the
+    // A unit that shares its tile first runs the head of the order -- this call's top hint and zero motion -- for the
     // thresholds only (not recorded: the unit that owns those entries records them).  Without it a unit whose part
     // of the order holds no good candidate starts from nothing and records far more than it needs to.
+    // (TWO entries.  Eight until round 4 -- zero motion and the first seven hints: where a segment's pixels have no match,
+    //  the strips a pan exposes, no test can drop a candidate and each of the eight was a full evaluation, 13 us in front of
+    //  every part of every rim segment: 877 units a call.  What the six further hints bought the segments that do match was
+    //  less: 2 -> pan 3,415 -> 3,562 frames/s with three frames in flight, 2,640 -> 2,728 one at a time, noisy +1.3 %,
+    //  moving objects +0.5 %, occluded +0.2 %, fade +1 %; 3 and 4 lie in between.  One -- the top hint alone -- is the first
+    //  batch itself and leaves the second one empty.)
 #ifndef LFG_HEAD
-#define LFG_HEAD 8
+#define LFG_HEAD 2
 #endif
     constexpr int kHead = LFG_HEAD;
+    static_assert(kHead > LFG_FIRST_BATCH, "the head is the first batch and at least one entry more");
     // (the parts of a segment handed over at run time start from the thresholds of the wave that handed it over --
     //  which had tried every hint -- instead: see the push and `run` below)
     const int nHead = (chunk > 0 && !(fromQueue && LFG_QUEUE_INIT)) ? kHead : 0;
@@ -1119,7 +1126,7 @@ __device__ __forceinline__ void prefilter_unit(
 #ifndef LFG_FOURPOINT_MAX
 #define LFG_FOURPOINT_MAX (4.0f * 510.0f)
 #endif
-        bool useFourPoint = true, useSixteen = LFG_SIXTEEN != 0;
+        bool useFourPoint = true, useSixteen = LFG_SIXTEEN != 0, useEight = true;
         auto fourPointApplies = [&]() { return useFourPoint && !(waveThr < kOnePointMax) && waveThr < LFG_FOURPOINT_MAX; };
         // (per lane: the candidate `ordL` still has to be evaluated in full)
         // (Tried in round 3 and dropped: the same walk on sums of absolute differences first -- a distance is at least half
@@ -1311,29 +1318,36 @@ __device__ __forceinline__ void prefilter_unit(
                 // batch of 64 candidates: a sixth of evaluating them.  A rolled loop (32 unrolled columns would be 4,000
                 // instructions); positions outside the image add nothing, groups that no pixel inside the
                 // image maps to are left out.
+                // EIGHT points first (round 4): the lattice's every other column -- columns = 0 mod 4, rows even -- still puts
+                // 2 x 4 points into every block (columns 4 t0, 4 t0 + 4 with t0 = ceil(i / 4) for pixel column i; rows as above),
+                // S~ >= (the sum of those eight distances) (1 - 9.1 u) by the same argument, and the walk is half as long.  Their
+                // sum is 1,650 +- 200 for a wrong candidate, of which the smallest of a segment's groups is some 1,100: enough against
+                // thresholds below 512 (LFG_EIGHT_MAX) -- the rows above the strip a vertical pan exposes, whose blocks reach into it
+                // (386 under the benchmark's pan: 40 -> 21 us per wave in these walks), sensor noise -- and where the threshold
+                // is larger, or for the candidates it lets through when they are many, the sixteen-point walk follows as before.
                 auto bitsOf = [](float d) { return __builtin_bit_cast(uint32_t, d); };
-                lds_ro_u32_ptr w = (lds_ro_u32_ptr)(sWin + kSeg * seg) + (ordL >> 16);
-                uint32_t gMin = 0x7F800000u;
-                float vOld[9], hOld[2][9];
-#pragma unroll
-                for (int a = 0; a < 9; ++a) { vOld[a] = 0.0f; hOld[0][a] = 0.0f; hOld[1][a] = 0.0f; }
                 int rowsL = ty0 + kSeg * seg;
                 asm volatile("" : "+s"(rowsL));
                 uint32_t rowRelevant = 0u;                              // bit a: some pixel row inside the image maps to vertical group a
 #pragma unroll
                 for (int a = 0; a < 9; ++a) rowRelevant |= (!border || rowsL + max(0, 2 * a - 1) < H) ? (1u << a) : 0u;
-                const int bLo = (bandLo + 1) >> 1, bHi = (bandHi + 1) >> 1;   // groups ceil(i / 2) of the band's pixel columns i
                 const bool restricted = LFG_BAND && (bandLo > 0 || bandHi < kPTW - 1);
-                auto walk = [&](auto banded, auto atBorder) {           // (four copies: see the four-point test)
-                constexpr bool kBanded = decltype(banded)::value, kBorder = decltype(atBorder)::value;
-                if (!kBorder) {             // (the groups that the first three columns would close: kept out of the minimum by huge sums)
+                auto walk = [&](auto banded, auto atBorder, auto eightTag) -> uint32_t {     // (eight copies: see the four-point test)
+                constexpr bool kBanded = decltype(banded)::value, kBorder = decltype(atBorder)::value, kEight = decltype(eightTag)::value;
+                constexpr int kStep = kEight ? 4 : 2, kCols = kEight ? 16 : 32, kClose = kEight ? 1 : 3;   // lattice column stride; columns; a group is closed by its last column
+                // groups ceil(i / kStep) of the band's pixel columns i
+                const int bLo = (bandLo + kStep - 1) / kStep, bHi = (bandHi + kStep - 1) / kStep;
+                lds_ro_u32_ptr w = (lds_ro_u32_ptr)(sWin + kSeg * seg) + (ordL >> 16);
+                uint32_t gMin = 0x7F800000u;
+                float vOld[9], hOld[2][9];
 #pragma unroll
-                    for (int a = 0; a < 9; ++a) { vOld[a] = 1.0e30f; hOld[0][a] = 1.0e30f; hOld[1][a] = 1.0e30f; }
+                for (int a = 0; a < 9; ++a) {       // (interior: the groups that the first columns would close are kept out of the minimum by huge sums)
+                    vOld[a] = kBorder ? 0.0f : 1.0e30f; hOld[0][a] = kBorder ? 0.0f : 1.0e30f; hOld[1][a] = kBorder ? 0.0f : 1.0e30f;
                 }
 #pragma unroll 2
-                for (int t = 0; t < 32; ++t, w += 2 * kWinH) {
-                    if (kBanded && (t < bLo || t > bHi + 3)) continue;  // (wave-uniform)
-                    int colL = 2 * t;
+                for (int t = 0; t < kCols; ++t, w += kStep * kWinH) {
+                    if (kBanded && (t < bLo || t > bHi + kClose)) continue;  // (wave-uniform)
+                    int colL = kStep * t;
                     asm volatile("" : "+s"(colL));
                     uint32_t tex[12];
 #pragma unroll
@@ -1351,26 +1365,51 @@ __device__ __forceinline__ void prefilter_unit(
                     for (int k = 0; k < 11; ++k) pr[k] = d[k] + d[k + 1];
 #pragma unroll
                     for (int a = 0; a < 9; ++a) v[a] = pr[a] + pr[a + 2];
-                    // columns t-1, t; with the pair sum of columns t-3, t-2 the group b = t - 3, whose first pixel
-                    // column is max(0, 2 b - 1)
-                    const bool colRelevant = t >= (kBanded ? bLo : 0) + 3 && (!kBorder || tx0 + max(0, 2 * (t - 3) - 1) < W);
+                    // sixteen: columns t-1, t; with the pair sum of columns t-3, t-2 the group b = t - 3, whose first pixel column
+                    // is max(0, 2 b - 1).  eight: columns t-1, t are the group b = t - 1, first pixel column max(0, 4 b - 3).
+                    const bool colRelevant = t >= (kBanded ? bLo : 0) + kClose &&
+                                             (!kBorder || tx0 + max(0, kStep * (t - kClose) - (kStep - 1)) < W);
                     const int sel = t & 1;                             // hOld[sel] holds the pair sum made two columns ago
 #pragma unroll
                     for (int a = 0; a < 9; ++a) {
                         const float h = vOld[a] + v[a];
-                        const uint32_t g = bitsOf((sel ? hOld[1][a] : hOld[0][a]) + h);
+                        const uint32_t g = kEight ? bitsOf(h) : bitsOf((sel ? hOld[1][a] : hOld[0][a]) + h);
                         if (kBorder) gMin = min(gMin, (colRelevant && ((rowRelevant >> a) & 1u)) ? g : 0x7F800000u);
                         else gMin = min(gMin, g);
-                        if (sel) hOld[1][a] = h; else hOld[0][a] = h;
+                        if (!kEight) { if (sel) hOld[1][a] = h; else hOld[0][a] = h; }
                         vOld[a] = v[a];
                     }
                 }
+                return gMin;
                 };
-                if (border) { if (restricted) walk(std::true_type{}, std::true_type{}); else walk(std::false_type{}, std::true_type{}); }
-                else        { if (restricted) walk(std::true_type{}, std::false_type{}); else walk(std::false_type{}, std::false_type{}); }
-                bool pass = !(gMin > bitsOf(waveThr * 1.000002f));
-                if (restricted) pass = zeroHit(ordL) || pass;          // (the settled pixels outside the band)
-                need = need && pass;
+                auto walkAs = [&](auto eightTag) -> uint32_t {
+                    if (border) return restricted ? walk(std::true_type{}, std::true_type{}, eightTag) : walk(std::false_type{}, std::true_type{}, eightTag);
+                    return restricted ? walk(std::true_type{}, std::false_type{}, eightTag) : walk(std::false_type{}, std::false_type{}, eightTag);
+                };
+#ifndef LFG_EIGHT
+#define LFG_EIGHT 1
+#endif
+#ifndef LFG_EIGHT_MAX
+#define LFG_EIGHT_MAX 512.0f            // (1,024: the top and right rim of the pan, thresholds of 620 - 700, let more than a dozen of a batch
+                                        //  through and pay for both walks -- pan -1.3 %; 512: pan +1.3 %, noisy +2 %, occluded +1.1 %,
+                                        //  moving objects +0.8 %; 400 and 600 within 0.5 % of it)
+#endif
+#ifndef LFG_SIXTEEN_FROM
+#define LFG_SIXTEEN_FROM 12             // (see the batch loop)
+#endif
+                const bool settledHit = restricted ? zeroHit(ordL) : false;     // (the settled pixels outside the band)
+                bool decided = false;
+                if (LFG_EIGHT && useEight && waveThr < LFG_EIGHT_MAX) {
+                    const uint32_t eMin = walkAs(std::true_type{});
+                    need = need && (!(eMin > bitsOf(waveThr * 1.000002f)) || settledHit);
+                    const int left = __builtin_popcountll(__ballot(need));
+                    if (fullBatch && left >= 48) useEight = false;
+                    decided = left <= LFG_SIXTEEN_FROM;                // (few enough to evaluate: the longer walk would cost more)
+                }
+                if (!decided) {
+                    const uint32_t gMin = walkAs(std::false_type{});
+                    need = need && (!(gMin > bitsOf(waveThr * 1.000002f)) || settledHit);
+                }
                 if (fullBatch && __builtin_popcountll(__ballot(need)) >= 48) useSixteen = false;
             }
             return __ballot(need);
