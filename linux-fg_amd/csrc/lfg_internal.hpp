@@ -101,6 +101,7 @@ struct PrefilterPlan {               // passed by value to the kernels
     float *dynUmin;
     uint32_t *dynCount;
     uint32_t *dynInit;               // per handed-over segment: the 16 x 56 thresholds of the wave that handed it over
+    int dynParts;                    // parts of the candidate order a handed-over segment is searched in: 8 (two workgroups) one frame at a time, 4 with frames in flight
     uint32_t *openList, *openCount;  // the segments left to the resolve kernel (tile * 4 + segment), appended as units end
     // Calls that went through the lean kernel first (motion_lean.hip): the table's last units -- that kernel's tiles -- are not drawn
     // from the table; instead the tiles in which it LEFT a segment come from the list it wrote (hardCount: nullptr = no such call).

@@ -533,8 +533,11 @@ __device__ unsigned long long gResolveStats[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, ~0
                                        // +24 % on matched content, 6 % faster only where every segment searches in full)
 #endif
 #ifndef LFG_DYN_PARTS
-#define LFG_DYN_PARTS 8                 // parts of the candidate order a handed-over segment is searched in (4 or 8)
-#endif
+#define LFG_DYN_PARTS 8                 // parts of the candidate order a handed-over segment is searched in, AT MOST (4 or 8): what the scratch is
+#endif                                  // laid out for.  A call uses sp.dynParts: eight when one frame runs at a time (two workgroups halve the
+                                        // longest units of a launch: occluded 841 -> 890 frames/s, moving objects 983 -> 1,074), four with
+                                        // frames in flight, where the sum of all units' times is what counts and a part's staging and setup
+                                        // are paid half as often (occluded 1,047 -> 1,082, moving objects 1,272 -> 1,281).
 static_assert(LFG_DYN_PARTS == 4 || LFG_DYN_PARTS == 8, "four parts per queue entry, at most eight lists per pixel in the resolve kernel");
 
 // One work unit of the prefilter (see motion_prefilter_kernel below, which hands units to its workgroups).
@@ -1957,7 +1960,7 @@ __device__ __forceinline__ void prefilter_unit(
         uint32_t *const pend = sPending[wave];
         int pendCount = 0;
         if (LFG_QUEUE_INIT && fromQueue) {                             // the thresholds of the wave that handed the segment over
-            const uint32_t *const init = sp.dynInit + (size_t)(unit / (LFG_DYN_PARTS / 4)) * (size_t)(kSeg * kPTW);
+            const uint32_t *const init = sp.dynInit + (size_t)(unit / (sp.dynParts / 4)) * (size_t)(kSeg * kPTW);
             uint32_t theirs[2][kRun];
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb) {
@@ -2002,7 +2005,7 @@ __device__ __forceinline__ void prefilter_unit(
                 ((i0 == hintsEnd && !(waveThr < 4.0f * 510.0f)) || (i0 == hintsEnd + 64 && firstBatchSurvivors >= 16))) {
                 // LFG_DYN_PARTS parts of the candidate order, four per queue entry (one workgroup each); the entries of a
                 // segment are consecutive slots, so its private lists are the blocks 4 slot .. 4 slot + parts - 1
-                constexpr uint32_t kEntries = LFG_DYN_PARTS / 4;
+                const uint32_t kEntries = (uint32_t)sp.dynParts / 4u;
                 uint32_t slot = 0u;
                 if (lane == 0) slot = atomicAdd(sp.queueCount, kEntries);
                 slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
@@ -2039,10 +2042,10 @@ __device__ __forceinline__ void prefilter_unit(
                     }
                     if (lane == 0) {
                         sp.openList[atomicAdd(sp.openCount, 1u)] = (uint32_t)(tile * (kPTH / kSeg) + seg);                 // (its parts leave it to the resolve kernel)
-                        sp.segMap[tile * (kPTH / kSeg) + seg] = (4u * slot) | ((uint32_t)LFG_DYN_PARTS << 24) | (1u << 31);    // (read by the resolve kernel)
+                        sp.segMap[tile * (kPTH / kSeg) + seg] = (4u * slot) | ((uint32_t)sp.dynParts << 24) | (1u << 31);    // (read by the resolve kernel)
                         // the entry itself is the "slot filled" signal (never 0): an atomic, like the read that waits for it
                         for (uint32_t k = 0; k < kEntries; ++k)
-                            atomicExch(&sp.queue[slot + k], (uint32_t)tile | ((4u * k) << 20) | ((uint32_t)LFG_DYN_PARTS << 24) | (1u << 28) | ((uint32_t)seg << 29));
+                            atomicExch(&sp.queue[slot + k], (uint32_t)tile | ((4u * k) << 20) | ((uint32_t)sp.dynParts << 24) | (1u << 28) | ((uint32_t)seg << 29));
                     }
                     return 2;
                 }
@@ -3205,7 +3208,7 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, int ri
     l.dynInit = align(l.dynCount + dynBlocks * kSeg * kPTW * sizeof(uint32_t));
     // where the parts of a flagged tile meet (motion_tiled_8_16_kernel): kShareBelow slots of 64 x 64 words, all ones between calls
     // the segments the prefilter leaves open, for the resolve kernel: one word per 16-row segment at most
-    l.openList = align(l.dynInit + (size_t)l.queueCap / (LFG_DYN_PARTS / 4) * kSeg * kPTW * sizeof(uint32_t));
+    l.openList = align(l.dynInit + (size_t)l.queueCap / (LFG_DYN_PARTS / 4) * kSeg * kPTW * sizeof(uint32_t));      // (one block per segment: see the push)
     l.merge = align(l.openList + ptiles * (kPTH / kSeg) * sizeof(uint32_t));
     l.mergeBytes = (size_t)kShareBelow * kTW * kTH * sizeof(unsigned long long);
     l.leanTiles = align(l.merge + l.mergeBytes);
@@ -3577,6 +3580,10 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
     sp.openList = reinterpret_cast<uint32_t *>(workspace + l.openList);
     sp.openCount = reinterpret_cast<uint32_t *>(workspace + l.ctrl) + 4;
     sp.fused = fused;
+    sp.dynParts = framesInFlight ? 4 : LFG_DYN_PARTS;
+    if (const char *dp = getenv("LFG_DYN_PARTS_RT")) sp.dynParts = atoi(dp) == 4 ? 4 : LFG_DYN_PARTS;      // (measurement)
+    // (as many SEGMENTS as the queue holds in LFG_DYN_PARTS parts, whatever the parts of this call: one block of thresholds each)
+    sp.queueCap = l.queueCap / ((LFG_DYN_PARTS / 4) / (sp.dynParts / 4));
     sp.unitsStatic = lean ? l.units2Static : units;
     sp.hardTiles = lean ? reinterpret_cast<const uint32_t *>(workspace + l.hardTiles) : nullptr;
     sp.hardCount = lean ? reinterpret_cast<const uint32_t *>(workspace + l.ctrl) + 5 : nullptr;          // (ctrl[5]: cleared by the hint kernel with the rest)
