@@ -295,8 +295,11 @@ int ensure_motion_workspace(lfg_context *ctx, uint32_t width, uint32_t height) {
         t2.insert(t2.end(), plan2.unitAux.begin(), plan2.unitAux.end());
         t2.insert(t2.end(), plan2.tileMap.begin(), plan2.tileMap.end());
         LFG_HIP(ctx, hipMemcpy(ctx->motion_ws + layout.plan2, t2.data(), t2.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        if (!plan2.leanTiles.empty())
-            LFG_HIP(ctx, hipMemcpy(ctx->motion_ws + layout.leanTiles, plan2.leanTiles.data(), plan2.leanTiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (!plan2.leanTiles.empty()) {
+            std::vector<uint32_t> listed = plan2.leanTiles;
+            listed.insert(listed.end(), plan2.leanPartial.begin(), plan2.leanPartial.end());
+            LFG_HIP(ctx, hipMemcpy(ctx->motion_ws + layout.leanTiles, listed.data(), listed.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
     }
     // what the kernels expect to find between calls: a cleared control area (the hint kernel's counter of finished
     // workgroups lies in it, and that kernel is what clears the rest per call) and the merge words of the flagged tiles all ones

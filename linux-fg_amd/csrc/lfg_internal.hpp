@@ -79,7 +79,7 @@ struct FusedOut {
 };
 
 struct MotionWorkspaceLayout { size_t list, umin, count, tileFlags, segDone, segMap, queueCount, ctrl, order, plan, auxList, auxUmin, auxCount,
-                               queue, dynList, dynUmin, dynCount, dynInit, openList, merge, mergeBytes, leanTiles, hardTiles, plan2, total; int queueCap, slots, rimSplit, listMain, listAux, listDyn, leanCount, rimSplit2, units, units2, units2Static /* the second plan's units without the lean kernel's tiles, which come last in its table */, tiles, lastLean /* the lane's last call went by the second plan */; };
+                               queue, dynList, dynUmin, dynCount, dynInit, openList, merge, mergeBytes, leanTiles, hardTiles, plan2, total; int queueCap, slots, rimSplit, listMain, listAux, listDyn, leanCount, leanLaunch /* with the partial tiles behind them */, rimSplit2, units, units2, units2Static /* the second plan's units without the lean kernel's tiles, which come last in its table */, tiles, lastLean /* the lane's last call went by the second plan */; };
 // Work units of the motion prefilter (motion.hip: prefilter_plan).  A unit is a 56 x 64 tile, or one of nChunks
 // contiguous parts of a tile's candidate order, or one 16-row segment of a tile with its four waves on four parts of
 // the order; parts have private lists in the aux arrays (merged by the resolve kernel).
@@ -113,6 +113,7 @@ struct PrefilterPlanHost {
     int tilesX = 0, tiles = 0, units = 0, auxUnits = 0;
     std::vector<uint32_t> unitMap, unitAux, tileMap;
     std::vector<uint32_t> leanTiles;     // the whole tiles the lean kernel may take first (motion_lean.hip: lean_tile_ok)
+    std::vector<uint32_t> leanPartial;   // ... and rim tiles of which it takes the segments that lie inside the image: tile | mask of segments << 24
 };
 
 struct ProfileSlot {
@@ -218,6 +219,7 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
 // The lean kernel for whole interior tiles (motion_lean.hip): runs between the order kernel and the generic prefilter, marks the
 // segments it settles in segDone; the generic kernel skips those.
 bool lean_tile_ok(int tile, int tilesX, int W, int H);
+bool lean_segment_ok(int tile, int seg, int tilesX, int W, int H);
 bool lean_frames_ok(const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv);
 hipError_t launch_motion_lean(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv,
                               const uint32_t *order32, const uint32_t *leanTiles, int nTiles, int tilesX, uint32_t *segDone,

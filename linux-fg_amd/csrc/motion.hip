@@ -588,6 +588,9 @@ __device__ __forceinline__ void prefilter_unit(
         const uint32_t *const d = segDone + tile * (kPTH / kSeg);
         if (__builtin_amdgcn_readfirstlane((int)(d[0] & d[1] & d[2] & d[3])) != 0) return;
     }
+    // ... and so is a segment unit whose segment that kernel has settled (a rim tile's segments inside the image: all four waves
+    // of the unit work on the one segment, and leave together)
+    if (segUnit && !fromQueue && __builtin_amdgcn_readfirstlane((int)segDone[tile * (kPTH / kSeg) + (int)((um >> 29) & 3u)]) != 0) return;
     if (tid == 0) sGiveUp = 0u;
     // (the two flags of this call's order, requested here: read where they are used -- behind the staging barrier -- each
     //  was a scalar load from memory with nothing to hide its latency, two microseconds per unit)
@@ -1940,7 +1943,10 @@ __device__ __forceinline__ void prefilter_unit(
         // (a part of a handed-over segment starts with thresholds that already reflect the hints: full batches from its
         //  first entry on, and the narrow-search decision before the first of them)
         const bool inherited = LFG_QUEUE_INIT && fromQueue;
-        const int hintsEnd = inherited ? 0 : nHead ? kHead : max(kHead, min((int)orderHints, 2 + 62));
+#ifndef LFG_HINTS_MAX
+#define LFG_HINTS_MAX (2 + 62)
+#endif
+        const int hintsEnd = inherited ? 0 : nHead ? kHead : max(kHead, min((int)orderHints, LFG_HINTS_MAX));
         int firstBatchSurvivors = 0;
         // BY RANK.  Once every pixel of the wave owns a zero-cost candidate only candidates that come EARLIER in the tie
         // order than the latest of those can still matter (zeroBound).  Walking on through the visiting order would
@@ -3213,7 +3219,8 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, int ri
     l.mergeBytes = (size_t)kShareBelow * kTW * kTH * sizeof(unsigned long long);
     l.leanTiles = align(l.merge + l.mergeBytes);
     l.leanCount = (int)plan2.leanTiles.size();
-    l.hardTiles = align(l.leanTiles + (plan2.leanTiles.size() + 1) * sizeof(uint32_t));
+    l.leanLaunch = plan2.leanTiles.empty() ? 0 : (int)(plan2.leanTiles.size() + plan2.leanPartial.size());
+    l.hardTiles = align(l.leanTiles + (plan2.leanTiles.size() + plan2.leanPartial.size() + 1) * sizeof(uint32_t));
     l.total = align(l.hardTiles + (plan2.leanTiles.size() + 1) * sizeof(uint32_t));
     if (layout) *layout = l;
     return l.total;
@@ -3321,6 +3328,22 @@ PrefilterPlanHost prefilter_plan(uint32_t width, uint32_t height, int slots, int
         }
     } else {
         p.leanTiles = lean;
+    }
+    // ... and of the rim tiles above and below them it takes the segments that lie inside the image as the tiles above do
+    // (lean_segment_ok): the plan keeps its units for them, which leave at once when they find the segment settled.
+#ifndef LFG_LEAN_PARTIAL
+#define LFG_LEAN_PARTIAL 1
+#endif
+    if (LFG_LEAN_PARTIAL && !p.leanTiles.empty()) {
+        for (int t = 0; t < p.tiles; ++t) {
+            if (lean_tile_ok(t, p.tilesX, W, H)) continue;
+            uint32_t mask = 0u;
+            for (int seg = 0; seg < kPTH / kSeg; ++seg) mask |= lean_segment_ok(t, seg, p.tilesX, W, H) ? (1u << seg) : 0u;
+            // (only the tiles the plan cut into segment units of four parts each: those are the units that look at the marks)
+            const uint32_t tm = p.tileMap[(size_t)t];
+            if (mask != 0u && tm != 0xFFFFFFFFu && ((tm >> 24) & 0xFu) == 4u) p.leanPartial.push_back((uint32_t)t | ((mask & ~(tm >> 28)) << 24));
+        }
+        p.leanPartial.erase(std::remove_if(p.leanPartial.begin(), p.leanPartial.end(), [](uint32_t e) { return (e >> 24) == 0u; }), p.leanPartial.end());
     }
     return p;
 }
@@ -3613,7 +3636,7 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
         if (lean) {
             // (beside the persistent kernel on a stream of its own, with that kernel's grid cut to 448 .. 320 workgroups to leave it room:
             //  measured for a context that runs one frame at a time, 2,160 - 2,430 frames/s against 2,610 without the kernel: not done)
-            e = launch_motion_lean(s, prev, curr, mv, order, reinterpret_cast<const uint32_t *>(workspace + l.leanTiles), l.leanCount, sp.tilesX, segDone,
+            e = launch_motion_lean(s, prev, curr, mv, order, reinterpret_cast<const uint32_t *>(workspace + l.leanTiles), l.leanLaunch, sp.tilesX, segDone,
                                    reinterpret_cast<uint32_t *>(workspace + l.hardTiles), ctrl + 5, ctrl + 6,
                                    getenv("LFG_LEAN_FORCE") != nullptr && atoi(getenv("LFG_LEAN_FORCE")) == 1);      // (ctrl[5]: tiles it left; ctrl[6], [7]: segments it settled, segments it left -- counted in diagnostic builds)
             if (e != hipSuccess) return e;

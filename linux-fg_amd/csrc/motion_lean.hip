@@ -123,7 +123,13 @@ __global__ __launch_bounds__(kPNT, 3) void motion_lean_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), seg = wave;
-    const int tile = (int)leanTiles[blockIdx.x];
+    // an entry: the tile, and for a rim tile above or below the interior the segments to take (bits 24..27; 0: all four) -- those
+    // whose block positions all lie inside the image; the window's rows outside it are zeros, as texelFetch reads them
+    const uint32_t entry = leanTiles[blockIdx.x];
+    const int tile = (int)(entry & 0xFFFFFFu);
+    const uint32_t segMask = (entry >> 24) != 0u ? (entry >> 24) : 0xFu;
+    const bool partial = (entry >> 24) != 0u;
+    const bool segOn = ((segMask >> seg) & 1u) != 0u;                  // (wave-uniform)
     const int tileY = tile / tilesX, tileX = tile - tileY * tilesX;
     const int tx0 = tileX * kPTW, ty0 = tileY * kPTH;
     const int bx0 = tx0 - kB / 2, by0 = ty0 - kB / 2;                  // image coordinates of block position (0, 0)
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(kPNT, 3) void motion_lean_kernel(
     // content the kernel is for, and every workgroup leaves before it has staged anything
     // (a tile in which anything is left goes onto the list the generic kernel draws from behind its own table: here, all of them)
     if ((order32[kCand + 2] & 1u) == 0u && !whateverTheVerdict) {
-        if (tid == 0) hardTiles[atomicAdd(hardCount, 1u)] = (uint32_t)tile;
+        if (tid == 0 && !partial) hardTiles[atomicAdd(hardCount, 1u)] = (uint32_t)tile;      // (a rim tile's segments have their units in the plan)
         return;
     }
     if (tid == 0) sLeft = 0u;
@@ -143,7 +149,9 @@ __global__ __launch_bounds__(kPNT, 3) void motion_lean_kernel(
     // ---- this lane's 23 block positions of the current frame (column bx0 + lane, rows by0 + 16 seg + j): all inside the image
     uint32_t c[kSegD], cc[kSegD];
     {
-        const uint8_t *const column = curr + (size_t)(bx0 + min(lane, kPTW + kB - 2)) * 4u + (size_t)(by0 + kSeg * seg) * (size_t)currPitch;
+        // (a wave whose segment is not taken reads the rows of one that is: valid memory, never used)
+        const int segC = segOn ? seg : (int)__builtin_ctz(segMask);
+        const uint8_t *const column = curr + (size_t)(bx0 + min(lane, kPTW + kB - 2)) * 4u + (size_t)(by0 + kSeg * segC) * (size_t)currPitch;
 #pragma unroll
         for (int j = 0; j < kSegD; ++j) c[j] = *reinterpret_cast<const uint32_t *>(column + (size_t)j * (size_t)currPitch);
     }
@@ -158,6 +166,12 @@ __global__ __launch_bounds__(kPNT, 3) void motion_lean_kernel(
 #pragma unroll
         for (int k = 0; k < kRounds; ++k) {
             const int wy = min(wyK, kWinH - 1);
+            if (partial) {                 // (wave-uniform) rows above or below the image: the nearest row is loaded and dropped (a mask, not a select)
+                const int gy = by0 - kR + wy;
+                const uint4 t = *reinterpret_cast<const uint4 *>(prev + (size_t)min(max(gy, 0), H - 1) * (size_t)prevPitch + (size_t)(bx0 - kR + 4 * gK) * 4u);
+                const uint32_t keep = (gy >= 0 && gy < H) ? 0xFFFFFFFFu : 0u;
+                v[k] = uint4{t.x & keep, t.y & keep, t.z & keep, t.w & keep};
+            } else
             v[k] = *reinterpret_cast<const uint4 *>(prev + (size_t)(by0 - kR + wy) * (size_t)prevPitch + (size_t)(bx0 - kR + 4 * gK) * 4u);
             gK += 16; wyK += 10;
             if (gK >= kGroups) { gK -= kGroups; wyK += 1; }
@@ -182,6 +196,7 @@ __global__ __launch_bounds__(kPNT, 3) void motion_lean_kernel(
         if (lane < nHints) atomicOr(&sVisited[(hintL & 0xFFFFu) >> 5], 1u << (hintL & 31u));
     }
     __syncthreads();                       // window and hint set in place; the waves do not meet again before the end
+    if (!segOn) { __syncthreads(); return; }   // (the barrier the other waves end with)
 
     const lean_lds_u32 winCol = (lean_lds_u32)(sWin + min(lane, kPTW + kB - 2) * kWinH + kSeg * seg);       // this lane's position column
     const lean_lds_u32 winSeg = (lean_lds_u32)(sWin + kSeg * seg);
@@ -447,7 +462,7 @@ __global__ __launch_bounds__(kPNT, 3) void motion_lean_kernel(
     }
     if (__builtin_amdgcn_readfirstlane(__ballot(open) != 0ull) && lane == 0) sLeft = 1u;
     __syncthreads();
-    if (tid == 0 && sLeft != 0u) hardTiles[atomicAdd(hardCount, 1u)] = (uint32_t)tile;
+    if (tid == 0 && sLeft != 0u && !partial) hardTiles[atomicAdd(hardCount, 1u)] = (uint32_t)tile;
 #ifdef LFG_LEAN_STATS                       // (diagnostic build only: 8,576 device-scope atomics on two words are 120 us of a 70 us launch)
     if (leanStats && lane == 0) atomicAdd(&leanStats[__builtin_amdgcn_readfirstlane(__ballot(open) == 0ull) ? 0 : 1], 1u);
 #endif
@@ -460,6 +475,16 @@ bool lean_tile_ok(int tile, int tilesX, int W, int H) {
     const int bx0 = tx * kPTW - kB / 2, by0 = ty * kPTH - kB / 2;
     return bx0 - kR >= 0 && bx0 - kR + 96 <= W && by0 - kR >= 0 && by0 - kR + kWinH <= H &&
            tx * kPTW + kPTW <= W && ty * kPTH + kPTH <= H && bx0 + kPTW + kB - 2 + kR < W && by0 + kPTH + kB - 2 + kR < H;
+}
+
+// A segment of a tile that is not the kernel's as a whole: the tile's columns as above, and the segment's rows -- its 23 rows of
+// block positions and its 16 rows of pixels inside the image, and no candidate's block outside prev altogether (no plateaus).
+bool lean_segment_ok(int tile, int seg, int tilesX, int W, int H) {
+    const int ty = tile / tilesX, tx = tile - ty * tilesX;
+    const int bx0 = tx * kPTW - kB / 2, by0 = ty * kPTH - kB / 2, y0 = ty * kPTH + kSeg * seg;
+    return bx0 - kR >= 0 && bx0 - kR + 96 <= W && tx * kPTW + kPTW <= W && bx0 + kPTW + kB - 2 + kR < W &&
+           by0 + kSeg * seg >= 0 && by0 + kSeg * seg + kSegD - 1 < H && y0 + kSeg <= H &&
+           y0 + kB / 2 - 1 - kR >= 0 && y0 + kSeg - 1 - kB / 2 + kR < H;
 }
 
 bool lean_frames_ok(const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv) {
