@@ -3532,13 +3532,14 @@ __global__ __launch_bounds__(kHints) void motion_order_kernel(
         order32[kCand] = unmatchedAll * 4u <= (uint32_t)kHints ? 1u : 0u;
         // ... and for the lean kernel (motion_lean.hip), which keeps a segment only while its largest threshold stays below
         // kOnePointOnly: a block whose best SAD is 2 x that or more cannot cost less (a distance is at least half its SAD).  The
-        // kernel and the plan that goes with it pay where nearly EVERY sample matches that closely -- a pan +9 %, stills +21 % -- are
-        // neutral where a few percent of them do not (moving objects, 250 of 256: +0.7 %; occlusions, 242: -1.3 %) and cost 8 % on
-        // frames with sensor noise (none close): the bar is 63 in 64.
+        // kernel and the plan that goes with it pay where nearly every sample matches that closely -- a pan +9 %, stills +21 % -- still
+        // pay where a few percent of them do not (moving objects, 250 of 256: +5.8 %; occlusions, 242: +0.5 % -- neutral and -1.3 %
+        // before the kernel took the rim tiles' inner segments and handed-over segments were searched in four parts) and cost 8 % on
+        // frames with sensor noise (none close): the bar is 15 in 16 (63 in 64 until late in round 4).
         uint32_t closeAll = 0u;
         for (int w = 0; w < kWaves; ++w) closeAll += sWaveClose[w];
         // (bit 0: the verdict; above it the two counts, for LFG_DEBUG)
-        order32[kCand + 2] = (((closeAll & 0xFFFFu) * 64u >= 63u * (uint32_t)kHints) ? 1u : 0u) | ((closeAll & 0xFFFFu) << 1) | ((closeAll >> 16) << 12);
+        order32[kCand + 2] = (((closeAll & 0xFFFFu) * 16u >= 15u * (uint32_t)kHints) ? 1u : 0u) | ((closeAll & 0xFFFFu) << 1) | ((closeAll >> 16) << 12);
         order32[0] = entryOfScan[top];
         if (top != zero) order32[1] = entryOfScan[zero];
         sRunning = top != zero ? 2u : 1u;
