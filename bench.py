@@ -119,8 +119,9 @@ def make_content(name: str, w_in: int, h_in: int, rank: int, content_rank: int):
             curr_in[y0:y0 + ph, x0:x0 + pw] = prev_in[y0 - dy:y0 - dy + ph, x0 - dx:x0 - dx + pw]
     elif name == "noisy":                          # the translated pair plus sensor-like noise: +-2 levels per channel
         curr_in = synth.translate(prev_in, rank_shift, synth.BASE_SEED + rank)
-        n = synth.noise_bytes(w_in, h_in, (synth.BASE_SEED + 15485863 * (rank + 1)) & 0xFFFFFFFF) % 5
-        curr_in = np.clip(curr_in.astype(np.int16) + n.astype(np.int16) - 2, 0, 255).astype(np.uint8)
+        amp = int(os.environ.get("LFG_BENCH_NOISE_AMP", "2"))      # (experiments: other amplitudes; the benchmark's content is +-2)
+        n = synth.noise_bytes(w_in, h_in, (synth.BASE_SEED + 15485863 * (rank + 1)) & 0xFFFFFFFF) % (2 * amp + 1)
+        curr_in = np.clip(curr_in.astype(np.int16) + n.astype(np.int16) - amp, 0, 255).astype(np.uint8)
     elif name == "static":
         curr_in = prev_in.copy()
     elif name == "fade":

@@ -1150,10 +1150,7 @@ __device__ __forceinline__ void prefilter_unit(
                 // here; groups that no pixel inside the image maps to are left out.  Walks the lattice column by
                 // column: five distances, four vertical pair sums, four group sums with the previous column's.
                 // (Positions = 0 mod 4 did the same with 6 x 16 points until late in round 2.)
-                lds_ro_u32_ptr w = (lds_ro_u32_ptr)(sWin + kSeg * seg) + (ordL >> 16) + (3 * kWinH + 3);
                 auto bitsOf = [](float d) { return __builtin_bit_cast(uint32_t, d); };
-                uint32_t pMin = 0x7F800000u;
-                float vPrev[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                 int tx0L = tx0, rowsL = ty0 + kSeg * seg;
                 asm volatile("" : "+s"(tx0L), "+s"(rowsL));
                 uint32_t rowRelevant = 0u;                              // bit h: some pixel row inside the image maps to vertical group h (rows 4 h .. 4 h + 3)
@@ -1167,14 +1164,23 @@ __device__ __forceinline__ void prefilter_unit(
                 // (four copies of the walk: with and without the band's bounds -- the bounds' tests in the one walk cost the
                 //  segments whose band is the whole width, noise everywhere, 6 % -- and with and without the masks of a segment
                 //  at the image border: a select per point and per group is a third of the SAD walk's instructions)
-                auto walk = [&](auto banded, auto atBorder) {
-                constexpr bool kBanded = decltype(banded)::value, kBorder = decltype(atBorder)::value;
+                // ... times two currencies (round 4): by DISTANCES, as described, and by sums of absolute differences -- a distance is
+                // at least half the sum of its four absolute channel differences (Cauchy-Schwarz), so S~ >= (the four SADs' sum) / 2
+                // (1 - 10 u) as well, one v_sad_u8 and integer adds per point where a distance is three dot products, two adds and a
+                // square root.  Weaker by the ratio of the two norms (0.75 - 0.87 on natural differences): used while the wave's
+                // largest threshold is below LFG_FOUR_SAD_MAX -- a match under sensor noise -- where a wrong candidate's four SADs are
+                // still twice the threshold; what it lets through waits for the eight- and sixteen-point walks with the rest.
+                auto walk = [&](auto banded, auto atBorder, auto sadTag) -> uint32_t {
+                constexpr bool kBanded = decltype(banded)::value, kBorder = decltype(atBorder)::value, kSad = decltype(sadTag)::value;
+                typedef typename std::conditional<kSad, uint32_t, float>::type T;
+                auto asBits = [&](T v) -> uint32_t { if constexpr (kSad) return (uint32_t)v; else return __builtin_bit_cast(uint32_t, v); };
+                lds_ro_u32_ptr w = (lds_ro_u32_ptr)(sWin + kSeg * seg) + (ordL >> 16) + (3 * kWinH + 3);
+                uint32_t pMin = 0x7F800000u;
                 // a group that is not wanted -- the one "before" the first lattice column -- is kept out of the minimum by a
                 // previous column whose sums are huge, not by a select per group
-                if (!kBorder) {
+                T vPrev[4];
 #pragma unroll
-                    for (int h = 0; h < 4; ++h) vPrev[h] = 1.0e30f;
-                }
+                for (int h = 0; h < 4; ++h) vPrev[h] = kBorder ? (T)0 : (kSad ? (T)0x10000000u : (T)1.0e30f);
 #pragma unroll 3
                 for (int a = 0; a < kPTW / 4 + 1; ++a, w += 4 * kWinH) {   // lattice column 3 + 4 a closes group a - 1
                     if (kBanded && (a < gLo || a > gHi + 1)) continue;  // (wave-uniform)
@@ -1188,28 +1194,48 @@ __device__ __forceinline__ void prefilter_unit(
                     const uint32_t inImage = kBorder ? (uint32_t)__builtin_amdgcn_readlane((int)valid, colL) : 0xFFFFFFFFu;
                     // group (a - 1, h): its pixels are columns 4 (a - 1) .. + 3, rows 4 h .. + 3
                     const bool colRelevant = a > (kBanded ? gLo : 0) && (!kBorder || tx0L + 4 * (a - 1) < W);
-                    float d[5];
+                    T d[5];
 #pragma unroll
                     for (int b = 0; b < 5; ++b) {
-                        const float dd = __builtin_amdgcn_sqrtf(distanceOf((uint32_t)__builtin_amdgcn_readlane((int)c[3 + 4 * b], colL), tex[b]));
+                        const uint32_t cT = (uint32_t)__builtin_amdgcn_readlane((int)c[3 + 4 * b], colL);
                         const uint32_t keep = 0u - ((inImage >> (3 + 4 * b)) & 1u);    // scalar: all ones or zero
-                        d[b] = kBorder ? __builtin_bit_cast(float, bitsOf(dd) & keep) : dd;
+                        if constexpr (kSad) {
+                            const uint32_t dd = __builtin_amdgcn_sad_u8(cT, tex[b], 0u);
+                            d[b] = kBorder ? (dd & keep) : dd;
+                        } else {
+                            const float dd = __builtin_amdgcn_sqrtf(distanceOf(cT, tex[b]));
+                            d[b] = kBorder ? __builtin_bit_cast(float, bitsOf(dd) & keep) : dd;
+                        }
                     }
-                    float v[4];
+                    T v[4];
 #pragma unroll
                     for (int h = 0; h < 4; ++h) v[h] = d[h] + d[h + 1];
 #pragma unroll
                     for (int h = 0; h < 4; ++h) {
-                        const uint32_t g = bitsOf(vPrev[h] + v[h]);
+                        const uint32_t g = asBits(vPrev[h] + v[h]);
                         if (kBorder) pMin = min(pMin, (colRelevant && ((rowRelevant >> h) & 1u)) ? g : 0x7F800000u);
                         else pMin = min(pMin, g);
                         vPrev[h] = v[h];
                     }
                 }
+                return pMin;
                 };
-                if (border) { if (restricted) walk(std::true_type{}, std::true_type{}); else walk(std::false_type{}, std::true_type{}); }
-                else        { if (restricted) walk(std::true_type{}, std::false_type{}); else walk(std::false_type{}, std::false_type{}); }
-                bool pass = !(pMin > bitsOf(waveThr * 1.000002f));
+                auto walkAs = [&](auto sadTag) -> uint32_t {
+                    if (border) return restricted ? walk(std::true_type{}, std::true_type{}, sadTag) : walk(std::false_type{}, std::true_type{}, sadTag);
+                    return restricted ? walk(std::true_type{}, std::false_type{}, sadTag) : walk(std::false_type{}, std::false_type{}, sadTag);
+                };
+#ifndef LFG_FOUR_SAD_MAX
+#define LFG_FOUR_SAD_MAX 300.0f
+#endif
+                bool pass;
+                if (waveThr < LFG_FOUR_SAD_MAX && !restricted) {       // (noise everywhere; a band's few columns -- the left rim of a pan -- lose by it: pan -0.9 %)
+                    const uint32_t sadMin = border ? walk(std::false_type{}, std::true_type{}, std::true_type{}) : walk(std::false_type{}, std::false_type{}, std::true_type{});
+                    // (an integer below 2^24: exact as a float; the margin covers the product's rounding and the bound's 10 u)
+                    pass = !((float)sadMin > (2.0f * waveThr) * 1.00001f);
+                } else {
+                    const uint32_t pMin = walkAs(std::false_type{});
+                    pass = !(pMin > bitsOf(waveThr * 1.000002f));
+                }
                 if (restricted) pass = zeroHit(ordL) || pass;          // (the settled pixels outside the band)
                 need = need && pass;
                 if (fullBatch && __builtin_popcountll(__ballot(need)) >= 48) useFourPoint = false;
@@ -1403,13 +1429,21 @@ __device__ __forceinline__ void prefilter_unit(
 #ifndef LFG_SIXTEEN_FROM
 #define LFG_SIXTEEN_FROM 12             // (see the batch loop)
 #endif
+#ifndef LFG_EIGHT_MAX_INSIDE
+#define LFG_EIGHT_MAX_INSIDE 1024.0f    // ... away from the border, where such thresholds are heavy noise everywhere (+-8 levels at the input:
+                                        //  575 -> 682 frames/s) and not a rim's few rows; a wave whose first full batch leaves more than the
+                                        //  sixteen-point walk's worth (LFG_EIGHT_OFF_AT) stops trying
+#endif
+#ifndef LFG_EIGHT_OFF_AT
+#define LFG_EIGHT_OFF_AT 16
+#endif
                 const bool settledHit = restricted ? zeroHit(ordL) : false;     // (the settled pixels outside the band)
                 bool decided = false;
-                if (LFG_EIGHT && useEight && waveThr < LFG_EIGHT_MAX) {
+                if (LFG_EIGHT && useEight && waveThr < (border ? LFG_EIGHT_MAX : LFG_EIGHT_MAX_INSIDE)) {
                     const uint32_t eMin = walkAs(std::true_type{});
                     need = need && (!(eMin > bitsOf(waveThr * 1.000002f)) || settledHit);
                     const int left = __builtin_popcountll(__ballot(need));
-                    if (fullBatch && left >= 48) useEight = false;
+                    if (fullBatch && left >= LFG_EIGHT_OFF_AT) useEight = false;      // (not decisive here: the sixteen-point walk alone from now on)
                     decided = left <= LFG_SIXTEEN_FROM;                // (few enough to evaluate: the longer walk would cost more)
                 }
                 if (!decided) {
