@@ -1238,7 +1238,10 @@ __device__ __forceinline__ void prefilter_unit(
                 }
                 if (restricted) pass = zeroHit(ordL) || pass;          // (the settled pixels outside the band)
                 need = need && pass;
-                if (fullBatch && __builtin_popcountll(__ballot(need)) >= 48) useFourPoint = false;
+#ifndef LFG_FOUR_OFF_AT
+#define LFG_FOUR_OFF_AT 48
+#endif
+                if (fullBatch && __builtin_popcountll(__ballot(need)) >= LFG_FOUR_OFF_AT) useFourPoint = false;
                 return need;
         };
 #ifndef LFG_SIXTEEN_MAX
@@ -3772,6 +3775,7 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
                 const char *names[6] = {"top", "bottom, last segment", "bottom, other segments", "left", "right", "corner or other"};
                 double dur[6] = {0}, evs[6] = {0}, bts[6] = {0}, thrA[6] = {0}, thrB[6] = {0}; int nu[6] = {0}, nNarrow[6] = {0}, nWaves[6] = {0}, nZero[6] = {0}, nBand[6] = {0}; double wBand[6] = {0}, srchK[6] = {0}, fstK[6] = {0};
                 double hardDur[6] = {0}, hardEv[6] = {0}, hardBt[6] = {0}, hardPh[6][3] = {{0}};
+                double inDur = 0, inEv = 0, inPh[3] = {0, 0, 0}; int inN = 0;
                 int maxTx = 0, maxTy = 0;
                 for (int u = 0; u < n; ++u) { const unsigned long long *o = &h[(u * 4) * 8]; if (!o[1]) continue; maxTx = std::max(maxTx, (int)((o[6] >> 12) & 0xFF)); maxTy = std::max(maxTy, (int)((o[6] >> 20) & 0xFF)); }
                 for (int u = 0; u < n; ++u) {
@@ -3779,6 +3783,10 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
                     for (int w = 0; w < 4; ++w) { const unsigned long long *o = &h[(u * 4 + w) * 8]; if (!o[1]) continue; a = std::min(a, o[0]); b = std::max(b, o[1]); evals += o[2]; batches += o[3] & 0xFFFFFFFFull;
                         se = std::max(se, (double)(o[3] >> 33) / 100.0); if (o[5]) fs = std::max(fs, (double)(o[5] - o[0]) / 100.0);
                         rim = (int)((o[3] >> 32) & 1); tx = (int)((o[6] >> 12) & 0xFF); ty = (int)((o[6] >> 20) & 0xFF); sg = (int)((o[6] >> 10) & 3); ++nw; }
+#ifdef LFG_STAMP_PHASES
+                    if (b && !rim) for (int w = 0; w < 4; ++w) { const unsigned long long *o = &h[(u * 4 + w) * 8]; if (!o[1]) continue; ++inN; inDur += (double)(o[1] - o[0]) / 100.0; inEv += (double)(o[2] & 0xFFFFull);
+                        inPh[0] += (double)(o[5] & 0xFFFFFull) / 100.0; inPh[1] += (double)((o[5] >> 20) & 0xFFFFFull) / 100.0; inPh[2] += (double)((o[5] >> 40) & 0xFFFFFull) / 100.0; }
+#endif
                     if (!b || !rim) continue;
                     const bool l = tx == 0, r = tx == maxTx, t = ty == 0, bo = ty == maxTy;
                     const int k = (l + r + t + bo) != 1 ? 5 : t ? 0 : bo ? (sg == 2 ? 1 : 2) : l ? 3 : 4;
@@ -3798,6 +3806,8 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
                 for (int k = 0; k < 6; ++k) if (nWaves[k] - nZero[k] > 0) fprintf(stderr, "  %s, the %d waves that are not settled by the hints: mean %.1f us, %.1f full evaluations, %.1f batches\n", names[k], nWaves[k] - nZero[k],
                                                         hardDur[k] / (nWaves[k] - nZero[k]), hardEv[k] / (nWaves[k] - nZero[k]), hardBt[k] / (nWaves[k] - nZero[k]));
 #ifdef LFG_STAMP_PHASES
+                if (inN) fprintf(stderr, "  interior units, their %d waves: mean %.1f us, %.1f full evaluations; %.1f us in the batch tests, %.1f in the eight- and sixteen-point tests, %.1f in full evaluations\n",
+                                 inN, inDur / inN, inEv / inN, inPh[0] / inN, inPh[1] / inN, inPh[2] / inN);
                 for (int k = 0; k < 6; ++k) if (nWaves[k] - nZero[k] > 0) fprintf(stderr, "  %s, those waves: %.1f us in the batch tests, %.1f in the sixteen-point test, %.1f in full evaluations\n", names[k],
                                                         hardPh[k][0] / (nWaves[k] - nZero[k]), hardPh[k][1] / (nWaves[k] - nZero[k]), hardPh[k][2] / (nWaves[k] - nZero[k]));
 #endif
