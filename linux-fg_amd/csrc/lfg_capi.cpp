@@ -762,7 +762,7 @@ static int motion_run(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *
         }
         if (ctx->lean_ev_pending && hipEventQuery(ctx->lean_ev) == hipSuccess) { ctx->lean_predict = (*ctx->lean_flag & 1u) != 0u; ctx->lean_ev_pending = false; }
         if (const char *f = getenv("LFG_LEAN_FORCE")) ctx->lean_predict = atoi(f);          // (measurement: 1 = every call, 0 = none)
-        ctx->motion_ws_layout.lastLean = (leanPossible && ctx->lean_predict != 0 && !fo.data && lfg::lean_frames_ok(*prev, *curr, *mv)) ? 1 : 0;
+        ctx->motion_ws_layout.lastLean = (leanPossible && ctx->motion_ws_layout.leanCount > 0 && ctx->lean_predict != 0 && !fo.data && lfg::lean_frames_ok(*prev, *curr, *mv)) ? 1 : 0;
         e = lfg::launch_motion_prefiltered_8_16(ctx->stream, *prev, *curr, *mv, ctx->motion_ws, ctx->motion_ws_layout, ctx->motion_units,
                                                 rank2scan, order32, order32 + lfg::kMotionTableWords,
                                                 ctx->motion_tables + 6 * lfg::kMotionTableWords, ctx->motion_hints, ctx->lanes.size() >= 2, fo,

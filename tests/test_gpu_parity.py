@@ -1487,6 +1487,26 @@ def test_lean_kernel_agrees_with_the_literal_kernel(lean_ctx, case):
     lean_ctx.lane_select(0)
 
 
+@pytest.mark.parametrize("wh,shift", [((1284, 726), (2, 5)), ((1284, 726), (-3, -4)), ((1540, 870), (0, -6)), ((1352, 778), (4, 0))])
+def test_lean_kernel_on_ragged_sizes(lean_ctx, wh, shift):
+    """Heights that are no multiple of a tile's 64 rows or a segment's 16, pans in every direction: which segments of the rim tiles
+    above and below the interior the lean kernel takes (lean_segment_ok: all of a segment's block positions inside the image, no
+    candidate's block outside prev altogether), its window rows outside the image staged as zeros, the plan's units for those
+    segments leaving when they find them settled -- whole frame against the literal kernel, both lanes."""
+    from linux_fg_amd import capi
+    w, h = wh
+    prev = synth.make_prev(w, h, seed=synth.BASE_SEED + w + h)
+    curr = synth.translate(prev, shift, synth.BASE_SEED + w - h)
+    for lane in (0, 1):
+        lean_ctx.lane_select(lane)
+        a, _ = run_motion_mode(lean_ctx, prev, curr, capi.MOTION_PREFILTERED)
+        used, listed, left = lean_ctx.motion_lean_stats()
+        assert used and listed > 50, (used, listed)
+        b, _ = run_motion_mode(lean_ctx, prev, curr, capi.MOTION_EXACT_ONLY)
+        assert (a == b).all(), f"{wh} {shift}, lane {lane}: {(a != b).any(-1).sum()} pixels differ"
+    lean_ctx.lane_select(0)
+
+
 def test_lean_kernel_at_4k_and_after_a_change_of_content(lean_ctx, oracle):
     """BASELINE config 3's size: the benchmark's own frames (a 1080p pan, both frames upscaled on the device) and the 4K mixture
     one after the other on one lane -- the second plan's lists and the tiles the kernel left are reused from call to call --
