@@ -5,7 +5,10 @@ sixteen-point test, by-rank walk, band-restricted tests, inherited thresholds, l
 320 cases; round 3 (lists of depth 10 with the restart rule, the resolve kernel on the list of open segments, the
 single fallback launch): 0 differences in 200 cases one frame at a time and 120 with LFG_FUZZ_LANES=3 (the plan of a
 context with frames in flight); the round's final library (lattice walks in four copies, survivors always deferred, ranks by
-arithmetic, thresholds written late, kernels templated for the north-star order): 0 differences in 400 + 240 cases."""
+arithmetic, thresholds written late, kernels templated for the north-star order): 0 differences in 400 + 240 cases; round 4's
+final library (lean kernel incl. the rim tiles' inner segments, row band, eight-point and SAD four-point walks, heads of two
+entries, handed-over segments in four parts with frames in flight): 0 differences in 300 cases one frame at a time, 200 with
+LFG_FUZZ_LANES=3 and 160 with LFG_FUZZ_LANES=3 LFG_LEAN_FORCE=1 (every call through the lean kernel)."""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
