@@ -139,7 +139,7 @@ struct lfg_lane_state {
     uint32_t *lean_flag = nullptr;             // pinned: the order kernel's verdict on the lane's last call ("content for the lean kernel")
     hipEvent_t lean_ev = nullptr;              // ... recorded behind its copy
     bool lean_ev_pending = false;
-    int lean_predict = 0;                      // the verdict the next call goes by
+    int lean_predict = 0;                      // the verdict word the next call goes by (bit 0: lean kernel; bit 31: most sample blocks have a match)
 };
 
 struct lfg_context {
@@ -215,7 +215,8 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
                                           const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &layout, int units,
                                           const uint32_t *rank2scan, const uint32_t *order32,
                                           const uint32_t *entryOfScan, const uint32_t *baseScan, bool useHints, bool framesInFlight,
-                                          const FusedOut &fused = FusedOut(), bool lean = false, uint32_t *leanFlagHost = nullptr);
+                                          const FusedOut &fused = FusedOut(), bool lean = false, uint32_t *leanFlagHost = nullptr,
+                                          int groupsCap = 0 /* persistent workgroups at most (0: as many as the device holds) */);
 // The lean kernel for whole interior tiles (motion_lean.hip): runs between the order kernel and the generic prefilter, marks the
 // segments it settles in segDone; the generic kernel skips those.
 bool lean_tile_ok(int tile, int tilesX, int W, int H);

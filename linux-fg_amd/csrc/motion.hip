@@ -3566,7 +3566,8 @@ __global__ __launch_bounds__(kHints) void motion_order_kernel(
     if (tid == 0) {
         uint32_t unmatchedAll = 0u;
         for (int w = 0; w < kWaves; ++w) unmatchedAll += sWaveSum[w];
-        order32[kCand] = unmatchedAll * 4u <= (uint32_t)kHints ? 1u : 0u;
+        const uint32_t mostMatch = unmatchedAll * 4u <= (uint32_t)kHints ? 1u : 0u;
+        order32[kCand] = mostMatch;
         // ... and for the lean kernel (motion_lean.hip), which keeps a segment only while its largest threshold stays below
         // kOnePointOnly: a block whose best SAD is 2 x that or more cannot cost less (a distance is at least half its SAD).  The
         // kernel and the plan that goes with it pay where nearly every sample matches that closely -- a pan +9 %, stills +21 % -- still
@@ -3575,8 +3576,9 @@ __global__ __launch_bounds__(kHints) void motion_order_kernel(
         // frames with sensor noise (none close): the bar is 15 in 16 (63 in 64 until late in round 4).
         uint32_t closeAll = 0u;
         for (int w = 0; w < kWaves; ++w) closeAll += sWaveClose[w];
-        // (bit 0: the verdict; above it the two counts, for LFG_DEBUG)
-        order32[kCand + 2] = (((closeAll & 0xFFFFu) * 16u >= 15u * (uint32_t)kHints) ? 1u : 0u) | ((closeAll & 0xFFFFu) << 1) | ((closeAll >> 16) << 12);
+        // (bit 0: the verdict; above it the two counts, for LFG_DEBUG; bit 31: most sample blocks have a match -- the host sizes the
+        //  persistent grid of the lane's next call by it)
+        order32[kCand + 2] = (((closeAll & 0xFFFFu) * 16u >= 15u * (uint32_t)kHints) ? 1u : 0u) | ((closeAll & 0xFFFFu) << 1) | (((closeAll >> 16) & 0x7FFFFu) << 12) | (mostMatch << 31);
         order32[0] = entryOfScan[top];
         if (top != zero) order32[1] = entryOfScan[zero];
         sRunning = top != zero ? 2u : 1u;
@@ -3612,7 +3614,7 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
                                           const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &l, int units,
                                           const uint32_t *rank2scan, const uint32_t *order,
                                           const uint32_t *entryOfScan, const uint32_t *baseScan, bool useHints, bool framesInFlight,
-                                          const FusedOut &fused, bool lean, uint32_t *leanFlagHost) {
+                                          const FusedOut &fused, bool lean, uint32_t *leanFlagHost, int groupsCap) {
     const int tilesX = ((int)curr.width + kTW - 1) / kTW;
     lean = lean && useHints && !fused.data && l.units2 > 0 && l.leanCount > 0 && curr.width >= 64u && curr.height >= 64u && lean_frames_ok(prev, curr, mv);
     if (lean) units = l.units2;          // the plan that goes with the lean kernel
@@ -3684,7 +3686,8 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
         if (e != hipSuccess) return e;
     }
     int groups = std::max(1, std::min(sp.units, l.slots > 0 ? l.slots : sp.units));
-    if (const char *g = getenv("LFG_PREF_GROUPS")) groups = std::max(1, std::min(groups, atoi(g)));      // (experiment: a smaller persistent grid)
+    if (groupsCap > 0) groups = std::max(1, std::min(groups, groupsCap));      // (frames in flight: lfg_capi.cpp, motion_run)
+    if (const char *g = getenv("LFG_PREF_GROUPS")) groups = std::max(1, std::min(l.slots > 0 ? l.slots : groups, atoi(g)));      // (measurement)
     if (fused.data)
         hipLaunchKernelGGL(motion_prefilter_kernel<true>, dim3(groups), dim3(kPNT), 0, s,
                            (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
