@@ -402,13 +402,13 @@ void lane_store(lfg_context *ctx, lfg_lane_state &l) {
     l.own_stream = ctx->own_stream; l.stream = ctx->stream; l.mv_tmp = ctx->mv_tmp; l.mid_tmp = ctx->mid_tmp;
     l.motion_ws = ctx->motion_ws; l.motion_ws_bytes = ctx->motion_ws_bytes; l.motion_ws_w = ctx->motion_ws_w; l.motion_ws_h = ctx->motion_ws_h;
     l.motion_ws_layout = ctx->motion_ws_layout; l.motion_units = ctx->motion_units; l.mark = ctx->mark; l.marked = ctx->marked;
-    l.lean_flag = ctx->lean_flag; l.lean_ev = ctx->lean_ev; l.lean_ev_pending = ctx->lean_ev_pending; l.lean_predict = ctx->lean_predict;
+    l.lean_flag = ctx->lean_flag; l.lean_ev = ctx->lean_ev; l.lean_ev_pending = ctx->lean_ev_pending; l.lean_predict = ctx->lean_predict; l.lean_seen = ctx->lean_seen;
 }
 void lane_load(lfg_context *ctx, const lfg_lane_state &l) {
     ctx->own_stream = l.own_stream; ctx->stream = l.stream; ctx->mv_tmp = l.mv_tmp; ctx->mid_tmp = l.mid_tmp;
     ctx->motion_ws = l.motion_ws; ctx->motion_ws_bytes = l.motion_ws_bytes; ctx->motion_ws_w = l.motion_ws_w; ctx->motion_ws_h = l.motion_ws_h;
     ctx->motion_ws_layout = l.motion_ws_layout; ctx->motion_units = l.motion_units; ctx->mark = l.mark; ctx->marked = l.marked;
-    ctx->lean_flag = l.lean_flag; ctx->lean_ev = l.lean_ev; ctx->lean_ev_pending = l.lean_ev_pending; ctx->lean_predict = l.lean_predict;
+    ctx->lean_flag = l.lean_flag; ctx->lean_ev = l.lean_ev; ctx->lean_ev_pending = l.lean_ev_pending; ctx->lean_predict = l.lean_predict; ctx->lean_seen = l.lean_seen;
 }
 void lane_release(lfg_lane_state &l) {
     if (l.stream) (void)hipStreamSynchronize(l.stream);
@@ -766,14 +766,18 @@ static int motion_run(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *
             *ctx->lean_flag = 0u;
             LFG_HIP(ctx, hipEventCreateWithFlags(&ctx->lean_ev, hipEventDisableTiming));
         }
-        if (ctx->lean_ev_pending && hipEventQuery(ctx->lean_ev) == hipSuccess) { ctx->lean_predict = (int)*ctx->lean_flag; ctx->lean_ev_pending = false; }
+        if (ctx->lean_ev_pending && hipEventQuery(ctx->lean_ev) == hipSuccess) { ctx->lean_predict = (int)*ctx->lean_flag; ctx->lean_ev_pending = false; ctx->lean_seen = true; }
         if (const char *f = getenv("LFG_LEAN_FORCE")) ctx->lean_predict = (ctx->lean_predict & ~1) | (atoi(f) & 1);          // (measurement: 1 = every call, 0 = none)
         ctx->motion_ws_layout.lastLean = (leanPossible && ctx->motion_ws_layout.leanCount > 0 && (ctx->lean_predict & 1) != 0 && !fo.data && lfg::lean_frames_ok(*prev, *curr, *mv)) ? 1 : 0;
         const int groupsCap = (flagWanted && ((uint32_t)ctx->lean_predict >> 31) != 0u) ? std::max(1, ctx->motion_slots * 5 / 8) : 0;
+        // ... and bit 30 whether that call sent a tile through the literal kernel (flat content under a fade, exact ties): if not, this
+        // call's fallback launch is 64 workgroups instead of 2,048 -- they take whatever it flags after all, in turns (1.4 % of the
+        // frame rate under a pan: workgroups of 42 KB of LDS that read a count and leave still have to be placed)
+        const bool expectNoFallback = flagWanted && ctx->lean_seen && (((uint32_t)ctx->lean_predict >> 30) & 1u) == 0u && !getenv("LFG_FALLBACK_FULL") /* (measurement) */;
         e = lfg::launch_motion_prefiltered_8_16(ctx->stream, *prev, *curr, *mv, ctx->motion_ws, ctx->motion_ws_layout, ctx->motion_units,
                                                 rank2scan, order32, order32 + lfg::kMotionTableWords,
                                                 ctx->motion_tables + 6 * lfg::kMotionTableWords, ctx->motion_hints, ctx->lanes.size() >= 2, fo,
-                                                ctx->motion_ws_layout.lastLean != 0, (flagWanted && !ctx->lean_ev_pending) ? ctx->lean_flag : nullptr, groupsCap);
+                                                ctx->motion_ws_layout.lastLean != 0, (flagWanted && !ctx->lean_ev_pending) ? ctx->lean_flag : nullptr, groupsCap, expectNoFallback);
         if (e == hipSuccess && flagWanted && !ctx->lean_ev_pending && !fo.data) { e = hipEventRecord(ctx->lean_ev, ctx->stream); ctx->lean_ev_pending = true; }
     }
     else if (tiled) e = lfg::launch_motion_tiled_8_16(ctx->stream, *prev, *curr, *mv, nullptr, rank2scan, nullptr, nullptr, fo);

@@ -139,7 +139,8 @@ struct lfg_lane_state {
     uint32_t *lean_flag = nullptr;             // pinned: the order kernel's verdict on the lane's last call ("content for the lean kernel")
     hipEvent_t lean_ev = nullptr;              // ... recorded behind its copy
     bool lean_ev_pending = false;
-    int lean_predict = 0;                      // the verdict word the next call goes by (bit 0: lean kernel; bit 31: most sample blocks have a match)
+    int lean_predict = 0;                      // the verdict word the next call goes by (bit 0: lean kernel; bit 30: a tile went through the literal kernel; bit 31: most sample blocks have a match)
+    bool lean_seen = false;                    // ... and whether any call's word has arrived yet
 };
 
 struct lfg_context {
@@ -152,6 +153,7 @@ struct lfg_context {
     hipEvent_t lean_ev = nullptr;
     bool lean_ev_pending = false;
     int lean_predict = 0;
+    bool lean_seen = false;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::string error;
@@ -203,7 +205,8 @@ int scale_2x_strips_per_xcd(int inH);
 void scale_2x_strip_host(int inH, int xcd, int index, int &first, int &steps);
 hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                     const lfg_frame &mv, const uint32_t *tileFlags, const uint32_t *rank2scan,
-                                    unsigned long long *merge = nullptr, uint32_t *flaggedTiles = nullptr, const FusedOut &fused = FusedOut());
+                                    unsigned long long *merge = nullptr, uint32_t *flaggedTiles = nullptr, const FusedOut &fused = FusedOut(),
+                                    bool expectNothing = false, uint32_t *verdictWord = nullptr);
 // Candidate tables of the blockSize 8 / searchRadius 16 paths for one tie-break rule (motion.hip: motion_tables).
 constexpr int kMotionTableWords = 1092;     // 33 * 33 candidates + the sentinel, padded to a multiple of 4
 void motion_tables(bool intended, uint32_t *rank2scan, uint32_t *order32, uint32_t *entryOfScan, uint32_t *baseScan);
@@ -216,7 +219,8 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
                                           const uint32_t *rank2scan, const uint32_t *order32,
                                           const uint32_t *entryOfScan, const uint32_t *baseScan, bool useHints, bool framesInFlight,
                                           const FusedOut &fused = FusedOut(), bool lean = false, uint32_t *leanFlagHost = nullptr,
-                                          int groupsCap = 0 /* persistent workgroups at most (0: as many as the device holds) */);
+                                          int groupsCap = 0 /* persistent workgroups at most (0: as many as the device holds) */,
+                                          bool expectNoFallback = false /* the lane's previous call flagged no tile: a small fallback launch */);
 // The lean kernel for whole interior tiles (motion_lean.hip): runs between the order kernel and the generic prefilter, marks the
 // segments it settles in segDone; the generic kernel skips those.
 bool lean_tile_ok(int tile, int tilesX, int W, int H);

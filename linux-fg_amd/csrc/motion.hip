@@ -103,49 +103,13 @@ static_assert(kNT / 64 * kMainRows >= kDH && kExtra <= kNT, "phase-A map covers 
 
 constexpr int kShareBelow = 256;        // flagged tiles up to which the exact kernel shares each between several workgroups
 constexpr int kFallbackParts = 8;       // workgroups that share a flagged tile (contiguous parts of the tie order)
+// One tile (or one part of a flagged tile) of the literal kernel: see motion_tiled_8_16_kernel, which decides what this workgroup takes.
 template <bool kFused>
-__global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
+__device__ __forceinline__ void exact_tile(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
-    int8_t *__restrict__ mv, int mvPitch, int W, int H, const uint32_t *__restrict__ tileFlags,
-    const uint32_t *__restrict__ rank2scan, unsigned long long *__restrict__ merge,
-    uint32_t *__restrict__ flaggedTiles, int tilesX, int tiles, FusedOut fo) {
-    // Two uses.  tileFlags == nullptr: the literal kernel for the whole frame (LFG_MOTION_MODE=1), one workgroup per tile of
-    // the 2-D grid.  Otherwise the SECOND PASS of the prefiltered path, ONE launch of a 1-D grid (max(tiles, kShareBelow *
-    // kFallbackParts) workgroups) whatever the prefilter flagged -- usually nothing: every workgroup reads the count and leaves:
-    //   * up to kShareBelow flagged tiles (counted and listed on the device as they were flagged: flaggedTiles[0], [1 ..]):
-    //     a workgroup needs 4.3 ms for a tile whatever else the chip is doing, so each tile is shared by kFallbackParts
-    //     workgroups, each on a contiguous part of the tie order.  The parts meet in `merge` (one 64-bit word per pixel
-    //     of the slot's 64 x 64 tile, all ones between calls): atomicMin of (cost bits << 32 | rank) is the smallest cost
-    //     and, among equal costs, the first candidate in tie order; the part that arrives LAST (a counter per slot behind
-    //     the list) turns the words into vectors and leaves them all ones again.  (Round 2: two launches for the two
-    //     regimes, a third for the merge, and the words lived in the lists, preset by the resolve kernel.)
-    //   * more flagged tiles fill the chip by themselves: one workgroup each, vectors written directly.
-    // Candidates are visited in TIE ORDER: rank2scan[r] is the scan index (dy+R)*33 + (dx+R) of the r-th candidate
-    // and the first strict minimum wins, so the table decides between equal costs.  Reference semantics: the
-    // identity (motion.comp's scan order).  Entry kCand is a sentinel (scan index kCand, one row below the window).
-    __shared__ __attribute__((aligned(16))) float sD[2][kDH * kDS];    // 2 x 21 KB
-    __shared__ uint32_t sLast;
-
-    int tileX = (int)blockIdx.x, tileY = (int)blockIdx.y;
-    int parts = 1, part = 0, slot = 0;
-    if (tileFlags) {
-        const uint32_t flagged = *flaggedTiles;
-        if (flagged == 0u) return;                                     // the usual case
-        int t;
-        if (flagged <= (uint32_t)kShareBelow) {
-            // (slot fastest: workgroups go round the XCDs in launch order, so the eight parts of a slot land on ONE XCD and
-            //  share the tile's search window in its L2 -- part fastest put them on eight and cost a quarter more, measured)
-            static_assert(kShareBelow % 8 == 0, "a slot's parts on one XCD");
-            parts = kFallbackParts; slot = (int)blockIdx.x % kShareBelow; part = (int)blockIdx.x / kShareBelow;
-            if ((uint32_t)slot >= flagged || part >= kFallbackParts) return;
-            t = (int)flaggedTiles[1 + slot];
-        } else {
-            t = (int)blockIdx.x;
-            if (t >= tiles || tileFlags[t] == 0u) return;
-        }
-        tileY = t / tilesX; tileX = t - tileY * tilesX;
-    }
-
+    int8_t *__restrict__ mv, int mvPitch, int W, int H, const uint32_t *__restrict__ rank2scan, unsigned long long *__restrict__ merge,
+    uint32_t *__restrict__ flaggedTiles, const FusedOut &fo, const int tileX, const int tileY, const int parts, const int part, const int slot,
+    float (&sD)[2][kDH * kDS], uint32_t &sLast) {
     constexpr int kOob = (int)0x80000000;        // a buffer offset that always fails the range check
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -341,6 +305,88 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
                 }
             }
         }
+    }
+}
+
+// What a workgroup of the second pass takes: item -> (tile, parts, part, slot); false: nothing.
+__device__ __forceinline__ bool fallback_item(int item, uint32_t flagged, const uint32_t *__restrict__ tileFlags, const uint32_t *__restrict__ flaggedTiles,
+                                              int tilesX, int tiles, int &tileX, int &tileY, int &parts, int &part, int &slot) {
+    int t;
+    parts = 1; part = 0; slot = 0;
+    if (flagged <= (uint32_t)kShareBelow) {
+        // (slot fastest: workgroups go round the XCDs in launch order, so the eight parts of a slot land on ONE XCD and
+        //  share the tile's search window in its L2 -- part fastest put them on eight and cost a quarter more, measured;
+        //  a grid that loops has to be a multiple of eight for that: it is)
+        static_assert(kShareBelow % 8 == 0, "a slot's parts on one XCD");
+        parts = kFallbackParts; slot = item % kShareBelow; part = item / kShareBelow;
+        if ((uint32_t)slot >= flagged || part >= kFallbackParts) return false;
+        t = (int)flaggedTiles[1 + slot];
+    } else {
+        t = item;
+        if (t >= tiles || tileFlags[t] == 0u) return false;
+    }
+    tileY = t / tilesX; tileX = t - tileY * tilesX;
+    return true;
+}
+
+template <bool kFused>
+__global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
+    const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
+    int8_t *__restrict__ mv, int mvPitch, int W, int H, const uint32_t *__restrict__ tileFlags,
+    const uint32_t *__restrict__ rank2scan, unsigned long long *__restrict__ merge,
+    uint32_t *__restrict__ flaggedTiles, int tilesX, int tiles, FusedOut fo, uint32_t *__restrict__ verdictWord) {
+    // Two uses.  tileFlags == nullptr: the literal kernel for the whole frame (LFG_MOTION_MODE=1), one workgroup per tile of
+    // the 2-D grid.  Otherwise the SECOND PASS of the prefiltered path, ONE launch of a 1-D grid whatever the prefilter flagged
+    // -- usually nothing: every workgroup reads the count and leaves.  The workgroups share out the ITEMS below, workgroup b
+    // taking items b, b + grid, ...: max(tiles, kShareBelow * kFallbackParts) workgroups take one each; a smaller grid -- what a
+    // lane launches with frames in flight when its previous call flagged nothing (2,048 workgroups of 42 KB of LDS that only
+    // read a count and leave still have to be placed behind the other lanes' kernels: 1.4 % of the frame rate) -- loops, in a
+    // kernel of its own (motion_tiled_8_16_loop_kernel):
+    //   * up to kShareBelow flagged tiles (counted and listed on the device as they were flagged: flaggedTiles[0], [1 ..]):
+    //     a workgroup needs 4.3 ms for a tile whatever else the chip is doing, so each tile is shared by kFallbackParts
+    //     workgroups, each on a contiguous part of the tie order.  The parts meet in `merge` (one 64-bit word per pixel
+    //     of the slot's 64 x 64 tile, all ones between calls): atomicMin of (cost bits << 32 | rank) is the smallest cost
+    //     and, among equal costs, the first candidate in tie order; the part that arrives LAST (a counter per slot behind
+    //     the list) turns the words into vectors and leaves them all ones again.  (Round 2: two launches for the two
+    //     regimes, a third for the merge, and the words lived in the lists, preset by the resolve kernel.)
+    //   * more flagged tiles fill the chip by themselves: one workgroup each, vectors written directly.
+    // Candidates are visited in TIE ORDER: rank2scan[r] is the scan index (dy+R)*33 + (dx+R) of the r-th candidate
+    // and the first strict minimum wins, so the table decides between equal costs.  Reference semantics: the
+    // identity (motion.comp's scan order).  Entry kCand is a sentinel (scan index kCand, one row below the window).
+    __shared__ __attribute__((aligned(16))) float sD[2][kDH * kDS];    // 2 x 21 KB
+    __shared__ uint32_t sLast;
+    int tileX = (int)blockIdx.x, tileY = (int)blockIdx.y;
+    int parts = 1, part = 0, slot = 0;
+    if (tileFlags) {
+        const uint32_t flagged = *flaggedTiles;
+        // (for the host, which sizes the lane's NEXT launch of this pass by it: bit 30 of the call's verdict word)
+        if (flagged != 0u && verdictWord && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(verdictWord, 1u << 30);
+        if (flagged == 0u) return;                                     // the usual case
+        if (!fallback_item((int)blockIdx.x, flagged, tileFlags, flaggedTiles, tilesX, tiles, tileX, tileY, parts, part, slot)) return;
+    }
+    exact_tile<kFused>(prev, prevPitch, curr, currPitch, mv, mvPitch, W, H, rank2scan, merge, flaggedTiles, fo, tileX, tileY, parts, part, slot, sD, sLast);
+}
+
+// The same pass on a grid smaller than its items (see above): workgroup b takes items b, b + grid, ...  A kernel of its own: with
+// the loop around it the tile's code keeps more alive (128 registers and a spill where the kernel above has 117), and the kernel
+// above is the one that runs where tiles ARE flagged.
+template <bool kFused>
+__global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_loop_kernel(
+    const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
+    int8_t *__restrict__ mv, int mvPitch, int W, int H, const uint32_t *__restrict__ tileFlags,
+    const uint32_t *__restrict__ rank2scan, unsigned long long *__restrict__ merge,
+    uint32_t *__restrict__ flaggedTiles, int tilesX, int tiles, FusedOut fo, uint32_t *__restrict__ verdictWord) {
+    __shared__ __attribute__((aligned(16))) float sD[2][kDH * kDS];
+    __shared__ uint32_t sLast;
+    const uint32_t flagged = *flaggedTiles;
+    if (flagged != 0u && verdictWord && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(verdictWord, 1u << 30);
+    if (flagged == 0u) return;
+    const int items = flagged <= (uint32_t)kShareBelow ? kShareBelow * kFallbackParts : tiles;
+    for (int item = (int)blockIdx.x; item < items; item += (int)gridDim.x) {
+        int tileX, tileY, parts, part, slot;
+        if (fallback_item(item, flagged, tileFlags, flaggedTiles, tilesX, tiles, tileX, tileY, parts, part, slot))
+            exact_tile<kFused>(prev, prevPitch, curr, currPitch, mv, mvPitch, W, H, rank2scan, merge, flaggedTiles, fo, tileX, tileY, parts, part, slot, sD, sLast);
+        __syncthreads();                   // (the next item reuses the distance planes and sLast)
     }
 }
 
@@ -3186,20 +3232,21 @@ __global__ __launch_bounds__(256) void motion_resolve_kernel(
 // whatever was flagged (see the kernel).
 hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                     const lfg_frame &mv, const uint32_t *tileFlags, const uint32_t *rank2scan,
-                                    unsigned long long *merge, uint32_t *flaggedTiles, const FusedOut &fused) {
+                                    unsigned long long *merge, uint32_t *flaggedTiles, const FusedOut &fused,
+                                    bool expectNothing, uint32_t *verdictWord) {
     const int tilesX = ((int)curr.width + kTW - 1) / kTW, tilesY = ((int)curr.height + kTH - 1) / kTH;
-    const dim3 grid = tileFlags ? dim3((unsigned)std::max(tilesX * tilesY, kShareBelow * kFallbackParts), 1, 1)
+    // (expectNothing: the lane's previous call flagged no tile -- 64 workgroups, which take it all if this one does after all)
+    const dim3 grid = tileFlags ? dim3(expectNothing ? 64u : (unsigned)std::max(tilesX * tilesY, kShareBelow * kFallbackParts), 1, 1)
                                 : dim3((unsigned)tilesX, (unsigned)tilesY, 1);
-    if (fused.data)
-        hipLaunchKernelGGL(motion_tiled_8_16_kernel<true>, grid, dim3(kNT), 0, s,
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, grid, dim3(kNT), 0, s,
                            (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
                            (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, tileFlags, rank2scan,
-                           merge, flaggedTiles, tilesX, tilesX * tilesY, fused);
-    else
-        hipLaunchKernelGGL(motion_tiled_8_16_kernel<false>, grid, dim3(kNT), 0, s,
-                           (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
-                           (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, tileFlags, rank2scan,
-                           merge, flaggedTiles, tilesX, tilesX * tilesY, fused);
+                           merge, flaggedTiles, tilesX, tilesX * tilesY, fused, verdictWord);
+    };
+    const bool loops = tileFlags != nullptr && expectNothing;
+    if (fused.data) { if (loops) launch(motion_tiled_8_16_loop_kernel<true>); else launch(motion_tiled_8_16_kernel<true>); }
+    else            { if (loops) launch(motion_tiled_8_16_loop_kernel<false>); else launch(motion_tiled_8_16_kernel<false>); }
     return hipGetLastError();
 }
 
@@ -3614,7 +3661,7 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
                                           const lfg_frame &mv, uint8_t *workspace, const MotionWorkspaceLayout &l, int units,
                                           const uint32_t *rank2scan, const uint32_t *order,
                                           const uint32_t *entryOfScan, const uint32_t *baseScan, bool useHints, bool framesInFlight,
-                                          const FusedOut &fused, bool lean, uint32_t *leanFlagHost, int groupsCap) {
+                                          const FusedOut &fused, bool lean, uint32_t *leanFlagHost, int groupsCap, bool expectNoFallback) {
     const int tilesX = ((int)curr.width + kTW - 1) / kTW;
     lean = lean && useHints && !fused.data && l.units2 > 0 && l.leanCount > 0 && curr.width >= 64u && curr.height >= 64u && lean_frames_ok(prev, curr, mv);
     if (lean) units = l.units2;          // the plan that goes with the lean kernel
@@ -3653,6 +3700,7 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
     uint32_t *segDone = reinterpret_cast<uint32_t *>(workspace + l.segDone);
     uint32_t *const ctrl = reinterpret_cast<uint32_t *>(workspace + l.ctrl);
     hipError_t e = hipSuccess;
+    uint32_t *verdictWord = nullptr;       // this call's verdict word (its own order table's entry kCand + 2), where there is one
     if (useHints && curr.width >= 64u && curr.height >= 64u) {
         // this call's visiting order (motion_hint_kernel, which also clears the call's control area -- tile flags, segment
         // marks and map, counters, queue -- and motion_order_kernel)
@@ -3671,6 +3719,7 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         order = callOrder;
+        verdictWord = callOrder + kCand + 2;
         // the whole interior tiles, through the lean kernel first (motion_lean.hip): what it settles it marks in segDone -- cleared by
         // the hint kernel above -- and the generic kernel below skips
         if (lean) {
@@ -3875,7 +3924,7 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
     return hipSuccess;
 #endif
     e = launch_motion_tiled_8_16(s, prev, curr, mv, flags, rank2scan, reinterpret_cast<unsigned long long *>(workspace + l.merge),
-                                 sp.queueCount + 1, fused);
+                                 sp.queueCount + 1, fused, expectNoFallback && verdictWord != nullptr, verdictWord);
     // the order kernel's verdict on this call's content (order32[kCand + 2]) for the host, which decides with it whether the lane's
     // NEXT call goes through the lean kernel: four bytes into pinned memory, behind everything else of the call
     if (e == hipSuccess && leanFlagHost && useHints && curr.width >= 64u && curr.height >= 64u)

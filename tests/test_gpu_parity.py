@@ -1558,6 +1558,34 @@ def test_lean_verdict_follows_the_content():
         c.close()
 
 
+def test_small_fallback_launch_takes_the_tiles_a_call_flags_after_all():
+    """With frames in flight a lane whose previous call sent no tile through the literal kernel launches that kernel with 64
+    workgroups instead of one per part of every possible flagged tile; they loop.  A pan (nothing flagged), then -- the lane's
+    verdict has arrived: the context is synchronised between the calls -- a fade over flat bars, which flags tiles by the dozen,
+    then the fade again (now expected: the large grid) and the pan: every call's vectors are the literal kernel's."""
+    from linux_fg_amd import capi
+    W, H = 1920, 1080
+    base = synth.make_prev(W, H, seed=synth.BASE_SEED + 606)
+    pan = synth.translate(base, (2, 3), synth.BASE_SEED + 606)
+    flat_prev, flat_curr = base.copy(), pan.copy()
+    flat_prev[300:700] = 100; flat_curr[300:700] = 101          # a flat band whose brightness changes: ties at a non-zero cost
+    c = capi.Context(0)
+    try:
+        c.lanes(2)
+        want_pan, _ = run_motion_mode(c, base, pan, capi.MOTION_EXACT_ONLY)
+        want_flat, _ = run_motion_mode(c, flat_prev, flat_curr, capi.MOTION_EXACT_ONLY)
+        flagged = []
+        for name in ("pan", "pan", "flat", "flat", "pan", "flat"):
+            prev, curr, want = (base, pan, want_pan) if name == "pan" else (flat_prev, flat_curr, want_flat)
+            got, st = run_motion_mode(c, prev, curr, capi.MOTION_PREFILTERED)
+            c.sync()
+            flagged.append(st[1])
+            assert (got == want).all(), f"{name}: {(got != want).any(-1).sum()} pixels differ"
+        assert flagged[0] == 0 and flagged[1] == 0 and flagged[2] > 0 and flagged[3] == flagged[2] and flagged[4] == 0, flagged
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("seed", [21, 22, 23])
 def test_band_restricted_lattice_tests_agree_with_the_literal_kernel(ctx, seed):
     """Segments in which most pixels own a zero-cost candidate and a few columns only nearly match (costs of a few hundred:
