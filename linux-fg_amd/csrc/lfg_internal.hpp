@@ -206,7 +206,7 @@ void scale_2x_strip_host(int inH, int xcd, int index, int &first, int &steps);
 hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                     const lfg_frame &mv, const uint32_t *tileFlags, const uint32_t *rank2scan,
                                     unsigned long long *merge = nullptr, uint32_t *flaggedTiles = nullptr, const FusedOut &fused = FusedOut(),
-                                    bool expectNothing = false, uint32_t *verdictWord = nullptr);
+                                    bool expectNothing = false, uint32_t *verdictWord = nullptr, uint32_t *hostWord = nullptr);
 // Candidate tables of the blockSize 8 / searchRadius 16 paths for one tie-break rule (motion.hip: motion_tables).
 constexpr int kMotionTableWords = 1092;     // 33 * 33 candidates + the sentinel, padded to a multiple of 4
 void motion_tables(bool intended, uint32_t *rank2scan, uint32_t *order32, uint32_t *entryOfScan, uint32_t *baseScan);

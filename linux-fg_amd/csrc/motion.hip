@@ -334,7 +334,7 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int8_t *__restrict__ mv, int mvPitch, int W, int H, const uint32_t *__restrict__ tileFlags,
     const uint32_t *__restrict__ rank2scan, unsigned long long *__restrict__ merge,
-    uint32_t *__restrict__ flaggedTiles, int tilesX, int tiles, FusedOut fo, uint32_t *__restrict__ verdictWord) {
+    uint32_t *__restrict__ flaggedTiles, int tilesX, int tiles, FusedOut fo, uint32_t *__restrict__ verdictWord, uint32_t *__restrict__ hostWord) {
     // Two uses.  tileFlags == nullptr: the literal kernel for the whole frame (LFG_MOTION_MODE=1), one workgroup per tile of
     // the 2-D grid.  Otherwise the SECOND PASS of the prefiltered path, ONE launch of a 1-D grid whatever the prefilter flagged
     // -- usually nothing: every workgroup reads the count and leaves.  The workgroups share out the ITEMS below, workgroup b
@@ -359,8 +359,13 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_kernel(
     int parts = 1, part = 0, slot = 0;
     if (tileFlags) {
         const uint32_t flagged = *flaggedTiles;
-        // (for the host, which sizes the lane's NEXT launch of this pass by it: bit 30 of the call's verdict word)
-        if (flagged != 0u && verdictWord && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(verdictWord, 1u << 30);
+        // (for the host, which sizes the lane's NEXT launch of this pass by it: bit 30 of the call's verdict word -- which this
+        //  launch, the call's last, also delivers: one store into the host's pinned word, not a copy command behind the call)
+        if (verdictWord && blockIdx.x == 0 && threadIdx.x == 0) {
+            const uint32_t word = *verdictWord | (flagged != 0u ? 1u << 30 : 0u);
+            if (flagged != 0u) *verdictWord = word;
+            if (hostWord) __hip_atomic_store(hostWord, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         if (flagged == 0u) return;                                     // the usual case
         if (!fallback_item((int)blockIdx.x, flagged, tileFlags, flaggedTiles, tilesX, tiles, tileX, tileY, parts, part, slot)) return;
     }
@@ -375,11 +380,15 @@ __global__ __launch_bounds__(kNT, 4) void motion_tiled_8_16_loop_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int8_t *__restrict__ mv, int mvPitch, int W, int H, const uint32_t *__restrict__ tileFlags,
     const uint32_t *__restrict__ rank2scan, unsigned long long *__restrict__ merge,
-    uint32_t *__restrict__ flaggedTiles, int tilesX, int tiles, FusedOut fo, uint32_t *__restrict__ verdictWord) {
+    uint32_t *__restrict__ flaggedTiles, int tilesX, int tiles, FusedOut fo, uint32_t *__restrict__ verdictWord, uint32_t *__restrict__ hostWord) {
     __shared__ __attribute__((aligned(16))) float sD[2][kDH * kDS];
     __shared__ uint32_t sLast;
     const uint32_t flagged = *flaggedTiles;
-    if (flagged != 0u && verdictWord && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(verdictWord, 1u << 30);
+    if (verdictWord && blockIdx.x == 0 && threadIdx.x == 0) {          // (see the kernel above)
+        const uint32_t word = *verdictWord | (flagged != 0u ? 1u << 30 : 0u);
+        if (flagged != 0u) *verdictWord = word;
+        if (hostWord) __hip_atomic_store(hostWord, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (flagged == 0u) return;
     const int items = flagged <= (uint32_t)kShareBelow ? kShareBelow * kFallbackParts : tiles;
     for (int item = (int)blockIdx.x; item < items; item += (int)gridDim.x) {
@@ -3233,7 +3242,7 @@ __global__ __launch_bounds__(256) void motion_resolve_kernel(
 hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                     const lfg_frame &mv, const uint32_t *tileFlags, const uint32_t *rank2scan,
                                     unsigned long long *merge, uint32_t *flaggedTiles, const FusedOut &fused,
-                                    bool expectNothing, uint32_t *verdictWord) {
+                                    bool expectNothing, uint32_t *verdictWord, uint32_t *hostWord) {
     const int tilesX = ((int)curr.width + kTW - 1) / kTW, tilesY = ((int)curr.height + kTH - 1) / kTH;
     // (expectNothing: the lane's previous call flagged no tile -- 64 workgroups, which take it all if this one does after all)
     const dim3 grid = tileFlags ? dim3(expectNothing ? 64u : (unsigned)std::max(tilesX * tilesY, kShareBelow * kFallbackParts), 1, 1)
@@ -3242,7 +3251,7 @@ hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const 
         hipLaunchKernelGGL(kernel, grid, dim3(kNT), 0, s,
                            (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch,
                            (int8_t *)mv.data, (int)mv.pitch, (int)curr.width, (int)curr.height, tileFlags, rank2scan,
-                           merge, flaggedTiles, tilesX, tilesX * tilesY, fused, verdictWord);
+                           merge, flaggedTiles, tilesX, tilesX * tilesY, fused, verdictWord, hostWord);
     };
     const bool loops = tileFlags != nullptr && expectNothing;
     if (fused.data) { if (loops) launch(motion_tiled_8_16_loop_kernel<true>); else launch(motion_tiled_8_16_kernel<true>); }
@@ -3924,11 +3933,12 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
     return hipSuccess;
 #endif
     e = launch_motion_tiled_8_16(s, prev, curr, mv, flags, rank2scan, reinterpret_cast<unsigned long long *>(workspace + l.merge),
-                                 sp.queueCount + 1, fused, expectNoFallback && verdictWord != nullptr, verdictWord);
-    // the order kernel's verdict on this call's content (order32[kCand + 2]) for the host, which decides with it whether the lane's
-    // NEXT call goes through the lean kernel: four bytes into pinned memory, behind everything else of the call
-    if (e == hipSuccess && leanFlagHost && useHints && curr.width >= 64u && curr.height >= 64u)
-        e = hipMemcpyAsync(leanFlagHost, order + kCand + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+                                 sp.queueCount + 1, fused, expectNoFallback && verdictWord != nullptr, verdictWord,
+                                 verdictWord ? leanFlagHost : nullptr);
+    // (the order kernel's verdict on this call's content (order32[kCand + 2]) reaches the host -- which decides with it how the lane's
+    //  NEXT call is launched -- by a store of that last launch into the host's pinned word; until round 4's end a copy command
+    //  behind the call, a dispatch of its own on the lane's stream: without it the pan is where it was, stills, moving objects and
+    //  occlusions +0.5 %)
     return e;
 }
 
