@@ -55,6 +55,12 @@ bool HipContext::InitComm(int ranks, int rank, const std::string& idFile, uint64
         LOG_ERROR("HipContext::InitComm: context not initialized");
         return false;
     }
+    // (several ranks need a nonce of their run: with the default 0 a rank that opens an earlier run's nonce-0 file before rank 0
+    //  has removed it would join a communicator that no longer exists and sit in ncclCommInitRank until the watchdog)
+    if (ranks > 1 && nonce == 0) {
+        LOG_ERROR("HipContext::InitComm: ", ranks, " ranks need a non-zero run nonce (--comm-nonce / LFG_COMM_NONCE: the same number for every rank of one run)");
+        return false;
+    }
     lfg_comm_id id{};
     if (rank == 0) {
         (void)remove(idFile.c_str());                                  // a stale id of an earlier run

@@ -29,7 +29,7 @@ static void PrintUsage() {
               << "                           One process per GPU (BASELINE config 4): the batch shares its previous frame\n"
               << "                           (synthetic stream 0, captured on rank 0, broadcast over RCCL per frame); each\n"
               << "                           rank's current frames are its own stream.  FILE carries the communicator id.\n"
-              << "  --comm-nonce N           A number the launcher gives every rank of ONE run (default: LFG_COMM_NONCE, else 0): an\n"
+              << "  --comm-nonce N           A number the launcher gives every rank of ONE run (default: LFG_COMM_NONCE, else 0; more than one rank needs a non-zero one): an\n"
               << "                           id file left behind by another run is then never joined\n"
               << "  --frames N               Number of input frames to process (default: 10)\n"
               << "  --device N               HIP device ordinal (default: 0)\n"

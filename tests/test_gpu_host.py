@@ -128,6 +128,17 @@ def run_host(args):
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
+def test_several_ranks_need_a_run_nonce(host_binary, tmp_path):
+    """Without a nonce of its run a rank > 0 could join an earlier run's communicator id (nonce 0 in a stale file) and wait in
+    ncclCommInitRank until the watchdog: more than one rank without --comm-nonce / LFG_COMM_NONCE is refused at once."""
+    env = {k: v for k, v in os.environ.items() if k != "LFG_COMM_NONCE"}
+    out = subprocess.run([HOST, "--input-width", "64", "--input-height", "36", "--output-width", "128", "--output-height", "72",
+                          "--frames", "1", "--quiet", "--ranks", "2", "--rank", "1", "--comm-file", str(tmp_path / "comm.id")],
+                         capture_output=True, text=True, timeout=60, env=env)
+    assert out.returncode != 0
+    assert "nonce" in (out.stderr + out.stdout)
+
+
 def _presented(tmp_path, w, h, mode_args, frames=4):
     d = tmp_path / ("dump_" + ("_".join(a.strip("-") for a in mode_args) if mode_args else "default") + f"_{frames}")
     d.mkdir()

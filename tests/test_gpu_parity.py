@@ -1023,6 +1023,35 @@ def test_interpolate_frames_in_the_north_star_order(ctx, oracle):
             ctx.destroy_frame(f)
 
 
+def test_north_star_order_with_frames_in_flight():
+    """The fused order on a context with three lanes (its own work-unit plan, the lanes' workspaces, the launches sized by each
+    lane's previous call): the generated frame is, byte for byte, the two stages' on every lane -- a pan, a mixture of content
+    kinds, and the pan again, so that a lane's verdict from one content meets the next."""
+    from linux_fg_amd import capi
+    w, h = 1920, 1080
+    base = synth.make_prev(w, h, seed=5300)
+    pairs = [(base, synth.translate(base, (4, -3), 5301)), _mixed_pair(w, h, 5302), (base, synth.translate(base, (4, -3), 5301))]
+    c = capi.Context(0)
+    try:
+        c.lanes(3)
+        for k, (prev, curr) in enumerate(pairs * 2):
+            c.lane_select(k % 3)
+            p, q = c.frame_from(prev), c.frame_from(curr)
+            a, b = c.create_frame(w, h), c.create_frame(w, h)
+            c.set_fused_motion_interpolate(False)
+            c.interpolate_frames(p, q, a, 0.5)
+            c.set_fused_motion_interpolate(True)
+            c.upload(b, np.full((h, w, 4), 0xA5, np.uint8))
+            c.interpolate_frames(p, q, b, 0.5)
+            c.set_fused_motion_interpolate(False)
+            assert (c.download(a) == c.download(b)).all(), (k, k % 3)
+            for f in (p, q, a, b):
+                c.destroy_frame(f)
+        c.lane_select(0)
+    finally:
+        c.close()
+
+
 def test_three_stage_path_small(ctx, oracle):
     """north_star order at small size: scale(prev), scale(curr) -> motion -> interpolate, each stage
     fed with the DEVICE result of the previous one; oracle chained the same way from the device's
