@@ -8,7 +8,9 @@ context with frames in flight); the round's final library (lattice walks in four
 arithmetic, thresholds written late, kernels templated for the north-star order): 0 differences in 400 + 240 cases; round 4's
 final library (lean kernel incl. the rim tiles' inner segments, row band, eight-point and SAD four-point walks, heads of two
 entries, handed-over segments in four parts with frames in flight): 0 differences in 300 cases one frame at a time, 200 with
-LFG_FUZZ_LANES=3 and 160 with LFG_FUZZ_LANES=3 LFG_LEAN_FORCE=1 (every call through the lean kernel)."""
+LFG_FUZZ_LANES=3 and 160 with LFG_FUZZ_LANES=3 LFG_LEAN_FORCE=1 (every call through the lean kernel); and again behind the
+launches sized by the lane's previous call (persistent grid, resolve grid, the looping fallback pass): 200 with LFG_FUZZ_LANES=3,
+120 without, no differences."""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
