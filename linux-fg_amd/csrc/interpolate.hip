@@ -281,6 +281,41 @@ __global__ __launch_bounds__(256, N == 1 ? LFG_INTERP_WAVES : LFG_INTERP_WAVES_M
         }
     }
 
+#ifndef LFG_INTERP_SURE_OUT
+#define LFG_INTERP_SURE_OUT 1
+#endif
+    // Under the literal semantics (F5) a vector is added to the NORMALISED coordinate in pixels: a component with |m * scale| >= 1
+    // puts the sample outside [0,1] wherever the pixel lies -- uv is at least 0.5 / size above 0 and below 1, far more than an
+    // ulp of 1, and rounding is monotone: uv + d > 1 for d >= 1, uv + d < 0 for d <= -1 -- so the pixel is (0,0,0,0) without its
+    // coordinate ever being computed.  A quad whose four pixels are like that for both samples and every factor stores its zeros
+    // and is done: the benchmark's pan (3 texels of displacement at t = 0.5) from 17.5 us a 4K frame towards what reading the
+    // vectors and writing the frame costs.  (The same products as sample_inside: m * scale in fp32, scale = -t and 1 - t.)
+    if (LFG_INTERP_SURE_OUT && !INTENDED && !zero) {
+        bool allOut = true;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const float t = tg.t[k], sa = -t, sb = 1.0f - t;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float mx = (float)m[2 * i], my = (float)m[2 * i + 1];
+                const bool outA = __builtin_fabsf(mx * sa) >= 1.0f || __builtin_fabsf(my * sa) >= 1.0f;
+                const bool outB = __builtin_fabsf(mx * sb) >= 1.0f || __builtin_fabsf(my * sb) >= 1.0f;
+                allOut = allOut && outA && outB;
+            }
+        }
+        if (allOut) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                uint8_t *orow = tg.out[k] + (size_t)py * (size_t)tg.pitch[k];
+                if (full) {
+                    *reinterpret_cast<uint4 *>(orow + (size_t)px0 * 4u) = uint4{0u, 0u, 0u, 0u};
+                } else {
+                    for (int i = 0; i < 4 && px0 + i < W; ++i) *reinterpret_cast<uint32_t *>(orow + (size_t)(px0 + i) * 4u) = 0u;
+                }
+            }
+            return;
+        }
+    }
     // ((float)p + 0.5f) / (float)size, interpolate.comp:30, from the host's tables (lfg_internal.hpp: UvTable; the tables are
     // padded to whole groups of four)
     const float uvy = uv_of(py, H, tb.rcpH, tb.rcpExact, tb.uvy);
