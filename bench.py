@@ -811,10 +811,10 @@ def main():
     rim_split, prefilter_groups = ctx.motion_plan()
     stage_pass = {"plan_rim_split": rim_split, "prefilter_workgroups": prefilter_groups, "lanes_of_the_context": n_lanes,
                   # (lfg_capi.cpp, motion_run: with frames in flight a call whose lane's previous call found most sample blocks matched
-                  #  launches 5/8 of the persistent workgroups the device holds -- more units per workgroup, room for the other lanes'
-                  #  kernels: +4 % frames/s, and a call measured ALONE on such a lane, as below, is that much longer than on a context
-                  #  that runs one frame at a time)
-                  "prefilter_workgroups_launched_with_frames_in_flight": (prefilter_groups * 5 // 8) if n_lanes > 1 else prefilter_groups,
+                  #  launches 5/8 of the persistent workgroups the device holds WHILE ANOTHER LANE IS BUSY -- more units per workgroup,
+                  #  room for the other lanes' kernels: +4 % frames/s; a call that has the device to itself, as in the pass below, takes
+                  #  them all)
+                  "prefilter_workgroups_launched_beside_other_lanes": (prefilter_groups * 5 // 8) if n_lanes > 1 else prefilter_groups,
                   "how": ("events around every stage call inside the timed regions (one frame at a time: nothing overlaps)" if n_lanes == 1 and args.workload != "scale" else
                           "a second pass, one call at a time on lane 0 of the SAME context as the timed regions, event-bracketed: the same "
                           f"work-unit plan (rim segments in {'4 parts' if rim_split == 4 else '4 parts, 8 at the top and bottom border' if rim_split == 48 else '8 parts'}) "

@@ -218,7 +218,7 @@ int  lfg_motion_workspace_size(lfg_context *ctx, uint32_t width, uint32_t height
  * 48 = four, and eight for the segments at the top and bottom border, when one frame runs at a time (the longest unit counts);
  * LFG_MOTION_RIM_SPLIT=4|8|48 in the environment at context creation overrides -- and *out_workgroups = the persistent
  * workgroups the device holds for its prefilter launch (0 before the first call; with frames in flight a call launches 5/8 of
- * them when the lane's previous call found most of its sample blocks matched: room for the other lanes' kernels).  The plan changes only inside lfg_lanes(); the first lfg_motion
+ * them when the lane's previous call found most of its sample blocks matched and another lane is busy: room for their kernels).  The plan changes only inside lfg_lanes(); the first lfg_motion
  * after such a change re-plans (it waits for the lane's stream once).  Reporting only; either pointer may be NULL. */
 int  lfg_motion_plan(const lfg_context *ctx, int *out_rim_split, int *out_workgroups);
 

@@ -769,7 +769,12 @@ static int motion_run(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *
         if (ctx->lean_ev_pending && hipEventQuery(ctx->lean_ev) == hipSuccess) { ctx->lean_predict = (int)*ctx->lean_flag; ctx->lean_ev_pending = false; ctx->lean_seen = true; }
         if (const char *f = getenv("LFG_LEAN_FORCE")) ctx->lean_predict = (ctx->lean_predict & ~1) | (atoi(f) & 1);          // (measurement: 1 = every call, 0 = none)
         ctx->motion_ws_layout.lastLean = (leanPossible && ctx->motion_ws_layout.leanCount > 0 && (ctx->lean_predict & 1) != 0 && !fo.data && lfg::lean_frames_ok(*prev, *curr, *mv)) ? 1 : 0;
-        const int groupsCap = (flagWanted && ((uint32_t)ctx->lean_predict >> 31) != 0u) ? std::max(1, ctx->motion_slots * 5 / 8) : 0;
+        // (only while another lane has work queued or running -- a stream query each: a call that has the device to itself takes the
+        //  full grid, and is as long as on a context without lanes)
+        bool othersBusy = false;
+        for (size_t j = 0; j < ctx->lanes.size() && !othersBusy; ++j)
+            if ((int)j != ctx->lane && ctx->lanes[j].stream && hipStreamQuery(ctx->lanes[j].stream) == hipErrorNotReady) othersBusy = true;
+        const int groupsCap = (flagWanted && othersBusy && ((uint32_t)ctx->lean_predict >> 31) != 0u) ? std::max(1, ctx->motion_slots * 5 / 8) : 0;
         // ... and bit 30 whether that call sent a tile through the literal kernel (flat content under a fade, exact ties): if not, this
         // call's fallback launch is 64 workgroups instead of 2,048 -- they take whatever it flags after all, in turns (1.4 % of the
         // frame rate under a pan: workgroups of 42 KB of LDS that read a count and leave still have to be placed)
