@@ -269,7 +269,7 @@ int ensure_motion_workspace(lfg_context *ctx, uint32_t width, uint32_t height) {
     lfg::MotionWorkspaceLayout layout;
     if (ctx->motion_slots == 0) {
         ctx->motion_slots = lfg::prefilter_slots();
-        if (getenv("LFG_DEBUG")) fprintf(stderr, "lfg: motion prefilter: %d workgroups resident at once\n", ctx->motion_slots);
+        if (ctx->knobs.debug) fprintf(stderr, "lfg: motion prefilter: %d workgroups resident at once\n", ctx->motion_slots);
     }
     const size_t bytes = lfg::motion_workspace_bytes(width, height, ctx->motion_slots, rimSplit, rimSplit2, &layout);
     if (bytes > ctx->motion_ws_bytes) {
@@ -388,10 +388,19 @@ LFG_EXPORT int lfg_context_create(int device_ordinal, lfg_context **out_ctx) {
     ctx->tables.reserve(17);                 // AxisTable pointers handed out stay valid
     if (const char *m = getenv("LFG_MOTION_HINTS")) ctx->motion_hints = atoi(m) != 0;
     if (const char *m = getenv("LFG_MOTION_LEAN")) ctx->motion_lean = atoi(m) != 0;
-    if (const char *m = getenv("LFG_MOTION_RIM_SPLIT")) { const int v = atoi(m); if (v == 4 || v == 8 || v == 48 || v == 88) ctx->rim_split_env = v; }
+    if (const char *m = getenv("LFG_MOTION_RIM_SPLIT")) { const int v = atoi(m); if (v == 4 || v == 8 || v == 48) ctx->rim_split_env = v; }
     if (const char *m = getenv("LFG_FUSED_INTERPOLATE_SCALE")) ctx->fuse_interpolate_scale = atoi(m) != 0;
     if (const char *m = getenv("LFG_FUSED_MOTION_INTERPOLATE")) ctx->fuse_motion_interpolate = atoi(m) != 0;
     if (const char *m = getenv("LFG_MOTION_MODE")) ctx->motion_mode = atoi(m) == 1 ? LFG_MOTION_EXACT_ONLY : LFG_MOTION_PREFILTERED;
+    // measurement knobs (lfg_internal.hpp: MotionKnobs): here and nowhere else -- no call reads the environment
+    if (const char *m = getenv("LFG_LEAN_FORCE")) ctx->knobs.leanForce = atoi(m) & 1;
+    if (getenv("LFG_FALLBACK_FULL")) ctx->knobs.fallbackFull = 1;
+    if (const char *m = getenv("LFG_DYN_PARTS_RT")) ctx->knobs.dynParts = atoi(m);
+    if (const char *m = getenv("LFG_PREF_GROUPS")) ctx->knobs.prefGroups = atoi(m);
+    if (const char *m = getenv("LFG_RESOLVE_GROUPS")) ctx->knobs.resolveGroups = atoi(m);
+    if (getenv("LFG_DEBUG")) ctx->knobs.debug = 1;
+    if (getenv("LFG_DEBUG_DYN")) ctx->knobs.debugDyn = 1;
+    if (const char *m = getenv("LFG_DEBUG_DYN_DEEP")) ctx->knobs.debugDynDeep = atoi(m);
     *out_ctx = ctx;
     return LFG_OK;
 }
@@ -767,7 +776,7 @@ static int motion_run(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *
             LFG_HIP(ctx, hipEventCreateWithFlags(&ctx->lean_ev, hipEventDisableTiming));
         }
         if (ctx->lean_ev_pending && hipEventQuery(ctx->lean_ev) == hipSuccess) { ctx->lean_predict = (int)*ctx->lean_flag; ctx->lean_ev_pending = false; ctx->lean_seen = true; }
-        if (const char *f = getenv("LFG_LEAN_FORCE")) ctx->lean_predict = (ctx->lean_predict & ~1) | (atoi(f) & 1);          // (measurement: 1 = every call, 0 = none)
+        if (ctx->knobs.leanForce >= 0) ctx->lean_predict = (ctx->lean_predict & ~1) | ctx->knobs.leanForce;          // (measurement: 1 = every call, 0 = none)
         ctx->motion_ws_layout.lastLean = (leanPossible && ctx->motion_ws_layout.leanCount > 0 && (ctx->lean_predict & 1) != 0 && !fo.data && lfg::lean_frames_ok(*prev, *curr, *mv)) ? 1 : 0;
         // (only while another lane has work queued or running -- a stream query each: a call that has the device to itself takes the
         //  full grid, and is as long as on a context without lanes)
@@ -778,11 +787,11 @@ static int motion_run(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *
         // ... and bit 30 whether that call sent a tile through the literal kernel (flat content under a fade, exact ties): if not, this
         // call's fallback launch is 64 workgroups instead of 2,048 -- they take whatever it flags after all, in turns (1.4 % of the
         // frame rate under a pan: workgroups of 42 KB of LDS that read a count and leave still have to be placed)
-        const bool expectNoFallback = flagWanted && ctx->lean_seen && (((uint32_t)ctx->lean_predict >> 30) & 1u) == 0u && !getenv("LFG_FALLBACK_FULL") /* (measurement) */;
+        const bool expectNoFallback = flagWanted && ctx->lean_seen && (((uint32_t)ctx->lean_predict >> 30) & 1u) == 0u && !ctx->knobs.fallbackFull /* (measurement) */;
         e = lfg::launch_motion_prefiltered_8_16(ctx->stream, *prev, *curr, *mv, ctx->motion_ws, ctx->motion_ws_layout, ctx->motion_units,
                                                 rank2scan, order32, order32 + lfg::kMotionTableWords,
                                                 ctx->motion_tables + 6 * lfg::kMotionTableWords, ctx->motion_hints, ctx->lanes.size() >= 2, fo,
-                                                ctx->motion_ws_layout.lastLean != 0, (flagWanted && !ctx->lean_ev_pending) ? ctx->lean_flag : nullptr, groupsCap, expectNoFallback);
+                                                ctx->motion_ws_layout.lastLean != 0, (flagWanted && !ctx->lean_ev_pending) ? ctx->lean_flag : nullptr, groupsCap, expectNoFallback, ctx->knobs);
         if (e == hipSuccess && flagWanted && !ctx->lean_ev_pending && !fo.data) { e = hipEventRecord(ctx->lean_ev, ctx->stream); ctx->lean_ev_pending = true; }
     }
     else if (tiled) e = lfg::launch_motion_tiled_8_16(ctx->stream, *prev, *curr, *mv, nullptr, rank2scan, nullptr, nullptr, fo);
@@ -836,7 +845,7 @@ LFG_EXPORT int lfg_motion_open_segments(lfg_context *ctx, uint32_t *out_open, ui
     LFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t tx = (ctx->motion_ws_w + 55u) / 56u, ty = (ctx->motion_ws_h + 63u) / 64u;      // (prefilter tiles: 56 x 64 pixels)
     uint32_t open = 0;
-    LFG_HIP(ctx, hipMemcpy(&open, ctx->motion_ws + ctx->motion_ws_layout.ctrl + 4 * sizeof(uint32_t), sizeof(uint32_t), hipMemcpyDeviceToHost));
+    LFG_HIP(ctx, hipMemcpy(&open, ctx->motion_ws + ctx->motion_ws_layout.ctrl + lfg::kCtrlOpenCount * sizeof(uint32_t), sizeof(uint32_t), hipMemcpyDeviceToHost));
     *out_open = open;
     *out_segments = tx * ty * 4u;
     return LFG_OK;
@@ -850,7 +859,7 @@ LFG_EXPORT int lfg_motion_lean_stats(lfg_context *ctx, int *out_used, uint32_t *
     if (!ctx->motion_ws || ctx->motion_ws_w == 0) return fail(ctx, LFG_ERR_INVALID, "lfg_motion_lean_stats: the prefiltered path has not run");
     LFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     uint32_t left = 0;
-    LFG_HIP(ctx, hipMemcpy(&left, ctx->motion_ws + ctx->motion_ws_layout.ctrl + 5 * sizeof(uint32_t), sizeof(uint32_t), hipMemcpyDeviceToHost));
+    LFG_HIP(ctx, hipMemcpy(&left, ctx->motion_ws + ctx->motion_ws_layout.ctrl + lfg::kCtrlHardCount * sizeof(uint32_t), sizeof(uint32_t), hipMemcpyDeviceToHost));
     *out_used = ctx->motion_ws_layout.lastLean;
     *out_tiles = (uint32_t)ctx->motion_ws_layout.leanCount;
     *out_tiles_left = ctx->motion_ws_layout.lastLean ? left : 0u;
@@ -867,19 +876,19 @@ LFG_EXPORT int lfg_motion_last_stats(lfg_context *ctx, uint32_t *out_tiles, uint
     LFG_HIP(ctx, hipMemcpy(flags.data(), ctx->motion_ws + ctx->motion_ws_layout.tileFlags, flags.size() * 4, hipMemcpyDeviceToHost));
     uint32_t fb = 0;
     for (uint32_t f : flags) fb += f != 0u;
-    if (getenv("LFG_DEBUG")) {
+    if (ctx->knobs.debug) {
         uint32_t handed[2] = {0, 0};
         LFG_HIP(ctx, hipMemcpy(handed, ctx->motion_ws + ctx->motion_ws_layout.queueCount, 8, hipMemcpyDeviceToHost));
         fprintf(stderr, "lfg: motion prefilter: %u requests to hand a segment over (room for %d), %u tiles flagged for the exact kernel\n",
                 handed[0], ctx->motion_ws_layout.queueCap, handed[1]);
         uint32_t lean[2] = {0, 0};
-        LFG_HIP(ctx, hipMemcpy(lean, ctx->motion_ws + ctx->motion_ws_layout.ctrl + 6 * sizeof(uint32_t), 8, hipMemcpyDeviceToHost));
+        LFG_HIP(ctx, hipMemcpy(lean, ctx->motion_ws + ctx->motion_ws_layout.ctrl + lfg::kCtrlLeanSettled * sizeof(uint32_t), 8, hipMemcpyDeviceToHost));
         uint32_t flags[3] = {0, 0, 0};
-        LFG_HIP(ctx, hipMemcpy(flags, ctx->motion_ws + ctx->motion_ws_layout.order + (256 + 1089) * sizeof(uint32_t), 12, hipMemcpyDeviceToHost));
+        LFG_HIP(ctx, hipMemcpy(flags, ctx->motion_ws + ctx->motion_ws_layout.orderFlags, 12, hipMemcpyDeviceToHost));
         fprintf(stderr, "lfg: lean kernel: %d tiles listed, %u segments settled, %u left to the generic kernel (counted in -DLFG_LEAN_STATS builds); order flags: hand-over %u, hints %u, lean %u (sample blocks with a close match %u, with an exact one %u)\n",
                 ctx->motion_ws_layout.leanCount, lean[0], lean[1], flags[0], flags[1], flags[2] & 1u, (flags[2] >> 1) & 0x7FFu, (flags[2] >> 12) & 0x7FFFFu);
     }
-    if (getenv("LFG_DEBUG_DYN")) {       // the deepest private lists of the handed-over segments: block (4 x queue slot + wave), pixel, records
+    if (ctx->knobs.debugDyn) {       // the deepest private lists of the handed-over segments: block (4 x queue slot + wave), pixel, records
         uint32_t handed[2] = {0, 0};
         LFG_HIP(ctx, hipMemcpy(handed, ctx->motion_ws + ctx->motion_ws_layout.queueCount, 8, hipMemcpyDeviceToHost));
         const size_t blocks = (size_t)std::min<uint32_t>(handed[0], (uint32_t)ctx->motion_ws_layout.queueCap) * 4u, per = 16u * 56u;
@@ -887,7 +896,7 @@ LFG_EXPORT int lfg_motion_last_stats(lfg_context *ctx, uint32_t *out_tiles, uint
         if (!dc.empty()) LFG_HIP(ctx, hipMemcpy(dc.data(), ctx->motion_ws + ctx->motion_ws_layout.dynCount, dc.size() * 4, hipMemcpyDeviceToHost));
         size_t hist[40] = {0};
         int dumped = 0;
-        const uint32_t deep = getenv("LFG_DEBUG_DYN_DEEP") ? (uint32_t)atoi(getenv("LFG_DEBUG_DYN_DEEP")) : 14u;
+        const uint32_t deep = (uint32_t)ctx->knobs.debugDynDeep;
         for (size_t i = 0; i < dc.size(); ++i) {
             ++hist[std::min<uint32_t>(dc[i], 39u)];
             if (dc[i] > deep) {
@@ -933,7 +942,7 @@ LFG_EXPORT int lfg_motion_last_stats(lfg_context *ctx, uint32_t *out_tiles, uint
         for (int k = 0; k < 40; ++k) if (hist[k]) fprintf(stderr, " %d:%zu", k, hist[k]);
         fprintf(stderr, "\n");
     }
-    if (getenv("LFG_DEBUG"))
+    if (ctx->knobs.debug)
         for (size_t i = 0; i < flags.size(); ++i)
             if (flags[i]) fprintf(stderr, "lfg: motion fallback tile (%zu, %zu)\n", i % tx, i / tx);
     if (out_tiles) *out_tiles = tx * ty;

@@ -78,7 +78,32 @@ struct FusedOut {
     int storeMv = 1;              // 0: the caller has no use for the vectors (lfg_interpolate_frames' temporary)
 };
 
-struct MotionWorkspaceLayout { size_t list, umin, count, tileFlags, segDone, segMap, queueCount, ctrl, order, plan, auxList, auxUmin, auxCount,
+// Words of a call's control area (MotionWorkspaceLayout::ctrl), cleared by the hint kernel with the rest of the area.
+enum MotionCtrlWord : int {
+    kCtrlNextUnit = 0,        // next plan unit to draw
+    kCtrlUnitsDone = 1,       // plan units finished (only a running plan unit can push onto the queue)
+    kCtrlNextSlot = 2,        // next queue slot to draw
+    kCtrlOpenCount = 4,       // segments left to the resolve kernel (the length of openList)
+    kCtrlHardCount = 5,       // tiles in which the lean kernel left a segment (the length of hardTiles)
+    kCtrlLeanSettled = 6,     // segments the lean kernel settled / left: counted in -DLFG_LEAN_STATS builds only
+    kCtrlLeanLeft = 7,
+};
+
+// Measurement knobs, read ONCE from the environment when a context is created (lfg_context_create) and never again: a call's
+// launch geometry cannot change between two lfg_motion calls because somebody called setenv.  All of them are for A/B runs of
+// tools/; none changes a result.
+struct MotionKnobs {
+    int leanForce = -1;       // LFG_LEAN_FORCE = 1: every call through the lean kernel whatever the verdict, 0: none, unset: by the verdict
+    int fallbackFull = 0;     // LFG_FALLBACK_FULL: the second pass always on its full grid
+    int dynParts = 0;         // LFG_DYN_PARTS_RT = 4 | 8: parts of a handed-over segment, whatever the lane count
+    int prefGroups = 0;       // LFG_PREF_GROUPS: workgroups of the persistent kernel
+    int resolveGroups = 0;    // LFG_RESOLVE_GROUPS: workgroups of the resolve kernel
+    int debug = 0;            // LFG_DEBUG: reporting calls print what they read
+    int debugDyn = 0;         // LFG_DEBUG_DYN: lfg_motion_last_stats prints the deepest private lists of the handed-over segments,
+    int debugDynDeep = 14;    // LFG_DEBUG_DYN_DEEP: ... deeper than this
+};
+
+struct MotionWorkspaceLayout { size_t verdict /* byte offset of the call's verdict word, order32[kCand + 2] of its own order table; orderFlags: of [kCand] */, orderFlags; size_t list, umin, count, tileFlags, segDone, segMap, queueCount, ctrl, order, plan, auxList, auxUmin, auxCount,
                                queue, dynList, dynUmin, dynCount, dynInit, openList, merge, mergeBytes, leanTiles, hardTiles, plan2, total; int queueCap, slots, rimSplit, listMain, listAux, listDyn, leanCount, leanLaunch /* with the partial tiles behind them */, rimSplit2, units, units2, units2Static /* the second plan's units without the lean kernel's tiles, which come last in its table */, tiles, lastLean /* the lane's last call went by the second plan */; };
 // Work units of the motion prefilter (motion.hip: prefilter_plan).  A unit is a 56 x 64 tile, or one of nChunks
 // contiguous parts of a tile's candidate order, or one 16-row segment of a tile with its four waves on four parts of
@@ -176,6 +201,7 @@ struct lfg_context {
     bool fuse_motion_interpolate = false;      // lfg_interpolate_frames: the motion kernels write the generated frame themselves
     bool motion_hints = true;                  // per-call visiting order from sample-block hints (LFG_MOTION_HINTS=0: off)
     bool motion_lean = true;                   // whole interior tiles go through the lean kernel first (LFG_MOTION_LEAN=0: off)
+    lfg::MotionKnobs knobs;                    // measurement knobs, read once at creation
     // the one exchange of the path (lfg_comm.cpp): an RCCL communicator, its stream and two events
     void *comm = nullptr;                      // ncclComm_t
     int comm_ranks = 0, comm_rank = 0;
@@ -220,7 +246,15 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
                                           const uint32_t *entryOfScan, const uint32_t *baseScan, bool useHints, bool framesInFlight,
                                           const FusedOut &fused = FusedOut(), bool lean = false, uint32_t *leanFlagHost = nullptr,
                                           int groupsCap = 0 /* persistent workgroups at most (0: as many as the device holds) */,
-                                          bool expectNoFallback = false /* the lane's previous call flagged no tile: a small fallback launch */);
+                                          bool expectNoFallback = false /* the lane's previous call flagged no tile: a small fallback launch */,
+                                          const MotionKnobs &knobs = MotionKnobs());
+// This call's visiting order (motion_order.hip): hint kernel (which also clears the call's control area) + order kernel.
+hipError_t launch_motion_order(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr, uint32_t *hints, uint32_t *callOrder,
+                               const uint32_t *entryOfScan, const uint32_t *baseScan, uint32_t *clearFrom, int clearWords, bool framesInFlight);
+// The literal chain for what the prefilter left open (motion_resolve.hip); list / umin / count: the image-shaped arrays.
+hipError_t launch_motion_resolve(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv, const uint32_t *list,
+                                 const float *umin, const uint32_t *count, const uint32_t *tileFlags, int tilesX, const PrefilterPlan &sp,
+                                 const uint32_t *rank2scan, const uint32_t *segDone, int groups);
 // The lean kernel for whole interior tiles (motion_lean.hip): runs between the order kernel and the generic prefilter, marks the
 // segments it settles in segDone; the generic kernel skips those.
 bool lean_tile_ok(int tile, int tilesX, int W, int H);
