@@ -87,6 +87,8 @@ def parse_args():
     ap.add_argument("--semantics", choices=["reference", "intended"], default="reference",
                     help="reference (default): the shaders as written, the parity contract; intended: the opt-in lfg_set_semantics mode (vectors displace by "
                          "pixels, ties resolve to the shortest vector) -- a labelled variant, never the headline")
+    ap.add_argument("--stream", action="store_true",
+                    help="only the changing-stream measurement (extras.stream; see measure_stream): K = 12 distinct pairs whose content changes every three steps")
     ap.add_argument("--no-extras", action="store_true", help="skip scale_only / scale_interpolate / content_sweep (profiling runs)")
     return ap.parse_args()
 
@@ -214,27 +216,62 @@ def pmc_traffic(prefix="lfg::"):
     return int(total), src
 
 
+def valu_cost_weights():
+    """{kernel name: mean issue cost of one of its VALU wave-instructions, in plain-op units} from the newest committed
+    profiles/r*_valu_cost_weights.txt (tools/valu_cost_histogram.py: the kernel's STATIC opcode histogram x the guide's issue
+    costs) taken from the loaded library; {} otherwise."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_cost_weights.txt")))
+    if not files:
+        return {}, None
+    sha, w = None, {}
+    for line in open(files[-1]):
+        t = line.split()
+        if line.startswith("# lib_sha16"):
+            sha = t[2]
+        elif t and t[0] == "kernel":
+            w[t[1]] = float(t[t.index("mean_cost") + 1])
+    if sha != library_sha16():
+        return {}, f"{os.path.relpath(files[-1], ROOT)} was made from library {sha}, not the loaded one"
+    return w, os.path.relpath(files[-1], ROOT)
+
+
 def pmc_executed(prefix="lfg::motion_"):
     """What the kernels whose names start with `prefix` executed per pipeline step, from the newest committed SQ
     counter table: wave-level VALU / LDS / SALU instruction counts, and the share of the chip's VALU issue slots they
-    filled while they ran (4 cycles per VALU wave-instruction, 1024 SIMDs, 2.4 GHz peak clock).  None if unusable."""
+    filled while they ran -- under THREE stated conventions: a SIMD-32 issues a plain wave64 VALU instruction in
+    2 cycles once two waves are resident (MI355X_MICROARCH.md:54, the rate 157.3 TFLOP/s corresponds to): un-weighted, and
+    weighted by the kernel's static opcode mix (transcendentals and packed f32 twice a plain op: valu_cost_weights); and the
+    4 cycles per instruction that ONE wave alone sustains (round 4's figure, kept for comparison).  None if unusable."""
     table, src, why = read_profile("r*_sq_counters.txt")
     if table is None:
         return None
-    valu = lds = salu = us = 0.0
+    weights, wsrc = valu_cost_weights()
+    valu = lds = salu = us = weighted = 0.0
+    have_w = bool(weights)
     for k, v in table["kernels"].items():
         if k.startswith(prefix) and "SQ_INSTS_VALU" in v:
             n = v["launches_per_step"]
             valu += v["SQ_INSTS_VALU"] * n; lds += v.get("SQ_INSTS_LDS", 0.0) * n; salu += v.get("SQ_INSTS_SALU", 0.0) * n
             us += v["mean_us"] * n
+            wk = next((w for name, w in weights.items() if name.startswith(k) or k.startswith(name)), None)
+            have_w = have_w and wk is not None
+            weighted += v["SQ_INSTS_VALU"] * n * (wk or 1.0)
     if us <= 0:
         return None
-    slots = us * 1e-6 * 2.4e9 * 1024
-    return {"source": src, "kernels": prefix + ("*" if prefix.endswith("_") else ""), "kernel_us_per_step_in_that_pass": round(us, 2),
-            "valu_wave_instructions": valu, "lds_wave_instructions": lds, "salu_wave_instructions": salu,
-            "valu_issue_utilisation": round(valu * 4.0 / slots, 3),
-            "how": "VALU wave-instructions x 4 cycles / (kernel time x 2.4 GHz x 1024 SIMDs): the share of the VALU issue "
-                   "slots those kernels filled"}
+    cycles = us * 1e-6 * 2.4e9 * 1024
+    out = {"source": src, "kernels": prefix + ("*" if prefix.endswith("_") else ""), "kernel_us_per_step_in_that_pass": round(us, 2),
+           "valu_wave_instructions": valu, "lds_wave_instructions": lds, "salu_wave_instructions": salu,
+           "valu_issue_utilisation_simd32_2_cycles": round(valu * 2.0 / cycles, 3),
+           "valu_issue_utilisation_cost_weighted": round(weighted * 2.0 / cycles, 3) if have_w else None,
+           "valu_issue_utilisation_one_wave_alone_4_cycles": round(valu * 4.0 / cycles, 3),
+           "cost_weights": wsrc,
+           "how": "VALU wave-instructions (SQ_INSTS_VALU) x cycles per instruction / (kernel time x 2.4 GHz x 1024 SIMDs).  simd32_2_cycles: a SIMD-32 issues "
+                  "a plain wave64 VALU instruction in 2 cycles once two waves are resident -- the rate the 157.3 TFLOP/s fp32 peak corresponds to "
+                  "(MI355X_MICROARCH.md:54,:473); cost_weighted: the same, each kernel's count x the mean issue cost of its STATIC opcode mix "
+                  "(transcendental and packed-f32 instructions twice a plain one; tools/valu_cost_histogram.py -- a proxy: the executed mix is not counted); "
+                  "one_wave_alone_4_cycles: what one wave alone sustains, round 4's convention"}
+    return out
 
 
 def rank_motion(rank: int):
@@ -413,6 +450,176 @@ def measure_config5(torch, capi, dev, dev_index, n_lanes, steps=24, contents=("n
     return out
 
 
+STREAM_SEGMENTS = (("translated", 0), ("objects", 1), ("noisy", 2), ("translated", 7))     # (content, rank: its translation -- rank_motion)
+
+
+def measure_stream(torch, capi, dev, dev_index, n_lanes, pairs_per_segment=3, rotations=10):
+    """A stream that CHANGES: K = 12 distinct frame pairs in rotation, three of each segment of
+    STREAM_SEGMENTS -- the pan, moving objects on another pan, sensor noise on a third, a fourth pan -- so that the content a lane's
+    call meets differs from what the lane's previous call found every third step, and the three launch decisions that go by
+    that previous call (lean kernel and plan, persistent grid, second pass: lfg_capi.cpp, motion_run) can be wrong.  Same work per
+    step as `value` (scale -> motion -> interpolate at 1080p -> 4K, n_lanes frames in flight).  Two host loops:
+      paced    before a lane is reused the host waits for that lane's previous frame (lfg_lane_sync) -- what a caller with
+               n frames in flight does; a guess is then at most n calls old;
+      unpaced  the host enqueues as fast as it can, as the headline loop does; a guess can be a whole queue old.
+    Returns frames/s of both, the calls whose verdict came back and how many had been launched on a wrong guess
+    (lfg_motion_prediction_stats), each segment's content alone in the paced loop, the harmonic mean of those (weighted by steps)
+    and `verified`: the LAST step's vectors against the literal kernel, whole frame."""
+    w_in, h_in = SIZES["1080p"]
+    w, h = 2 * w_in, 2 * h_in
+    ctx = capi.Context(dev_index)
+    if n_lanes > 1:
+        ctx.lanes(n_lanes)
+    def frame(width, height, fmt=capi.FORMAT_RGBA8):
+        t = torch.empty((height, width, 4 if fmt == capi.FORMAT_RGBA8 else 2), dtype=torch.uint8, device=dev)
+        return t, capi.Context.wrap(t.data_ptr(), width, height, fmt)
+    from linux_fg_amd import synth
+    pairs = []                                   # (segment, curr_in frame, prev4 frame) + the tensors that keep them alive
+    for seg, (content, crank) in enumerate(STREAM_SEGMENTS):
+        for j in range(pairs_per_segment):
+            # distinct pairs: each its own previous frame (another seed), its current frame derived from it as make_content does
+            seed = (synth.BASE_SEED + 1000003 * (seg * pairs_per_segment + j + 1)) & 0xFFFFFFFF
+            prev_in = synth.make_prev(w_in, h_in, seed)
+            # (make_content derives curr from the shared stream-0 previous frame; here against this pair's own: the same edits)
+            curr_in = prev_in.copy()
+            if content in ("translated", "objects", "noisy"):
+                curr_in = synth.translate(prev_in, rank_motion(crank), seed + 17)
+            if content == "objects":
+                rng = np.random.default_rng(30240 + seg * 16 + j)
+                for _ in range(24):
+                    pw, ph = int(rng.integers(w_in // 60, w_in // 12)), int(rng.integers(h_in // 60, h_in // 12))
+                    x0, y0 = int(rng.integers(40, w_in - 40 - pw)), int(rng.integers(40, h_in - 40 - ph))
+                    dx, dy = int(rng.integers(-7, 8)), int(rng.integers(-7, 8))
+                    curr_in[y0:y0 + ph, x0:x0 + pw] = prev_in[y0 - dy:y0 - dy + ph, x0 - dx:x0 - dx + pw]
+            if content == "noisy":
+                n = synth.noise_bytes(w_in, h_in, (seed + 15485863) & 0xFFFFFFFF) % 5
+                curr_in = np.clip(curr_in.astype(np.int16) + n.astype(np.int16) - 2, 0, 255).astype(np.uint8)
+            tp = torch.from_numpy(prev_in).to(dev); fp = capi.Context.wrap(tp.data_ptr(), w_in, h_in, capi.FORMAT_RGBA8)
+            tc = torch.from_numpy(np.ascontiguousarray(curr_in)).to(dev); fc = capi.Context.wrap(tc.data_ptr(), w_in, h_in, capi.FORMAT_RGBA8)
+            tp4, fp4 = frame(w, h)
+            ctx.scale(fp, fp4)
+            pairs.append((seg, fc, fp4, (tp, tc, tp4)))
+    ctx.sync()
+    lanes = [(frame(w, h), frame(w, h, capi.FORMAT_MV_S8X2), frame(w, h)) for _ in range(n_lanes)]
+
+    def run(order, paced, n_steps):
+        """n_steps steps over the pairs of `order` in rotation; seconds"""
+        ctx.sync(); torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for k in range(n_steps):
+            _, fc, fp4, _ = pairs[order[k % len(order)]]
+            j = k % n_lanes
+            (tc4, fc4), (tm, fm), (to, fo) = lanes[j]
+            if n_lanes > 1:
+                ctx.lane_select(j)
+            if paced and k >= n_lanes:
+                ctx.lane_sync()                                 # frame k - n is done: its buffers are free, its verdict is in
+            if n_lanes > 1:
+                ctx.lane_wait((k - 1) % n_lanes)
+            ctx.scale(fc, fc4)
+            if n_lanes > 1:
+                ctx.lane_mark()
+            ctx.motion(fp4, fc4, fm, 8, 16.0)
+            ctx.interpolate(fp4, fc4, fm, fo, 0.5)
+        ctx.sync(); torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0
+
+    everything = list(range(len(pairs)))
+    n_steps = rotations * len(pairs)
+    out = {"pairs": len(pairs), "segments": [f"{c} (translation of rank {r}: {rank_motion(r)})" for c, r in STREAM_SEGMENTS],
+           "pairs_per_segment": pairs_per_segment, "steps": n_steps, "frames_in_flight": n_lanes}
+    for label, paced in (("paced", True), ("unpaced", False)):
+        run(everything, paced, 2 * len(pairs))
+        before = ctx.motion_prediction_stats()
+        t = run(everything, paced, n_steps)
+        after = ctx.motion_prediction_stats()
+        d = [a - b for a, b in zip(after, before)]
+        out[label] = {"frames_per_s": round(n_steps / t, 1), "ms_per_step": round(t / n_steps * 1e3, 5),
+                      "calls_whose_verdict_came_back": d[0],
+                      "of_which_launched_on_a_wrong_guess": {"lean_kernel_and_plan": d[1], "persistent_grid": d[2], "second_pass_small_grid_but_tiles_flagged": d[3]}}
+    # the last step's vectors (unpaced run: step n_steps - 1) against the literal kernel
+    last = n_steps - 1
+    _, fc, fp4, _ = pairs[everything[last % len(everything)]]
+    (tc4, fc4), (tm, fm), _ = lanes[last % n_lanes]
+    got = tm.cpu().numpy().view(np.int8).copy()
+    tchk, fchk = frame(w, h, capi.FORMAT_MV_S8X2)
+    if n_lanes > 1:
+        ctx.lane_select(0)
+    ctx.set_motion_mode(capi.MOTION_EXACT_ONLY)
+    ctx.motion(fp4, fc4, fchk, 8, 16.0)
+    ctx.set_motion_mode(capi.MOTION_PREFILTERED)
+    ctx.sync()
+    diff = int((got != tchk.cpu().numpy().view(np.int8)).any(-1).sum())
+    out["verified"] = {"step": last, "vectors_vs_literal_kernel": {"pixels": w * h, "differing": diff}, "ok": diff == 0}
+    # every segment's content alone (its own three pairs in rotation), paced: what the stream would run at if nothing were ever guessed wrong
+    alone, weights = {}, {}
+    for seg, (content, crank) in enumerate(STREAM_SEGMENTS):
+        mine = [i for i, p in enumerate(pairs) if p[0] == seg]
+        run(mine, True, 2 * len(mine) * n_lanes)
+        n = max(30, n_steps // 4)
+        t = run(mine, True, n)
+        alone[f"{seg}: {content}"] = round(n / t, 1)
+        weights[f"{seg}: {content}"] = len(mine)
+    hm = sum(weights.values()) / sum(weights[k] / alone[k] for k in alone)
+    out["segments_alone_paced_frames_per_s"] = alone
+    out["harmonic_mean_of_segments_alone"] = round(hm, 1)
+    out["paced_over_harmonic_mean"] = round(out["paced"]["frames_per_s"] / hm, 4)
+    out["how"] = ("K distinct pairs, content changing every %d steps; `paced` waits for a lane's previous frame before reusing the lane (lfg_lane_sync), `unpaced` "
+                  "enqueues ahead like the headline loop; wrong guesses counted by the library for the calls whose verdict word it read back" % pairs_per_segment)
+    ctx.close()
+    return out
+
+
+
+def measure_pcie_inclusive(torch, capi, ctx, dev, w_in, h_in, w, h):
+    """The PCIe-INCLUSIVE second metric of SURVEY.md 8(f) rank 3 -- never `value`.  The reference uploads every captured frame
+    through a staging buffer (src/window_capture.cpp:472-568) and reads every presented frame back (src/scaler.cpp:479-536);
+    here: (a) what the host link gives a pinned 1080p upload and a pinned 4K read-back through the C-ABI, alone; (b) the C++
+    host mirror's loop (linux-fg_amd/lfg_host: Scaler::ProcessFrame with the pinned ring, three frames in flight), which uploads
+    one input frame and reads back TWO 4K frames (real + generated) per input frame -- with the host's frame synthesis in the
+    loop as in round 2's figure (390 presented frames/s), and played back from memory with a presenter that looks at no pixel."""
+    import subprocess
+    out = {"host_link_spec_gbs": 63.0}
+    n_in, n_out = w_in * h_in * 4, w * h * 4
+    pin_in, pin_out = ctx.staging_create(n_in), ctx.staging_create(n_out)
+    t_in = torch.empty((h_in, w_in, 4), dtype=torch.uint8, device=dev); f_in = capi.Context.wrap(t_in.data_ptr(), w_in, h_in, capi.FORMAT_RGBA8)
+    t_out = torch.empty((h, w, 4), dtype=torch.uint8, device=dev); f_out = capi.Context.wrap(t_out.data_ptr(), w, h, capi.FORMAT_RGBA8)
+    def rate(fn, nbytes, n=60):
+        for _ in range(5):
+            fn()
+        ctx.sync(); t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        ctx.sync()
+        return round(nbytes * n / (time.perf_counter() - t0) / 1e9, 2)
+    out["pinned_upload_1080p_gbs"] = rate(lambda: ctx.upload_async(f_in, pin_in), n_in)
+    out["pinned_readback_4k_gbs"] = rate(lambda: ctx.download_async(f_out, pin_out), n_out)
+    ctx.staging_destroy(pin_in); ctx.staging_destroy(pin_out)
+    host = os.path.join(ROOT, "linux-fg_amd", "lfg_host")
+    if not os.path.exists(host):
+        out["host_loop"] = "linux-fg_amd/lfg_host not built"
+        return out
+    def run(extra, frames):
+        cmd = [host, "--input-width", str(w_in), "--input-height", str(h_in), "--output-width", str(w), "--output-height", str(h),
+               "--frames", str(frames), "--in-flight", "3", "--quiet"] + extra
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            return {"error": (r.stderr or r.stdout).strip()[-300:]}
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        per_input = n_in + 2 * n_out                      # one upload, two read-backs per input frame
+        d["readback_gbs"] = round(d["presented_fps"] * n_out / 1e9, 2)
+        d["link_bytes_per_input_frame"] = per_input
+        return {k: d[k] for k in ("input_frames", "presented", "interpolated", "seconds", "presented_fps", "readback_gbs", "link_bytes_per_input_frame", "note")}
+    out["host_loop_with_frame_synthesis"] = run([], 120)
+    out["host_loop_replayed"] = run(["--replay", "8", "--present-null"], 600)
+    out["why"] = ("round 2's 390 presented frames/s (13 GB/s of read-back) was the HOST's synthetic frame source -- a hash and a 4-byte copy per pixel on one "
+                  "core, 5 ms per 1080p frame -- plus a strided checksum over every presented frame, not the link: played back from memory with a presenter that "
+                  "looks at nothing, the same loop is bounded by the two 33 MB read-backs per input frame (`pinned_readback_4k_gbs`)")
+    out["how"] = "subprocess: lfg_host --in-flight 3 (Scaler::ProcessFrame, pinned ring, copy stream); a labelled second metric, never `value`"
+    return out
+
+
+
 def gather_ranks(dist, world, dev_index, rccl_ranks, verified):
     """What rank 0 needs from the other ranks for the line, over the control plane (gloo): which card every rank drove, the size of
     the RCCL communicator every rank joined (the driver checks its N against these), and every rank's check of its own frames."""
@@ -489,7 +696,8 @@ def assemble_line(r):
                 md["executed"] = ex
                 ex_all = pmc_executed("lfg::motion_")
                 if ex_all is not None:
-                    md["executed_all_motion_kernels"] = {k: ex_all[k] for k in ("kernels", "kernel_us_per_step_in_that_pass", "valu_issue_utilisation")}
+                    md["executed_all_motion_kernels"] = {k: ex_all[k] for k in ("kernels", "kernel_us_per_step_in_that_pass", "valu_issue_utilisation_simd32_2_cycles",
+                                                                                "valu_issue_utilisation_cost_weighted", "valu_issue_utilisation_one_wave_alone_4_cycles")}
         if motion_stats is not None:
             md["motion_mode"] = "prefiltered"
             md["fallback_tiles"] = {"of": motion_stats[0], "exact_kernel": motion_stats[1]}
@@ -582,6 +790,11 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from linux_fg_amd import capi, sharding, synth
+
+    if args.stream:                        # the changing-stream measurement alone (the default run carries it in `stream`)
+        print(json.dumps({"stream": measure_stream(torch, capi, dev, dev_index, max(1, min(args.in_flight, capi.MAX_LANES))),
+                          "library_sha16": library_sha16()}), flush=True)
+        return
 
     w_in, h_in = SIZES[args.input]
     w, h = 2 * w_in, 2 * h_in
@@ -992,6 +1205,41 @@ def main():
                                                  "how": "the step every rank runs at N > 1 -- scale(shared previous INPUT frame) + scale(curr) + motion + interpolate -- "
                                                         "on this GPU, without the broadcast: the denominator a scaling curve over N should use"}
             del slots2, bufs2
+        # ---- the opt-in intended semantics (lfg_set_semantics: vectors displace by pixels, ties go to the shortest vector) -- the only
+        # mode whose generated frames mean anything -- on the pan and on moving objects, frames in flight as `value`
+        intended = {}
+        ctx.set_semantics(capi.SEMANTICS_INTENDED)
+        for label in ("translated", "objects"):
+            p_in, c_in = make_content(label, w_in, h_in, 0, 0)
+            tp, fp = dev_frame(p_in)
+            tc, fc = dev_frame(c_in)
+            if n_lanes > 1:
+                ctx.lane_select(0)
+            ctx.scale(fp, f_prev4)
+            timed(lambda k: pipeline_step(k, fc, n_lanes), 4 * n_lanes)
+            n_i = 200
+            t_i = timed(lambda k: pipeline_step(k, fc, n_lanes), n_i)
+            if n_lanes > 1:
+                ctx.lane_select(0)
+            ctx.profile_reset(); ctx.profile_enable(True)
+            timed(lambda k: pipeline_step(k, fc, 1), 40)
+            per = {nm: round(ctx.profile_get(sid)[0] / max(ctx.profile_get(sid)[1], 1), 4)
+                   for nm, sid in (("scale", capi.STAGE_SCALE), ("motion", capi.STAGE_MOTION), ("interpolate", capi.STAGE_INTERPOLATE))}
+            ctx.profile_enable(False)
+            moved = interpolate_bytes_moved(lane_tensors[0][0].cpu().numpy().view(np.int8), factors, intended=True)
+            used, tiles, left = ctx.motion_lean_stats()
+            intended[label] = {"frames_per_s": round(n_i * len(factors) / t_i, 1), "ms_per_step": round(t_i / n_i * 1e3, 5), "steps": n_i,
+                               "stage_ms_one_call_at_a_time": per, "interpolate_bytes_moved": moved,
+                               "lean_kernel": {"used": used, "tiles": tiles, "tiles_left": left}}
+        ctx.set_semantics(capi.SEMANTICS_REFERENCE)
+        if n_lanes > 1:
+            ctx.lane_select(0)
+        ctx.scale(f_prev_in, f_prev4)
+        intended["how"] = ("lfg_set_semantics(INTENDED) on the headline context, same step and frames in flight as `value`; under these semantics interpolate "
+                           "samples displaced texels on every content (no rejected samples), and ties resolve to the shortest vector")
+        extras["intended_semantics"] = intended
+        extras["stream"] = measure_stream(torch, capi, dev, dev_index, n_lanes)
+        extras["pcie_inclusive"] = measure_pcie_inclusive(torch, capi, ctx, dev, w_in, h_in, w, h)
         extras["config5"] = measure_config5(torch, capi, dev, dev_index, n_lanes)
         extras["content_sweep"] = {"frames_per_s_by_content": sweep, "worst_case_frames_per_s": worst,
                                    "note": "same kernels, same results discipline (bit-exact vectors on every content); the motion "

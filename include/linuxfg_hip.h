@@ -110,6 +110,9 @@ int         lfg_sync(lfg_context *ctx);
  *   lfg_lane_select(ctx, j) the calls that follow enqueue on lane j
  *   lfg_lane_mark(ctx)      remember "here" on the selected lane
  *   lfg_lane_wait(ctx, i)   the selected lane's later work waits until lane i has reached its last mark
+ *   lfg_lane_sync(ctx)      the HOST waits for the selected lane alone (a frame's buffers are free again; lfg_sync waits for
+ *                           every lane) -- what vkQueueWaitIdle after each submission (src/scaler.cpp:389-393) becomes when
+ *                           n frames are in flight: wait for frame k before frame k + n goes onto its lane
  * e.g. frame k on lane k % 2:  select; scale(curr_k); mark; wait(other lane: scale(curr_k-1)); motion; interpolate.
  * lfg_context_set_stream applies to the selected lane. */
 #define LFG_MAX_LANES 4
@@ -119,6 +122,7 @@ int         lfg_lane_current(const lfg_context *ctx);
 int         lfg_lane_select(lfg_context *ctx, int lane);
 int         lfg_lane_mark(lfg_context *ctx);
 int         lfg_lane_wait(lfg_context *ctx, int other);
+int         lfg_lane_sync(lfg_context *ctx);
 /* Logger::GetLastError (src/logger.hpp:38).  ctx == NULL reads the creation-time error. */
 const char *lfg_last_error(const lfg_context *ctx);
 
@@ -207,6 +211,14 @@ int  lfg_motion_open_segments(lfg_context *ctx, uint32_t *out_open, uint32_t *ou
  * lane's last call did (1/0), how many tiles are listed for that kernel at this frame size, and in how many it left work to the
  * general kernel (synchronises; reporting and tests only).  No reference counterpart (shaders/motion.comp:27-52 is one pass). */
 int  lfg_motion_lean_stats(lfg_context *ctx, int *out_used, uint32_t *out_tiles, uint32_t *out_tiles_left);
+/* With frames in flight three launch decisions of an lfg_motion go by what the lane's PREVIOUS finished call found (its
+ * verdict word, stored into pinned host memory by that call's last launch): the lean kernel and the plan that goes with it,
+ * the size of the persistent grid, the size of the second pass.  A wrong guess changes no result, only the call's duration.
+ * Counters since the context was created, over all lanes: calls whose own verdict has been read back, and how many of them
+ * had been launched on a guess that this verdict contradicts, per decision (does not synchronise; reporting only).
+ * No reference counterpart: one queue, one dispatch per stage (src/frame_manager.cpp:342-366). */
+int  lfg_motion_prediction_stats(const lfg_context *ctx, uint64_t *out_verdicts, uint64_t *out_lean_wrong,
+                                 uint64_t *out_grid_wrong, uint64_t *out_second_pass_wrong);
 /* Bytes of device memory the prefiltered lfg_motion keeps for frames of this size (allocated on the first such call, kept
  * until the size changes or the context goes; one per lane).  No reference counterpart -- the reference's motion pass keeps
  * nothing between its two images (src/frame_manager.cpp:262-300); a host budgets lanes with it.  Needs no GPU work.

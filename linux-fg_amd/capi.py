@@ -55,6 +55,7 @@ SIGNATURES = {
     "lfg_lane_select": (_i, [_vp, _i]),
     "lfg_lane_mark": (_i, [_vp]),
     "lfg_lane_wait": (_i, [_vp, _i]),
+    "lfg_lane_sync": (_i, [_vp]),
     "lfg_last_error": (ctypes.c_char_p, [_vp]),
     "lfg_frame_create": (_i, [_vp, _u32, _u32, _u32, _FP]),
     "lfg_frame_destroy": (None, [_vp, _FP]),
@@ -77,6 +78,7 @@ SIGNATURES = {
     "lfg_motion_last_stats": (_i, [_vp, ctypes.POINTER(_u32), ctypes.POINTER(_u32), ctypes.POINTER(ctypes.c_double)]),
     "lfg_motion_open_segments": (_i, [_vp, ctypes.POINTER(_u32), ctypes.POINTER(_u32)]),
     "lfg_motion_lean_stats": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_u32), ctypes.POINTER(_u32)]),
+    "lfg_motion_prediction_stats": (_i, [_vp] + [ctypes.POINTER(ctypes.c_uint64)] * 4),
     "lfg_motion_workspace_size": (_i, [_vp, _u32, _u32, ctypes.POINTER(ctypes.c_uint64)]),
     "lfg_motion_plan": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "lfg_set_semantics": (_i, [_vp, _i]),
@@ -180,6 +182,10 @@ class Context:
 
     def lane_mark(self):
         self._check(self.lib.lfg_lane_mark(self.h), "lfg_lane_mark")
+
+    def lane_sync(self):
+        """The host waits for the selected lane alone."""
+        self._check(self.lib.lfg_lane_sync(self.h), "lfg_lane_sync")
 
     def lane_wait(self, other: int):
         self._check(self.lib.lfg_lane_wait(self.h, int(other)), "lfg_lane_wait")
@@ -287,6 +293,13 @@ class Context:
         u, t, l = ctypes.c_int(), ctypes.c_uint32(), ctypes.c_uint32()
         self._check(self.lib.lfg_motion_lean_stats(self.h, ctypes.byref(u), ctypes.byref(t), ctypes.byref(l)), "lfg_motion_lean_stats")
         return bool(u.value), t.value, l.value
+
+    def motion_prediction_stats(self):
+        """(calls whose verdict came back, of which launched on a wrong guess about: the lean kernel, the persistent grid, the
+        second pass) since the context was created, all lanes together (lfg_motion_prediction_stats)."""
+        v = [ctypes.c_uint64() for _ in range(4)]
+        self._check(self.lib.lfg_motion_prediction_stats(self.h, *[ctypes.byref(x) for x in v]), "lfg_motion_prediction_stats")
+        return tuple(int(x.value) for x in v)
 
     def motion_workspace_size(self, width: int, height: int) -> int:
         """Bytes the prefiltered motion path keeps for frames of this size (per lane)."""

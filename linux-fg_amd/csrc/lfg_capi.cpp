@@ -411,13 +411,13 @@ void lane_store(lfg_context *ctx, lfg_lane_state &l) {
     l.own_stream = ctx->own_stream; l.stream = ctx->stream; l.mv_tmp = ctx->mv_tmp; l.mid_tmp = ctx->mid_tmp;
     l.motion_ws = ctx->motion_ws; l.motion_ws_bytes = ctx->motion_ws_bytes; l.motion_ws_w = ctx->motion_ws_w; l.motion_ws_h = ctx->motion_ws_h;
     l.motion_ws_layout = ctx->motion_ws_layout; l.motion_units = ctx->motion_units; l.mark = ctx->mark; l.marked = ctx->marked;
-    l.lean_flag = ctx->lean_flag; l.lean_ev = ctx->lean_ev; l.lean_ev_pending = ctx->lean_ev_pending; l.lean_predict = ctx->lean_predict; l.lean_seen = ctx->lean_seen;
+    l.lean_flag = ctx->lean_flag; l.lean_ev = ctx->lean_ev; l.lean_ev_pending = ctx->lean_ev_pending; l.lean_predict = ctx->lean_predict; l.lean_seen = ctx->lean_seen; l.lean_request_guess = ctx->lean_request_guess;
 }
 void lane_load(lfg_context *ctx, const lfg_lane_state &l) {
     ctx->own_stream = l.own_stream; ctx->stream = l.stream; ctx->mv_tmp = l.mv_tmp; ctx->mid_tmp = l.mid_tmp;
     ctx->motion_ws = l.motion_ws; ctx->motion_ws_bytes = l.motion_ws_bytes; ctx->motion_ws_w = l.motion_ws_w; ctx->motion_ws_h = l.motion_ws_h;
     ctx->motion_ws_layout = l.motion_ws_layout; ctx->motion_units = l.motion_units; ctx->mark = l.mark; ctx->marked = l.marked;
-    ctx->lean_flag = l.lean_flag; ctx->lean_ev = l.lean_ev; ctx->lean_ev_pending = l.lean_ev_pending; ctx->lean_predict = l.lean_predict; ctx->lean_seen = l.lean_seen;
+    ctx->lean_flag = l.lean_flag; ctx->lean_ev = l.lean_ev; ctx->lean_ev_pending = l.lean_ev_pending; ctx->lean_predict = l.lean_predict; ctx->lean_seen = l.lean_seen; ctx->lean_request_guess = l.lean_request_guess;
 }
 void lane_release(lfg_lane_state &l) {
     if (l.stream) (void)hipStreamSynchronize(l.stream);
@@ -518,6 +518,13 @@ LFG_EXPORT int lfg_lane_wait(lfg_context *ctx, int other) {
     const lfg_lane_state &o = ctx->lanes[(size_t)other];
     if (!o.marked) return LFG_OK;              // nothing to wait for yet
     LFG_HIP(ctx, hipStreamWaitEvent(ctx->stream, o.mark, 0));
+    return LFG_OK;
+}
+
+LFG_EXPORT int lfg_lane_sync(lfg_context *ctx) {
+    if (!ctx) return LFG_ERR_INVALID;
+    LFG_HIP(ctx, hipSetDevice(ctx->device));
+    LFG_HIP(ctx, hipStreamSynchronize(ctx->stream));      // the selected lane's stream IS the context's current one
     return LFG_OK;
 }
 
@@ -758,12 +765,12 @@ static int motion_run(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *
     const lfg::FusedOut fo = (fused && tiled) ? *fused : lfg::FusedOut();
     if (tiled && ctx->motion_mode == LFG_MOTION_PREFILTERED) {
         // The lean kernel (motion_lean.hip) and the plan that goes with it: with frames in flight only (one frame at a time it sits
-        // in front of the rim's long units: 2,620 -> 2,360 frames/s), under the shaders' own tie order (it reads ranks as scan
-        // indices), and for content that suits it -- which the ORDER kernel knows (a pan, an object's motion: most sample blocks
+        // in front of the rim's long units: 2,620 -> 2,360 frames/s), under either tie order (round 5: the intended order's ranks go
+        // through rank2scan), and for content that suits it -- which the ORDER kernel knows (a pan, an object's motion: most sample blocks
         // match nearly but not exactly) and the host learns one call late: the verdict of the lane's last finished call decides.
         // A kernel that finds out on the device that it has nothing to do still has to be placed, 2,144 workgroups of 48 KB of LDS
         // behind the other lanes' persistent kernels: -7 % on noisy frames, measured.
-        const bool leanPossible = ctx->motion_ws_layout.rimSplit2 != 0 && ctx->semantics == 0 && ctx->motion_hints;
+        const bool leanPossible = ctx->motion_ws_layout.rimSplit2 != 0 && ctx->motion_hints;
         // The same word also says whether most sample blocks had a match at all.  With frames in flight the persistent kernel then
         // runs with 5/8 of the workgroups the device holds: each draws more units, fewer slots idle in a launch's tail, and the other
         // lanes' kernels find room beside it -- pan 3,660 -> 3,800 frames/s, stills +8 %, noise +3.7 %, occlusions and moving objects
@@ -775,7 +782,17 @@ static int motion_run(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *
             *ctx->lean_flag = 0u;
             LFG_HIP(ctx, hipEventCreateWithFlags(&ctx->lean_ev, hipEventDisableTiming));
         }
-        if (ctx->lean_ev_pending && hipEventQuery(ctx->lean_ev) == hipSuccess) { ctx->lean_predict = (int)*ctx->lean_flag; ctx->lean_ev_pending = false; ctx->lean_seen = true; }
+        if (ctx->lean_ev_pending && hipEventQuery(ctx->lean_ev) == hipSuccess) {
+            ctx->lean_predict = (int)*ctx->lean_flag; ctx->lean_ev_pending = false; ctx->lean_seen = true;
+            // (lfg_motion_prediction_stats) the call that delivered this word had been launched on lean_request_guess -- bit 0: it went
+            // through the lean kernel, bit 1: that kernel was available to it, bit 31: its persistent grid was sized for "most sample
+            // blocks match", bit 30: its second pass was the small looping grid -- and its own content said:
+            const uint32_t said = (uint32_t)ctx->lean_predict, guess = ctx->lean_request_guess;
+            ctx->pred_verdicts += 1;
+            if ((guess & 2u) && ((guess ^ said) & 1u)) ctx->pred_lean_wrong += 1;
+            if ((guess ^ said) >> 31) ctx->pred_grid_wrong += 1;
+            if (((guess >> 30) & 1u) && ((said >> 30) & 1u)) ctx->pred_second_wrong += 1;       // (small grid, and tiles were flagged: the costly direction)
+        }
         if (ctx->knobs.leanForce >= 0) ctx->lean_predict = (ctx->lean_predict & ~1) | ctx->knobs.leanForce;          // (measurement: 1 = every call, 0 = none)
         ctx->motion_ws_layout.lastLean = (leanPossible && ctx->motion_ws_layout.leanCount > 0 && (ctx->lean_predict & 1) != 0 && !fo.data && lfg::lean_frames_ok(*prev, *curr, *mv)) ? 1 : 0;
         // (only while another lane has work queued or running -- a stream query each: a call that has the device to itself takes the
@@ -791,8 +808,12 @@ static int motion_run(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *
         e = lfg::launch_motion_prefiltered_8_16(ctx->stream, *prev, *curr, *mv, ctx->motion_ws, ctx->motion_ws_layout, ctx->motion_units,
                                                 rank2scan, order32, order32 + lfg::kMotionTableWords,
                                                 ctx->motion_tables + 6 * lfg::kMotionTableWords, ctx->motion_hints, ctx->lanes.size() >= 2, fo,
-                                                ctx->motion_ws_layout.lastLean != 0, (flagWanted && !ctx->lean_ev_pending) ? ctx->lean_flag : nullptr, groupsCap, expectNoFallback, ctx->knobs);
-        if (e == hipSuccess && flagWanted && !ctx->lean_ev_pending && !fo.data) { e = hipEventRecord(ctx->lean_ev, ctx->stream); ctx->lean_ev_pending = true; }
+                                                ctx->motion_ws_layout.lastLean != 0, (flagWanted && !ctx->lean_ev_pending) ? ctx->lean_flag : nullptr, groupsCap, expectNoFallback, ctx->knobs, ctx->semantics == 0);
+        if (e == hipSuccess && flagWanted && !ctx->lean_ev_pending && !fo.data) {
+            e = hipEventRecord(ctx->lean_ev, ctx->stream); ctx->lean_ev_pending = true;
+            ctx->lean_request_guess = (ctx->motion_ws_layout.lastLean ? 1u : 0u) | ((leanPossible && ctx->motion_ws_layout.leanCount > 0) ? 2u : 0u) |
+                                      ((uint32_t)ctx->lean_predict & 0x80000000u) | (expectNoFallback ? 1u << 30 : 0u);
+        }
     }
     else if (tiled) e = lfg::launch_motion_tiled_8_16(ctx->stream, *prev, *curr, *mv, nullptr, rank2scan, nullptr, nullptr, fo);
     else e = lfg::launch_motion_generic(ctx->stream, *prev, *curr, *mv, block_size, R, ctx->semantics != 0);
@@ -863,6 +884,16 @@ LFG_EXPORT int lfg_motion_lean_stats(lfg_context *ctx, int *out_used, uint32_t *
     *out_used = ctx->motion_ws_layout.lastLean;
     *out_tiles = (uint32_t)ctx->motion_ws_layout.leanCount;
     *out_tiles_left = ctx->motion_ws_layout.lastLean ? left : 0u;
+    return LFG_OK;
+}
+
+LFG_EXPORT int lfg_motion_prediction_stats(const lfg_context *ctx, uint64_t *out_verdicts, uint64_t *out_lean_wrong,
+                                           uint64_t *out_grid_wrong, uint64_t *out_second_pass_wrong) {
+    if (!ctx) return LFG_ERR_INVALID;
+    if (out_verdicts) *out_verdicts = ctx->pred_verdicts;
+    if (out_lean_wrong) *out_lean_wrong = ctx->pred_lean_wrong;
+    if (out_grid_wrong) *out_grid_wrong = ctx->pred_grid_wrong;
+    if (out_second_pass_wrong) *out_second_pass_wrong = ctx->pred_second_wrong;
     return LFG_OK;
 }
 

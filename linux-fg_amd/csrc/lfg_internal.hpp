@@ -166,6 +166,7 @@ struct lfg_lane_state {
     bool lean_ev_pending = false;
     int lean_predict = 0;                      // the verdict word the next call goes by (bit 0: lean kernel; bit 30: a tile went through the literal kernel; bit 31: most sample blocks have a match)
     bool lean_seen = false;                    // ... and whether any call's word has arrived yet
+    uint32_t lean_request_guess = 0;           // what the call that carries the pending verdict request was launched on (motion_run)
 };
 
 struct lfg_context {
@@ -179,6 +180,9 @@ struct lfg_context {
     bool lean_ev_pending = false;
     int lean_predict = 0;
     bool lean_seen = false;
+    uint32_t lean_request_guess = 0;
+    // lfg_motion_prediction_stats: calls whose verdict came back, and the guesses it contradicted (all lanes together)
+    uint64_t pred_verdicts = 0, pred_lean_wrong = 0, pred_grid_wrong = 0, pred_second_wrong = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::string error;
@@ -247,7 +251,7 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
                                           const FusedOut &fused = FusedOut(), bool lean = false, uint32_t *leanFlagHost = nullptr,
                                           int groupsCap = 0 /* persistent workgroups at most (0: as many as the device holds) */,
                                           bool expectNoFallback = false /* the lane's previous call flagged no tile: a small fallback launch */,
-                                          const MotionKnobs &knobs = MotionKnobs());
+                                          const MotionKnobs &knobs = MotionKnobs(), bool rankIsScan = true);
 // This call's visiting order (motion_order.hip): hint kernel (which also clears the call's control area) + order kernel.
 hipError_t launch_motion_order(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr, uint32_t *hints, uint32_t *callOrder,
                                const uint32_t *entryOfScan, const uint32_t *baseScan, uint32_t *clearFrom, int clearWords, bool framesInFlight);
@@ -261,7 +265,8 @@ bool lean_tile_ok(int tile, int tilesX, int W, int H);
 bool lean_segment_ok(int tile, int seg, int tilesX, int W, int H);
 bool lean_frames_ok(const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv);
 hipError_t launch_motion_lean(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv,
-                              const uint32_t *order32, const uint32_t *leanTiles, int nTiles, int tilesX, uint32_t *segDone,
+                              const uint32_t *order32, const uint32_t *rank2scan, bool rankIsScan /* the shaders' own tie order: ranks are scan indices */,
+                              const uint32_t *leanTiles, int nTiles, int tilesX, uint32_t *segDone,
                               uint32_t *hardTiles, uint32_t *hardCount, uint32_t *stats, bool whateverTheVerdict);
 hipError_t launch_motion_generic(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                  const lfg_frame &mv, int block_size, int radius, bool intended);

@@ -24,7 +24,7 @@
 // candidates tie within the bracket -- is simply LEFT: the wave stops, nothing of it is written, and the generic kernel, which
 // skips the segments marked done here, does it from scratch.  Results therefore never depend on this kernel; only the time does.
 //
-// 168 VGPRs and 47 KB of LDS: three workgroups per CU.
+// 154 VGPRs and 48 KB of LDS (50 KB under the intended tie order: its rank table): three workgroups per CU.
 #include "lfg_device.hpp"
 #include "lfg_internal.hpp"
 #include "lfg_motion_tile.hpp"
@@ -110,16 +110,20 @@ __device__ __forceinline__ void lean_update(LeanState &st, const f32x2 (&s2)[kRu
     }
 }
 
-template <int kDummy>
+// kRankIsScan: the shaders' own tie order -- a candidate's rank IS its scan index (dy + R) * 33 + (dx + R), and phase 2 gets window
+// offsets and vectors from ranks by arithmetic.  false: the intended semantics' order (lfg_set_semantics: shortest vector first,
+// motion_order.hip: motion_tables) -- ranks go through rank2scan, staged in LDS once per workgroup (2.2 KB).
+template <bool kRankIsScan>
 __global__ __launch_bounds__(kPNT, 3) void motion_lean_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch, int W, int H,
-    const uint32_t *__restrict__ order32, const uint32_t *__restrict__ leanTiles, int tilesX,
+    const uint32_t *__restrict__ order32, const uint32_t *__restrict__ rank2scan, const uint32_t *__restrict__ leanTiles, int tilesX,
     int8_t *__restrict__ mv, int mvPitch, uint32_t *__restrict__ segDone, uint32_t *__restrict__ hardTiles, uint32_t *__restrict__ hardCount,
     uint32_t *__restrict__ leanStats, int whateverTheVerdict) {
     __shared__ uint32_t sWin[kWinH * kWinW];                           // 38.2 KB packed RGBA8 search window, column-major
     __shared__ __attribute__((aligned(8))) float sSlab[kPNT / 64][kLeanSlab];
     __shared__ uint32_t sVisited[(kCand + 31) / 32];                   // the ranks the hints hold (they are not looked at twice)
     __shared__ uint32_t sLeft;                                         // some wave of the workgroup left its segment to the generic kernel
+    __shared__ uint16_t sScan[kRankIsScan ? 2 : kCand + 1];            // scan index of rank r (intended order only)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), seg = wave;
@@ -142,6 +146,8 @@ __global__ __launch_bounds__(kPNT, 3) void motion_lean_kernel(
         return;
     }
     if (tid == 0) sLeft = 0u;
+    if (!kRankIsScan)
+        for (int i = tid; i < kCand; i += kPNT) sScan[i] = (uint16_t)rank2scan[i];
     const int nHints = min((int)order32[kCand + 1], kLeanHintsMax);
     // (the hints themselves, one per lane, asked for here: in flight with the window, not a memory latency each further down)
     const uint32_t hintL = order32[lane];
@@ -391,7 +397,8 @@ __global__ __launch_bounds__(kPNT, 3) void motion_lean_kernel(
 #pragma unroll
             for (int a = 0; a < kLeanAhead; ++a) {
                 const int r = r0 + 64 * a + lane, rc = min(r, kCand - 1);
-                const uint32_t dyi = ((uint32_t)rc * 1986u) >> 16, dxi = (uint32_t)rc - 33u * dyi;     // rc / 33, rc % 33 for rc < 1089
+                const uint32_t sc = kRankIsScan ? (uint32_t)rc : (uint32_t)sScan[rc];
+                const uint32_t dyi = (sc * 1986u) >> 16, dxi = sc - 33u * dyi;     // sc / 33, sc % 33 for sc < 1089
                 off[a] = dxi * (uint32_t)kWinH + dyi;
                 ordA[a] = (uint32_t)rc | (off[a] << 16);
                 need[a] = r < bound && ((sVisited[rc >> 5] >> (rc & 31)) & 1u) == 0u;
@@ -444,7 +451,7 @@ __global__ __launch_bounds__(kPNT, 3) void motion_lean_kernel(
         for (int hb = 0; hb < 2; ++hb) {
 #pragma unroll
             for (int i = 0; i < kRun; ++i) {
-                const uint32_t r = rankOf[hb][i];
+                const uint32_t r = kRankIsScan ? rankOf[hb][i] : (uint32_t)sScan[min(rankOf[hb][i], (uint32_t)kCand - 1u)];
                 const uint32_t dyi = (r * 1986u) >> 16, dxi = r - 33u * dyi;
                 rows[(8 * hb + r8) * kPTW + kRun * q + i] = (uint16_t)(uint8_t)(int8_t)((int)dxi - kR) | (uint16_t)((uint16_t)(uint8_t)(int8_t)((int)dyi - kR) << 8);
             }
@@ -493,12 +500,15 @@ bool lean_frames_ok(const lfg_frame &prev, const lfg_frame &curr, const lfg_fram
 }
 
 hipError_t launch_motion_lean(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv,
-                              const uint32_t *order32, const uint32_t *leanTiles, int nTiles, int tilesX, uint32_t *segDone,
-                              uint32_t *hardTiles, uint32_t *hardCount, uint32_t *stats, bool whateverTheVerdict) {
+                              const uint32_t *order32, const uint32_t *rank2scan, bool rankIsScan, const uint32_t *leanTiles, int nTiles, int tilesX,
+                              uint32_t *segDone, uint32_t *hardTiles, uint32_t *hardCount, uint32_t *stats, bool whateverTheVerdict) {
     if (nTiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(motion_lean_kernel<0>, dim3((unsigned)nTiles), dim3(kPNT), 0, s,
-                       (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch, (int)curr.width, (int)curr.height,
-                       order32, leanTiles, tilesX, (int8_t *)mv.data, (int)mv.pitch, segDone, hardTiles, hardCount, stats, whateverTheVerdict ? 1 : 0);
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3((unsigned)nTiles), dim3(kPNT), 0, s,
+                           (const uint8_t *)prev.data, (int)prev.pitch, (const uint8_t *)curr.data, (int)curr.pitch, (int)curr.width, (int)curr.height,
+                           order32, rank2scan, leanTiles, tilesX, (int8_t *)mv.data, (int)mv.pitch, segDone, hardTiles, hardCount, stats, whateverTheVerdict ? 1 : 0);
+    };
+    if (rankIsScan) launch(motion_lean_kernel<true>); else launch(motion_lean_kernel<false>);
     return hipGetLastError();
 }
 

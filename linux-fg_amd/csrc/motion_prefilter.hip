@@ -370,7 +370,7 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
                                           const uint32_t *rank2scan, const uint32_t *order,
                                           const uint32_t *entryOfScan, const uint32_t *baseScan, bool useHints, bool framesInFlight,
                                           const FusedOut &fused, bool lean, uint32_t *leanFlagHost, int groupsCap, bool expectNoFallback,
-                                          const MotionKnobs &knobs) {
+                                          const MotionKnobs &knobs, bool rankIsScan) {
     const int tilesX = ((int)curr.width + kTW - 1) / kTW;
     lean = lean && useHints && !fused.data && l.units2 > 0 && l.leanCount > 0 && curr.width >= 64u && curr.height >= 64u && lean_frames_ok(prev, curr, mv);
     if (lean) units = l.units2;          // the plan that goes with the lean kernel
@@ -424,7 +424,7 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
         if (lean) {
             // (beside the persistent kernel on a stream of its own, with that kernel's grid cut to 448 .. 320 workgroups to leave it room:
             //  measured for a context that runs one frame at a time, 2,160 - 2,430 frames/s against 2,610 without the kernel: not done)
-            e = launch_motion_lean(s, prev, curr, mv, order, reinterpret_cast<const uint32_t *>(workspace + l.leanTiles), l.leanLaunch, sp.tilesX, segDone,
+            e = launch_motion_lean(s, prev, curr, mv, order, rank2scan, rankIsScan, reinterpret_cast<const uint32_t *>(workspace + l.leanTiles), l.leanLaunch, sp.tilesX, segDone,
                                    reinterpret_cast<uint32_t *>(workspace + l.hardTiles), ctrl + kCtrlHardCount, ctrl + kCtrlLeanSettled, knobs.leanForce == 1);
             if (e != hipSuccess) return e;
         }

@@ -91,3 +91,20 @@ bool RawFileCapture::NextFrame(uint8_t* host) {
     }
     return true;
 }
+
+bool ReplayCapture::Initialize(uint32_t width, uint32_t height) {
+    if (!m_inner || !m_inner->Initialize(width, height)) return false;
+    m_bytes = (size_t)width * height * 4;
+    m_frames.resize(m_bytes * m_count);
+    for (uint32_t i = 0; i < m_count; ++i)
+        if (!m_inner->NextFrame(m_frames.data() + (size_t)i * m_bytes)) { LOG_ERROR("ReplayCapture: the source ended after ", i, " frames"); return false; }
+    m_next = 0;
+    return true;
+}
+
+bool ReplayCapture::NextFrame(uint8_t* host) {
+    if (m_frames.empty()) return false;
+    std::memcpy(host, m_frames.data() + (size_t)m_next * m_bytes, m_bytes);
+    m_next = (m_next + 1) % m_count;
+    return true;
+}

@@ -6,6 +6,7 @@
 #pragma once
 #include <cstdint>
 #include <cstdio>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -42,6 +43,25 @@ private:
     uint32_t m_seed, m_width = 0, m_height = 0, m_index = 0;
     int m_shiftX, m_shiftY;
     std::vector<uint8_t> m_last;
+};
+
+// A source played back from memory: the first `frames` frames of another source are produced ONCE, in Initialize, and handed
+// out in rotation afterwards (one memcpy into the pinned staging slot per frame -- what CopyToStagingBuffer does with a
+// captured image, src/window_capture.cpp:472-568).  For measurements in which the host's frame synthesis (5 ms per 1080p
+// frame on one core) must not be what bounds the loop: bench.py's PCIe-inclusive figure.
+class ReplayCapture : public FrameSource {
+public:
+    ReplayCapture(std::unique_ptr<FrameSource> inner, uint32_t frames) : m_inner(std::move(inner)), m_count(frames ? frames : 1) {}
+
+    bool Initialize(uint32_t width, uint32_t height) override;
+    bool NextFrame(uint8_t* host) override;
+    bool GetSize(uint32_t& width, uint32_t& height) const override { return m_inner->GetSize(width, height); }
+
+private:
+    std::unique_ptr<FrameSource> m_inner;
+    uint32_t m_count, m_next = 0;
+    size_t m_bytes = 0;
+    std::vector<uint8_t> m_frames;
 };
 
 // Raw RGBA8 frames (tightly packed, back to back) from a file or a pipe ("-" = stdin): the headless stand-in

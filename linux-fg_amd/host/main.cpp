@@ -36,6 +36,9 @@ static void PrintUsage() {
               << "  --dump-dir DIR           Write every presented frame to DIR as raw RGBA8\n"
               << "  --input-raw FILE         Read input frames (raw RGBA8, tightly packed, back to back) from FILE, '-' = stdin\n"
               << "  --output-raw FILE        Append every presented frame (raw RGBA8) to FILE, '-' = stdout\n"
+              << "  --replay N               Produce the source's first N frames once, before the clock starts, and play them back in rotation\n"
+              << "                           (the host's frame synthesis, 5 ms per 1080p frame, then does not bound the loop)\n"
+              << "  --present-null           The presenter looks at no pixel (default: a strided checksum over every presented frame)\n"
               << "  --sync-present           Wait for each call's own frames (reference behaviour) instead of pipelining\n"
               << "  --quiet                  Only warnings and errors\n";
 }
@@ -51,7 +54,8 @@ int main(int argc, char* argv[]) {
     int ranks = 0, rank = 0, inFlight = 2;
     unsigned long long commNonce = getenv("LFG_COMM_NONCE") ? strtoull(getenv("LFG_COMM_NONCE"), nullptr, 0) : 0ull;
     std::vector<float> factors;
-    bool syncPresent = false;
+    bool syncPresent = false, presentNull = false;
+    int replay = 0;
 
     for (int i = 1; i < argc; i++) {
         if (strcmp(argv[i], "--help") == 0) { PrintUsage(); return 0; }
@@ -82,6 +86,8 @@ int main(int argc, char* argv[]) {
         else if (strcmp(argv[i], "--input-raw") == 0 && i + 1 < argc) inputRaw = argv[++i];
         else if (strcmp(argv[i], "--output-raw") == 0 && i + 1 < argc) outputRaw = argv[++i];
         else if (strcmp(argv[i], "--sync-present") == 0) syncPresent = true;
+        else if (strcmp(argv[i], "--replay") == 0 && i + 1 < argc) replay = std::atoi(argv[++i]);
+        else if (strcmp(argv[i], "--present-null") == 0) presentNull = true;
         else if (strcmp(argv[i], "--quiet") == 0) Logger::Get().SetMinLevel(Logger::Level::WARNING);
         else {
             char* endPtr;
@@ -117,8 +123,13 @@ int main(int argc, char* argv[]) {
         Scaler::Get().SetSharedPreviousSource(std::make_unique<SyntheticCapture>(0));   // the batch's previous frames: stream 0
         if (stream == 0) stream = (uint32_t)rank + 1;                                   // a rank's own current frames
     }
-    if (!inputRaw.empty()) Scaler::Get().SetFrameSource(std::make_unique<RawFileCapture>(inputRaw));
-    else Scaler::Get().SetFrameSource(std::make_unique<SyntheticCapture>(stream));
+    {
+        std::unique_ptr<FrameSource> source;
+        if (!inputRaw.empty()) source = std::make_unique<RawFileCapture>(inputRaw);
+        else source = std::make_unique<SyntheticCapture>(stream);
+        if (replay > 0) source = std::make_unique<ReplayCapture>(std::move(source), (uint32_t)replay);
+        Scaler::Get().SetFrameSource(std::move(source));
+    }
     Scaler::Get().SetPipelined(!syncPresent);
     Scaler::Get().SetFramesInFlight(inFlight);
     if (!factors.empty()) Scaler::Get().SetInterpolationFactors(factors);
@@ -132,7 +143,7 @@ int main(int argc, char* argv[]) {
     Scaler::Get().SetPresenter([&](const uint8_t* rgba, uint32_t w, uint32_t h, bool interpolated) {
         const size_t n = (size_t)w * h * 4;
         uint64_t s = 0;
-        for (size_t i = 0; i < n; i += 64) s += rgba[i];
+        if (!presentNull) for (size_t i = 0; i < n; i += 64) s += rgba[i];
         checksum = checksum * 1315423911ull + s;
         if (!dumpDir.empty()) {
             char name[512];
@@ -164,8 +175,10 @@ int main(int argc, char* argv[]) {
     if (!ok) { LOG_ERROR("ProcessFrame failed: ", Logger::Get().GetLastError()); return 1; }
     if (rawOut && rawOut != stdout) fclose(rawOut);
     fprintf(report, "{\"input_frames\": %d, \"presented\": %llu, \"interpolated\": %llu, \"seconds\": %.4f, "
-           "\"presented_fps\": %.2f, \"checksum\": %llu, \"pipelined\": %s, \"note\": \"includes host frame synthesis, PCIe upload and readback\"}\n",
+           "\"presented_fps\": %.2f, \"checksum\": %llu, \"pipelined\": %s, \"replay\": %d, \"present_null\": %s, \"in_flight\": %d, "
+           "\"note\": \"includes %s, PCIe upload and readback\"}\n",
            frames, (unsigned long long)presented, (unsigned long long)generated, sec, presented / sec,
-           (unsigned long long)checksum, syncPresent ? "false" : "true");
+           (unsigned long long)checksum, syncPresent ? "false" : "true", replay, presentNull ? "true" : "false", inFlight,
+           replay > 0 ? "one memcpy per input frame into the staging slot" : "host frame synthesis");
     return 0;
 }

@@ -59,7 +59,11 @@ def test_counter_tables_are_read_back_only_for_the_library_that_made_them(tmp_pa
     assert b.pmc_traffic("lfg::scale_2x")[0] == (6616 + 32630) * 1024
     ex = b.pmc_executed("lfg::motion_")
     assert ex["valu_wave_instructions"] == 2 * 90250000 and ex["kernel_us_per_step_in_that_pass"] == 640.0
-    assert abs(ex["valu_issue_utilisation"] - 2 * 90250000 * 4 / (640e-6 * 2.4e9 * 1024)) < 1e-3
+    # three stated conventions: 2 cycles per instruction (SIMD-32, two waves resident), the same cost-weighted (no weights file
+    # for this made-up library: None), and round 4's 4 cycles (one wave alone)
+    assert abs(ex["valu_issue_utilisation_simd32_2_cycles"] - 2 * 90250000 * 2 / (640e-6 * 2.4e9 * 1024)) < 1e-3
+    assert abs(ex["valu_issue_utilisation_one_wave_alone_4_cycles"] - 2 * 90250000 * 4 / (640e-6 * 2.4e9 * 1024)) < 1e-3
+    assert ex["valu_issue_utilisation_cost_weighted"] is None
     monkeypatch.setattr(b, "library_sha16", lambda: "ffffffffffffffff")       # another build: nothing is quoted
     t, why = b.pmc_traffic("lfg::")
     assert t is None and "not quoted" in why

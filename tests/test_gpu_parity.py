@@ -1516,6 +1516,36 @@ def test_lean_kernel_agrees_with_the_literal_kernel(lean_ctx, case):
     lean_ctx.lane_select(0)
 
 
+@pytest.mark.parametrize("case", [0, 1, 3, 4, 5])
+def test_lean_kernel_under_the_intended_tie_order(lean_ctx, oracle, case):
+    """Round 5: the lean kernel also serves lfg_set_semantics(INTENDED), where a candidate's rank is its place in the shortest-vector-
+    first order and not its scan index (its ranks go through rank2scan): whole frames against the literal kernel under the same
+    semantics -- ties (stills, flat and periodic frames) are exactly where the two orders disagree -- and a region of the pan
+    against the ORACLE's intended mode."""
+    from linux_fg_amd import capi
+    name, prev, curr = list(_lean_cases())[case]
+    lean_ctx.set_semantics(capi.SEMANTICS_INTENDED)
+    try:
+        for lane in (0, 1):
+            lean_ctx.lane_select(lane)
+            a, _ = run_motion_mode(lean_ctx, prev, curr, capi.MOTION_PREFILTERED)
+            used, listed, left = lean_ctx.motion_lean_stats()
+            assert used and listed > 300, (used, listed)
+            if name in ("pan", "stills"):
+                assert left == 0, f"{name}: the lean kernel left work in {left} of {listed} tiles"
+            b, _ = run_motion_mode(lean_ctx, prev, curr, capi.MOTION_EXACT_ONLY)
+            assert (a == b).all(), f"{name}, lane {lane}: {(a != b).any(-1).sum()} pixels differ"
+        if name in ("pan", "stills"):
+            x0, y0, x1, y1 = roi = (600, 400, 700, 424)
+            want = as_int(oracle.motion(prev, curr, roi=roi, semantics=oracle.INTENDED))[y0:y1, x0:x1]
+            assert (a[y0:y1, x0:x1] == want).all(), name
+            if name == "stills":
+                assert (a[64:-64, 64:-64] == 0).all()          # (the shaders' own order says (-16, -16) on ties; the intended one the zero vector)
+    finally:
+        lean_ctx.set_semantics(capi.SEMANTICS_REFERENCE)
+        lean_ctx.lane_select(0)
+
+
 @pytest.mark.parametrize("wh,shift", [((1284, 726), (2, 5)), ((1284, 726), (-3, -4)), ((1540, 870), (0, -6)), ((1352, 778), (4, 0))])
 def test_lean_kernel_on_ragged_sizes(lean_ctx, wh, shift):
     """Heights that are no multiple of a tile's 64 rows or a segment's 16, pans in every direction: which segments of the rim tiles
@@ -1582,6 +1612,45 @@ def test_lean_verdict_follows_the_content():
             c.lane_select(k % 2)
             got = run_motion(c, base, pan if name == "pan" else noise)
             assert (got == want[name]).all(), (k, name)
+        c.lane_select(0)
+    finally:
+        c.close()
+
+
+def test_wrong_guesses_are_counted_and_a_lane_can_be_waited_for_alone():
+    """lfg_motion_prediction_stats: with frames in flight three launch decisions go by the lane's previous finished call.  A stream
+    that turns from a pan to noise and back, the host waiting for a lane's previous frame before it reuses the lane (lfg_lane_sync:
+    that lane alone): every call's verdict comes back, and exactly the calls at the two changes of content were launched on a
+    wrong guess about the lean kernel -- and still produced the literal kernel's vectors."""
+    from linux_fg_amd import capi
+    W, H = 1920, 1080
+    base = synth.make_prev(W, H, seed=synth.BASE_SEED + 707)
+    pan = synth.translate(base, (3, 2), synth.BASE_SEED + 707)
+    noise = synth.noise_bytes(W, H, 4242)
+    c = capi.Context(0)
+    try:
+        c.lanes(2)
+        want = {}
+        for name, curr in (("pan", pan), ("noise", noise)):
+            want[name], _ = run_motion_mode(c, base, curr, capi.MOTION_EXACT_ONLY)
+        P = c.frame_from(base); frames = {"pan": c.frame_from(pan), "noise": c.frame_from(noise)}
+        mvs = [c.create_frame(W, H, capi.FORMAT_MV_S8X2) for _ in range(2)]
+        assert c.motion_prediction_stats() == (0, 0, 0, 0)
+        seq = ["pan"] * 6 + ["noise"] * 6 + ["pan"] * 6
+        for k, name in enumerate(seq):
+            c.lane_select(k % 2)
+            c.lane_sync()                                   # this lane's previous frame is done (the other lane may still run)
+            if k >= 2:
+                assert (as_int(c.download(mvs[k % 2])) == want[seq[k - 2]]).all(), (k - 2, seq[k - 2])
+            c.motion(P, frames[name], mvs[k % 2])
+        c.sync()
+        verdicts, lean_wrong, grid_wrong, second_wrong = c.motion_prediction_stats()
+        # (a call's verdict is read when its lane is used next: the last two calls' are still out)
+        assert verdicts == len(seq) - 2, verdicts
+        # per lane: the first call (no guess yet: none of the lean kernel), the first noise call (guessed lean), the first pan after the
+        # noise (guessed none) -- and the second pass never flags a tile here
+        assert lean_wrong == 2 * 3 and second_wrong == 0, (lean_wrong, grid_wrong, second_wrong)
+        assert grid_wrong >= 2 * 2
         c.lane_select(0)
     finally:
         c.close()
