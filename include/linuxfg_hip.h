@@ -211,6 +211,11 @@ int  lfg_motion_open_segments(lfg_context *ctx, uint32_t *out_open, uint32_t *ou
  * lane's last call did (1/0), how many tiles are listed for that kernel at this frame size, and in how many it left work to the
  * general kernel (synchronises; reporting and tests only).  No reference counterpart (shaders/motion.comp:27-52 is one pass). */
 int  lfg_motion_lean_stats(lfg_context *ctx, int *out_used, uint32_t *out_tiles, uint32_t *out_tiles_left);
+/* The strips a frame's motion exposes along its edges -- sixteen pixel columns, eight rows: pixels without any match -- are
+ * searched by a kernel of their own before the general one (same vectors).  After an lfg_motion: how many pixel rows had their
+ * left or right band decided that way and how many pixel columns their top or bottom band (synchronises; reporting and tests
+ * only).  No reference counterpart (shaders/motion.comp:27-52 treats every pixel alike). */
+int  lfg_motion_strip_stats(lfg_context *ctx, uint32_t *out_rows, uint32_t *out_columns);
 /* With frames in flight three launch decisions of an lfg_motion go by what the lane's PREVIOUS finished call found (its
  * verdict word, stored into pinned host memory by that call's last launch): the lean kernel and the plan that goes with it,
  * the size of the persistent grid, the size of the second pass.  A wrong guess changes no result, only the call's duration.

@@ -78,6 +78,7 @@ SIGNATURES = {
     "lfg_motion_last_stats": (_i, [_vp, ctypes.POINTER(_u32), ctypes.POINTER(_u32), ctypes.POINTER(ctypes.c_double)]),
     "lfg_motion_open_segments": (_i, [_vp, ctypes.POINTER(_u32), ctypes.POINTER(_u32)]),
     "lfg_motion_lean_stats": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_u32), ctypes.POINTER(_u32)]),
+    "lfg_motion_strip_stats": (_i, [_vp, ctypes.POINTER(_u32), ctypes.POINTER(_u32)]),
     "lfg_motion_prediction_stats": (_i, [_vp] + [ctypes.POINTER(ctypes.c_uint64)] * 4),
     "lfg_motion_workspace_size": (_i, [_vp, _u32, _u32, ctypes.POINTER(ctypes.c_uint64)]),
     "lfg_motion_plan": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
@@ -293,6 +294,12 @@ class Context:
         u, t, l = ctypes.c_int(), ctypes.c_uint32(), ctypes.c_uint32()
         self._check(self.lib.lfg_motion_lean_stats(self.h, ctypes.byref(u), ctypes.byref(t), ctypes.byref(l)), "lfg_motion_lean_stats")
         return bool(u.value), t.value, l.value
+
+    def motion_strip_stats(self):
+        """(pixel rows whose left or right band, pixel columns whose top or bottom band the strip kernel decided in the last lfg_motion)."""
+        a, b = ctypes.c_uint32(), ctypes.c_uint32()
+        self._check(self.lib.lfg_motion_strip_stats(self.h, ctypes.byref(a), ctypes.byref(b)), "lfg_motion_strip_stats")
+        return a.value, b.value
 
     def motion_prediction_stats(self):
         """(calls whose verdict came back, of which launched on a wrong guess about: the lean kernel, the persistent grid, the

@@ -398,6 +398,7 @@ LFG_EXPORT int lfg_context_create(int device_ordinal, lfg_context **out_ctx) {
     if (const char *m = getenv("LFG_DYN_PARTS_RT")) ctx->knobs.dynParts = atoi(m);
     if (const char *m = getenv("LFG_PREF_GROUPS")) ctx->knobs.prefGroups = atoi(m);
     if (const char *m = getenv("LFG_RESOLVE_GROUPS")) ctx->knobs.resolveGroups = atoi(m);
+    if (const char *m = getenv("LFG_MOTION_STRIP")) ctx->knobs.strips = atoi(m) != 0;
     if (getenv("LFG_DEBUG")) ctx->knobs.debug = 1;
     if (getenv("LFG_DEBUG_DYN")) ctx->knobs.debugDyn = 1;
     if (const char *m = getenv("LFG_DEBUG_DYN_DEEP")) ctx->knobs.debugDynDeep = atoi(m);
@@ -884,6 +885,20 @@ LFG_EXPORT int lfg_motion_lean_stats(lfg_context *ctx, int *out_used, uint32_t *
     *out_used = ctx->motion_ws_layout.lastLean;
     *out_tiles = (uint32_t)ctx->motion_ws_layout.leanCount;
     *out_tiles_left = ctx->motion_ws_layout.lastLean ? left : 0u;
+    return LFG_OK;
+}
+
+LFG_EXPORT int lfg_motion_strip_stats(lfg_context *ctx, uint32_t *out_rows, uint32_t *out_columns) {
+    if (!ctx) return LFG_ERR_INVALID;
+    if (!out_rows || !out_columns) return fail(ctx, LFG_ERR_INVALID, "lfg_motion_strip_stats: NULL argument");
+    if (!ctx->motion_ws || ctx->motion_ws_w == 0) return fail(ctx, LFG_ERR_INVALID, "lfg_motion_strip_stats: the prefiltered path has not run");
+    LFG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<uint32_t> t((size_t)ctx->motion_ws_h + ctx->motion_ws_w);
+    LFG_HIP(ctx, hipMemcpy(t.data(), ctx->motion_ws + ctx->motion_ws_layout.colBand, t.size() * 4, hipMemcpyDeviceToHost));
+    uint32_t rows = 0, cols = 0;
+    for (uint32_t y = 0; y < ctx->motion_ws_h; ++y) rows += t[y] >> 31;
+    for (uint32_t x = 0; x < ctx->motion_ws_w; ++x) cols += t[ctx->motion_ws_h + x] >> 31;
+    *out_rows = rows; *out_columns = cols;
     return LFG_OK;
 }
 

@@ -98,12 +98,13 @@ struct MotionKnobs {
     int dynParts = 0;         // LFG_DYN_PARTS_RT = 4 | 8: parts of a handed-over segment, whatever the lane count
     int prefGroups = 0;       // LFG_PREF_GROUPS: workgroups of the persistent kernel
     int resolveGroups = 0;    // LFG_RESOLVE_GROUPS: workgroups of the resolve kernel
+    int strips = 1;           // LFG_MOTION_STRIP = 0: without the strip kernel (motion_strip.hip)
     int debug = 0;            // LFG_DEBUG: reporting calls print what they read
     int debugDyn = 0;         // LFG_DEBUG_DYN: lfg_motion_last_stats prints the deepest private lists of the handed-over segments,
     int debugDynDeep = 14;    // LFG_DEBUG_DYN_DEEP: ... deeper than this
 };
 
-struct MotionWorkspaceLayout { size_t verdict /* byte offset of the call's verdict word, order32[kCand + 2] of its own order table; orderFlags: of [kCand] */, orderFlags; size_t list, umin, count, tileFlags, segDone, segMap, queueCount, ctrl, order, plan, auxList, auxUmin, auxCount,
+struct MotionWorkspaceLayout { size_t colBand, rowBand /* [height], [width] words of the strip kernel (motion_strip.hip), inside the control area the hint kernel clears */; size_t verdict /* byte offset of the call's verdict word, order32[kCand + 2] of its own order table; orderFlags: of [kCand] */, orderFlags; size_t list, umin, count, tileFlags, segDone, segMap, queueCount, ctrl, order, plan, auxList, auxUmin, auxCount,
                                queue, dynList, dynUmin, dynCount, dynInit, openList, merge, mergeBytes, leanTiles, hardTiles, plan2, total; int queueCap, slots, rimSplit, listMain, listAux, listDyn, leanCount, leanLaunch /* with the partial tiles behind them */, rimSplit2, units, units2, units2Static /* the second plan's units without the lean kernel's tiles, which come last in its table */, tiles, lastLean /* the lane's last call went by the second plan */; };
 // Work units of the motion prefilter (motion.hip: prefilter_plan).  A unit is a 56 x 64 tile, or one of nChunks
 // contiguous parts of a tile's candidate order, or one 16-row segment of a tile with its four waves on four parts of
@@ -128,6 +129,9 @@ struct PrefilterPlan {               // passed by value to the kernels
     uint32_t *dynInit;               // per handed-over segment: the 16 x 56 thresholds of the wave that handed it over
     int dynParts;                    // parts of the candidate order a handed-over segment is searched in: 8 (two workgroups) one frame at a time, 4 with frames in flight
     uint32_t *openList, *openCount;  // the segments left to the resolve kernel (tile * 4 + segment), appended as units end
+    // Pixels the strip kernel has decided before this launch (motion_strip.hip; nullptr: that kernel did not run): colBand[y] =
+    // columns lo | hi << 16 | 1 << 31 of row y, rowBand[x] = rows of column x.  Rim units and the resolve kernel leave them alone.
+    const uint32_t *colBand, *rowBand;
     // Calls that went through the lean kernel first (motion_lean.hip): the table's last units -- that kernel's tiles -- are not drawn
     // from the table; instead the tiles in which it LEFT a segment come from the list it wrote (hardCount: nullptr = no such call).
     int unitsStatic;
@@ -268,6 +272,12 @@ hipError_t launch_motion_lean(hipStream_t s, const lfg_frame &prev, const lfg_fr
                               const uint32_t *order32, const uint32_t *rank2scan, bool rankIsScan /* the shaders' own tie order: ranks are scan indices */,
                               const uint32_t *leanTiles, int nTiles, int tilesX, uint32_t *segDone,
                               uint32_t *hardTiles, uint32_t *hardCount, uint32_t *stats, bool whateverTheVerdict);
+// The strips a pan exposes (motion_strip.hip): runs behind the order kernel, decides its pixels completely and lists them in
+// colBand / rowBand (cleared with the call's control area); the persistent kernel's rim units and the resolve kernel skip them.
+bool strip_frames_ok(const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv);
+hipError_t launch_motion_strip(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv, const uint32_t *order32,
+                               const uint32_t *rank2scan, bool rankIsScan, uint32_t *colBand, uint32_t *rowBand,
+                               uint32_t *tileFlags, uint32_t *flagged, int flagTilesX);
 hipError_t launch_motion_generic(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                  const lfg_frame &mv, int block_size, int radius, bool intended);
 hipError_t launch_interpolate(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,

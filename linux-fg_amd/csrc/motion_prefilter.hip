@@ -399,6 +399,7 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
     sp.dynInit = reinterpret_cast<uint32_t *>(workspace + l.dynInit);
     sp.openList = reinterpret_cast<uint32_t *>(workspace + l.openList);
     sp.openCount = ctrl + kCtrlOpenCount;
+    sp.colBand = sp.rowBand = nullptr;
     sp.fused = fused;
     sp.dynParts = framesInFlight ? 4 : LFG_DYN_PARTS;
     if (knobs.dynParts) sp.dynParts = knobs.dynParts == 4 ? 4 : LFG_DYN_PARTS;      // (measurement)
@@ -419,6 +420,13 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
         if (e != hipSuccess) return e;
         order = callOrder;
         verdictWord = reinterpret_cast<uint32_t *>(workspace + l.verdict);
+        // the strips the frame's motion exposes, decided completely by a kernel of their own (motion_strip.hip), which lists what it took
+        if (knobs.strips && !fused.data && strip_frames_ok(prev, curr, mv)) {
+            uint32_t *colBand = reinterpret_cast<uint32_t *>(workspace + l.colBand), *rowBand = reinterpret_cast<uint32_t *>(workspace + l.rowBand);
+            e = launch_motion_strip(s, prev, curr, mv, order, rank2scan, rankIsScan, colBand, rowBand, flags, sp.queueCount + 1, tilesX);
+            if (e != hipSuccess) return e;
+            sp.colBand = colBand; sp.rowBand = rowBand;
+        }
         // the whole interior tiles, through the lean kernel first (motion_lean.hip): what it settles it marks in segDone -- cleared by
         // the hint kernel above -- and the generic kernel below skips
         if (lean) {

@@ -72,7 +72,14 @@ LFG_STAMP(
     // A pixel of a segment the prefilter settled is final (and has no threshold or count: settled segments do not
     // write them); this block got here because the other tile it touches has work left.
     const bool settledSeg = segDone[ptile * (kPTH / kSeg) + (cpy % kPTH) / kSeg] != 0u;
-    const bool live = inside && flagged == 0u && !settledSeg;
+    // ... and so is a pixel the strip kernel has decided (motion_strip.hip): the units that own its segment parked it
+    bool stripDecided = false;
+    if (sp.colBand != nullptr) {
+        const uint32_t cb = sp.colBand[cpy], rb = sp.rowBand[cpx];
+        stripDecided = ((cb >> 31) != 0u && (uint32_t)cpx >= (cb & 0xFFFFu) && (uint32_t)cpx <= ((cb >> 16) & 0x7FFFu)) ||
+                       ((rb >> 31) != 0u && (uint32_t)cpy >= (rb & 0xFFFFu) && (uint32_t)cpy <= ((rb >> 16) & 0x7FFFu));
+    }
+    const bool live = inside && flagged == 0u && !settledSeg && !stripDecided;
     // Where this pixel's records live: one list in the image-shaped arrays, or several lists (one per unit that
     // shared the tile's candidates) in the auxiliary arrays -- blocks of a tile's 64 rows for the units of the plan,
     // of a segment's 16 rows for a segment handed over at run time.  Record k of list c: recs[c * listStride + k * recStride].

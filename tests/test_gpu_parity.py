@@ -1464,6 +1464,115 @@ def test_lanes_keep_frames_in_flight_apart():
         ctx.close()
 
 
+# ------------------------------------------------------------------ the strip kernel (csrc/motion_strip.hip)
+# The bands a pan exposes along the frame's edges, decided completely by a kernel of their own.  Whatever it takes, the vectors
+# are the literal kernel's -- and the ORACLE's on the strips themselves.
+
+def _strip_pairs():
+    W, H = 700, 420
+    base = synth.make_prev(W, H, seed=synth.BASE_SEED + 808)
+    for shift in [(6, -4), (-6, 4), (5, 0), (0, 7), (-16, 16), (16, -3), (-1, -1), (9, 12)]:
+        yield f"pan {shift}", base, synth.translate(base, shift, synth.BASE_SEED + 808), shift
+    # the exposed strip DARK (zeros) instead of fresh noise: every candidate whose block leaves prev ties exactly there (plateaus),
+    # and a black strip against black out-of-image texels costs exactly nothing
+    dark = synth.translate(base, (7, -5), synth.BASE_SEED + 809)
+    dark[:, :7] = 0; dark[-5:, :] = 0
+    yield "pan, exposed strip black", base, dark, (7, -5)
+    # letterbox: black bars above and below in both frames, a horizontal pan between them
+    lb_prev, lb_curr = base.copy(), synth.translate(base, (-8, 0), synth.BASE_SEED + 810)
+    for f in (lb_prev, lb_curr):
+        f[:60] = 0; f[-60:] = 0
+    yield "letterbox", lb_prev, lb_curr, (-8, 0)
+    # a flat exposed strip one level away from the flat prev border: exact ties at a non-zero cost (lists overflow: the literal kernel's)
+    flat_prev, flat_curr = base.copy(), synth.translate(base, (4, 0), synth.BASE_SEED + 811)
+    flat_prev[:, :40] = 100; flat_curr[:, :44] = 101
+    yield "flat border one level apart", flat_prev, flat_curr, (4, 0)
+
+
+@pytest.mark.parametrize("case", range(11))
+@pytest.mark.parametrize("lanes", [1, 3])
+def test_strip_kernel_agrees_with_the_literal_kernel_and_the_oracle(oracle, case, lanes):
+    from linux_fg_amd import capi
+    name, prev, curr, shift = list(_strip_pairs())[case]
+    H, W = prev.shape[:2]
+    c = capi.Context(0)
+    try:
+        if lanes > 1:
+            c.lanes(lanes)
+        for sem in (capi.SEMANTICS_REFERENCE, capi.SEMANTICS_INTENDED):
+            if sem == capi.SEMANTICS_INTENDED and case not in (0, 4, 8):
+                continue
+            c.set_semantics(sem)
+            a, _ = run_motion_mode(c, prev, curr, capi.MOTION_PREFILTERED)
+            rows, cols = c.motion_strip_stats()
+            # which edges a translation by `shift` exposes: the left one for shift x > 0 ... -- as the call's top hint says
+            assert rows == (H if shift[0] != 0 else 0) and cols == (W if shift[1] != 0 else 0), (name, rows, cols)
+            b, _ = run_motion_mode(c, prev, curr, capi.MOTION_EXACT_ONLY)
+            assert (a == b).all(), f"{name}, {lanes} lanes, semantics {sem}: {(a != b).any(-1).sum()} pixels differ from the literal kernel"
+            # the oracle on the strips themselves: left or right band across an item boundary (57 rows), top or bottom band across one (57 columns), a corner
+            rois = []
+            if shift[0] != 0:
+                x0 = 0 if shift[0] > 0 else W - 24
+                rois += [(x0, 50, x0 + 24, 64), (x0, H - 14, x0 + 24, H)]
+            if shift[1] != 0:
+                y0 = 0 if shift[1] > 0 else H - 12
+                rois += [(50, y0, 64, y0 + 12), (W - 20, y0, W, y0 + 12)]
+            for roi in rois:
+                rx0, ry0, rx1, ry1 = roi
+                want = as_int(oracle.motion(prev, curr, roi=roi, semantics=oracle.INTENDED if sem == capi.SEMANTICS_INTENDED else oracle.REFERENCE))[ry0:ry1, rx0:rx1]
+                assert (a[ry0:ry1, rx0:rx1] == want).all(), f"{name}, semantics {sem}: the oracle says otherwise in {roi}"
+        c.set_semantics(capi.SEMANTICS_REFERENCE)
+    finally:
+        c.close()
+
+
+def test_strip_kernel_at_4k_and_8k_against_the_oracle_on_the_strips(oracle):
+    """BASELINE config 3's and config 5's sizes, the benchmark's pan (both frames upscaled on the device), frames in flight: the
+    oracle ON the strips the pan exposes -- the left band across two items, the bottom band across two items, the corner where they
+    meet, the rows just above the bottom band (the persistent kernel's: their blocks reach into the strip) -- and on a tile the lean
+    kernel LEFT (a moving object's edge inside the frame)."""
+    from linux_fg_amd import capi
+    c = capi.Context(0)
+    try:
+        c.lanes(3)
+        for (w, h), rois_of in (((1920, 1080), lambda W, H: [(0, 1130, 24, 1150), (0, 560, 20, 580), (1130, H - 12, 1150, H), (2270, H - 20, 2290, H - 8),
+                                                            (0, H - 16, 40, H), (W - 24, 40, W, 52)]),
+                                ((3840, 2160), lambda W, H: [(0, 2270, 24, 2286), (4550, H - 12, 4570, H), (0, H - 12, 32, H)])):
+            pin = synth.make_prev(w, h, seed=synth.BASE_SEED)
+            cin = synth.translate(pin, (3, -2), synth.BASE_SEED)
+            if w == 1920:                       # a patch that moves on its own: the lean kernel leaves the tiles its edge crosses
+                cin[500:560, 800:880] = pin[497:557, 804:884]
+            p, q = c.frame_from(pin), c.frame_from(cin)
+            W, H = 2 * w, 2 * h
+            P, C = c.create_frame(W, H), c.create_frame(W, H)
+            M = c.create_frame(W, H, capi.FORMAT_MV_S8X2)
+            c.scale(p, P); c.scale(q, C)
+            Pn, Cn = c.download(P), c.download(C)
+            for lane in range(3):               # (every lane's workspace; the second call of a lane goes by its first call's verdict: the lean kernel)
+                for _ in range(2):
+                    c.lane_select(lane)
+                    c.motion(P, C, M)
+                    c.lane_sync()
+            Mn = as_int(c.download(M))
+            rows, cols = c.motion_strip_stats()
+            assert rows == H and cols == W, (rows, cols)
+            used, tiles, left = c.motion_lean_stats()
+            assert used, "the lean kernel did not run"
+            rois = rois_of(W, H)
+            if w == 1920:
+                assert left > 0
+                rois.append((1590, 990, 1620, 1006))                    # the moving patch's left edge (4K coordinates)
+            for roi in rois:
+                x0, y0, x1, y1 = roi
+                want = as_int(oracle.motion(Pn, Cn, roi=roi))[y0:y1, x0:x1]
+                assert (Mn[y0:y1, x0:x1] == want).all(), f"{W}x{H}: vectors differ from the oracle in {roi}: {(Mn[y0:y1, x0:x1] != want).any(-1).sum()} pixels"
+            for f in (p, q, P, C, M):
+                c.destroy_frame(f)
+        c.lane_select(0)
+    finally:
+        c.close()
+
+
 # ------------------------------------------------------------------ the lean kernel (csrc/motion_lean.hip)
 
 @pytest.fixture()
