@@ -399,6 +399,7 @@ LFG_EXPORT int lfg_context_create(int device_ordinal, lfg_context **out_ctx) {
     if (const char *m = getenv("LFG_PREF_GROUPS")) ctx->knobs.prefGroups = atoi(m);
     if (const char *m = getenv("LFG_RESOLVE_GROUPS")) ctx->knobs.resolveGroups = atoi(m);
     if (const char *m = getenv("LFG_MOTION_STRIP")) ctx->knobs.strips = atoi(m) != 0;
+    if (const char *m = getenv("LFG_STRIP_PAD")) ctx->knobs.stripPad = atoi(m);
     if (getenv("LFG_DEBUG")) ctx->knobs.debug = 1;
     if (getenv("LFG_DEBUG_DYN")) ctx->knobs.debugDyn = 1;
     if (const char *m = getenv("LFG_DEBUG_DYN_DEEP")) ctx->knobs.debugDynDeep = atoi(m);
@@ -896,8 +897,8 @@ LFG_EXPORT int lfg_motion_strip_stats(lfg_context *ctx, uint32_t *out_rows, uint
     std::vector<uint32_t> t((size_t)ctx->motion_ws_h + ctx->motion_ws_w);
     LFG_HIP(ctx, hipMemcpy(t.data(), ctx->motion_ws + ctx->motion_ws_layout.colBand, t.size() * 4, hipMemcpyDeviceToHost));
     uint32_t rows = 0, cols = 0;
-    for (uint32_t y = 0; y < ctx->motion_ws_h; ++y) rows += t[y] >> 31;
-    for (uint32_t x = 0; x < ctx->motion_ws_w; ++x) cols += t[ctx->motion_ws_h + x] >> 31;
+    for (uint32_t y = 0; y < ctx->motion_ws_h; ++y) rows += t[y] != 0u;
+    for (uint32_t x = 0; x < ctx->motion_ws_w; ++x) cols += t[ctx->motion_ws_h + x] != 0u;
     *out_rows = rows; *out_columns = cols;
     return LFG_OK;
 }

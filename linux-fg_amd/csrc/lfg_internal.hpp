@@ -98,7 +98,8 @@ struct MotionKnobs {
     int dynParts = 0;         // LFG_DYN_PARTS_RT = 4 | 8: parts of a handed-over segment, whatever the lane count
     int prefGroups = 0;       // LFG_PREF_GROUPS: workgroups of the persistent kernel
     int resolveGroups = 0;    // LFG_RESOLVE_GROUPS: workgroups of the resolve kernel
-    int strips = 1;           // LFG_MOTION_STRIP = 0: without the strip kernel (motion_strip.hip)
+    int strips = 0;           // LFG_MOTION_STRIP = 1: the exposed strips through a kernel of their own (motion_strip.hip: exact, measured slower)
+    int stripPad = -1;        // LFG_STRIP_PAD: bytes of dynamic LDS a strip workgroup asks for on top of its own (-1: the launcher's choice)
     int debug = 0;            // LFG_DEBUG: reporting calls print what they read
     int debugDyn = 0;         // LFG_DEBUG_DYN: lfg_motion_last_stats prints the deepest private lists of the handed-over segments,
     int debugDynDeep = 14;    // LFG_DEBUG_DYN_DEEP: ... deeper than this
@@ -129,8 +130,9 @@ struct PrefilterPlan {               // passed by value to the kernels
     uint32_t *dynInit;               // per handed-over segment: the 16 x 56 thresholds of the wave that handed it over
     int dynParts;                    // parts of the candidate order a handed-over segment is searched in: 8 (two workgroups) one frame at a time, 4 with frames in flight
     uint32_t *openList, *openCount;  // the segments left to the resolve kernel (tile * 4 + segment), appended as units end
-    // Pixels the strip kernel has decided before this launch (motion_strip.hip; nullptr: that kernel did not run): colBand[y] =
-    // columns lo | hi << 16 | 1 << 31 of row y, rowBand[x] = rows of column x.  Rim units and the resolve kernel leave them alone.
+    // Pixels the strip kernel has decided before this launch (motion_strip.hip; nullptr: that kernel did not run): colBand[y] bit 0 /
+    // bit 1 = the left / right kStripCols columns of row y, rowBand[x] = the top / bottom kStripRows rows of column x
+    // (lfg_motion_tile.hpp: strip_decided).  Rim units and the resolve kernel leave them alone.
     const uint32_t *colBand, *rowBand;
     // Calls that went through the lean kernel first (motion_lean.hip): the table's last units -- that kernel's tiles -- are not drawn
     // from the table; instead the tiles in which it LEFT a segment come from the list it wrote (hardCount: nullptr = no such call).
@@ -277,7 +279,7 @@ hipError_t launch_motion_lean(hipStream_t s, const lfg_frame &prev, const lfg_fr
 bool strip_frames_ok(const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv);
 hipError_t launch_motion_strip(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv, const uint32_t *order32,
                                const uint32_t *rank2scan, bool rankIsScan, uint32_t *colBand, uint32_t *rowBand,
-                               uint32_t *tileFlags, uint32_t *flagged, int flagTilesX);
+                               uint32_t *tileFlags, uint32_t *flagged, int flagTilesX, int ldsPad);
 hipError_t launch_motion_generic(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,
                                  const lfg_frame &mv, int block_size, int radius, bool intended);
 hipError_t launch_interpolate(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr,

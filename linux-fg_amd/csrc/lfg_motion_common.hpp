@@ -60,6 +60,12 @@ __device__ __forceinline__ float dist4(const float (&c)[4], f32x4 p) {
 }
 
 
+// Has the strip kernel decided pixel (px, py)?  cb = colBand[py], rb = rowBand[px] (lfg_motion_tile.hpp).
+__device__ __forceinline__ bool strip_decided(uint32_t cb, uint32_t rb, int px, int py, int W, int H) {
+    return ((cb & 1u) != 0u && px < kStripCols) || ((cb & 2u) != 0u && px >= W - kStripCols) ||
+           ((rb & 1u) != 0u && py < kStripRows) || ((rb & 2u) != 0u && py >= H - kStripRows);
+}
+
 // The literal kernel's tiles (motion_literal.hip): 64 x 64 pixels, 512 threads.  The prefilter flags tiles on THIS grid.
 constexpr int kTW = 64, kTH = 64;                 // pixel tile
 constexpr int kNT = 512;                          // threads per workgroup: one per 8x1 pixel patch

@@ -34,6 +34,12 @@ static_assert(kCand < 2048, "a rank fits eleven bits");
 // The one-point test alone decides while the wave's largest threshold is below this (motion.hip: LFG_ONEPOINT_MAX); the lean
 // kernel keeps a segment only while that holds.
 constexpr float kOnePointOnly = 32.0f;
+// The strip kernel (motion_strip.hip) decides the outermost kStripCols pixel columns (left, right) and kStripRows pixel rows (top,
+// bottom) that a frame's motion exposes -- a translation by t exposes |t| pixels, and the blocks of three more reach into them: twelve
+// columns cover |tx| <= 9 at the output resolution, eight rows |ty| <= 5 (what lies beyond stays with the persistent kernel) -- and says
+// so per pixel row / column: colBand[y] bit 0 = the left band of row y, bit 1 = the right band; rowBand[x] bit 0 = the top band of
+// column x, bit 1 = the bottom band (lfg_motion_common.hpp: strip_decided).
+constexpr int kStripCols = 12, kStripRows = 8;
 constexpr float kSadTestMax = 8.0f;     // ... by sums of absolute differences below this (motion.hip: LFG_SAD_TEST_MAX)
 
 }  // namespace lfg

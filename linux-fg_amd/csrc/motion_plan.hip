@@ -35,7 +35,7 @@ size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, int ri
     l.queue = l.ctrl + 8 * sizeof(uint32_t);     // ctrl: [0..2] the prefilter's unit counters, [4] open segments
     l.colBand = l.queue + (size_t)l.queueCap * sizeof(uint32_t);                 // the strip kernel's tables (motion_strip.hip): cleared with the rest
     l.rowBand = l.colBand + (size_t)height * sizeof(uint32_t);
-    l.order = align(l.rowBand + (size_t)width * sizeof(uint32_t));              // this call's hints and visiting order
+    l.order = align(l.rowBand + (size_t)width * sizeof(uint32_t));              // this call's hints and visiting order              // this call's hints and visiting order
     // work-unit tables and the auxiliary arrays of the shared tiles (see prefilter_plan): one 56 x 64 block per unit
     // (two plans side by side where the lean kernel may run -- frames in flight: the one for calls that go through it, rimSplit2,
     //  and the one for calls that do not; the host picks per call, lfg_capi.cpp: motion_run.  The auxiliary arrays serve either.)

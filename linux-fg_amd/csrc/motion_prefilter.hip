@@ -423,7 +423,8 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
         // the strips the frame's motion exposes, decided completely by a kernel of their own (motion_strip.hip), which lists what it took
         if (knobs.strips && !fused.data && strip_frames_ok(prev, curr, mv)) {
             uint32_t *colBand = reinterpret_cast<uint32_t *>(workspace + l.colBand), *rowBand = reinterpret_cast<uint32_t *>(workspace + l.rowBand);
-            e = launch_motion_strip(s, prev, curr, mv, order, rank2scan, rankIsScan, colBand, rowBand, flags, sp.queueCount + 1, tilesX);
+            e = launch_motion_strip(s, prev, curr, mv, order, rank2scan, rankIsScan, colBand, rowBand, flags, sp.queueCount + 1, tilesX,
+                                    knobs.stripPad >= 0 ? knobs.stripPad : (framesInFlight ? 0 : 20 * 1024));
             if (e != hipSuccess) return e;
             sp.colBand = colBand; sp.rowBand = rowBand;
         }

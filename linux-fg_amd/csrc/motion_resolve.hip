@@ -76,8 +76,7 @@ LFG_STAMP(
     bool stripDecided = false;
     if (sp.colBand != nullptr) {
         const uint32_t cb = sp.colBand[cpy], rb = sp.rowBand[cpx];
-        stripDecided = ((cb >> 31) != 0u && (uint32_t)cpx >= (cb & 0xFFFFu) && (uint32_t)cpx <= ((cb >> 16) & 0x7FFFu)) ||
-                       ((rb >> 31) != 0u && (uint32_t)cpy >= (rb & 0xFFFFu) && (uint32_t)cpy <= ((rb >> 16) & 0x7FFFu));
+        stripDecided = strip_decided(cb, rb, cpx, cpy, W, H);
     }
     const bool live = inside && flagged == 0u && !settledSeg && !stripDecided;
     // Where this pixel's records live: one list in the image-shaped arrays, or several lists (one per unit that

@@ -1491,8 +1491,9 @@ def _strip_pairs():
 
 @pytest.mark.parametrize("case", range(11))
 @pytest.mark.parametrize("lanes", [1, 3])
-def test_strip_kernel_agrees_with_the_literal_kernel_and_the_oracle(oracle, case, lanes):
+def test_strip_kernel_agrees_with_the_literal_kernel_and_the_oracle(oracle, monkeypatch, case, lanes):
     from linux_fg_amd import capi
+    monkeypatch.setenv("LFG_MOTION_STRIP", "1")           # (opt-in: read when the context is created)
     name, prev, curr, shift = list(_strip_pairs())[case]
     H, W = prev.shape[:2]
     c = capi.Context(0)
@@ -1505,7 +1506,7 @@ def test_strip_kernel_agrees_with_the_literal_kernel_and_the_oracle(oracle, case
             c.set_semantics(sem)
             a, _ = run_motion_mode(c, prev, curr, capi.MOTION_PREFILTERED)
             rows, cols = c.motion_strip_stats()
-            # which edges a translation by `shift` exposes: the left one for shift x > 0 ... -- as the call's top hint says
+            # the edges the translation exposes (the left or the right one, the top or the bottom one) -- as the call's top hint says
             assert rows == (H if shift[0] != 0 else 0) and cols == (W if shift[1] != 0 else 0), (name, rows, cols)
             b, _ = run_motion_mode(c, prev, curr, capi.MOTION_EXACT_ONLY)
             assert (a == b).all(), f"{name}, {lanes} lanes, semantics {sem}: {(a != b).any(-1).sum()} pixels differ from the literal kernel"
@@ -1526,12 +1527,13 @@ def test_strip_kernel_agrees_with_the_literal_kernel_and_the_oracle(oracle, case
         c.close()
 
 
-def test_strip_kernel_at_4k_and_8k_against_the_oracle_on_the_strips(oracle):
+def test_strip_kernel_at_4k_and_8k_against_the_oracle_on_the_strips(oracle, monkeypatch):
     """BASELINE config 3's and config 5's sizes, the benchmark's pan (both frames upscaled on the device), frames in flight: the
     oracle ON the strips the pan exposes -- the left band across two items, the bottom band across two items, the corner where they
     meet, the rows just above the bottom band (the persistent kernel's: their blocks reach into the strip) -- and on a tile the lean
     kernel LEFT (a moving object's edge inside the frame)."""
     from linux_fg_amd import capi
+    monkeypatch.setenv("LFG_MOTION_STRIP", "1")
     c = capi.Context(0)
     try:
         c.lanes(3)
