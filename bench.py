@@ -450,6 +450,105 @@ def measure_config5(torch, capi, dev, dev_index, n_lanes, steps=24, contents=("n
     return out
 
 
+def measure_with_communicator(torch, capi, sharding, dev, dev_index, n_lanes, contents=("translated", "uncorrelated"), steps=200, probe_us=170, use_comm=True):
+    """The step every rank runs at N > 1, WITH a communicator on this GPU: a context of its own whose streams are the library's (a
+    communicator takes 8 CUs away from them: include/linuxfg_hip.h, lfg_comm_reserved_cus), a communicator of one rank, the double-
+    buffered broadcast of the shared previous INPUT frame issued a step ahead through lfg_broadcast_frame / lfg_comm_wait as on rank 0
+    of a node -- and, because one rank's ncclBroadcast launches nothing, lfg_comm_probe in its place: 8 workgroups of RCCL's device
+    kernel's footprint that stay 170 us (8.3 MB at 50 GB/s of one xGMI link).  `probe_ms_behind_its_step`: host clock from the end of
+    the step the stand-in was ordered behind to its own end, sampled without frames in flight around it."""
+    w_in, h_in = SIZES["1080p"]
+    w, h = 2 * w_in, 2 * h_in
+    ctx = capi.Context(dev_index)
+    if n_lanes > 1:
+        ctx.lanes(n_lanes)
+    try:
+        if use_comm:
+            ctx.comm_init(1, 0, capi.Context.comm_unique_id())
+    except capi.LfgError as e:
+        ctx.close()
+        return {"skipped": str(e)}
+    def frame(width, height, fmt=capi.FORMAT_RGBA8):
+        t = torch.empty((height, width, 4 if fmt == capi.FORMAT_RGBA8 else 2), dtype=torch.uint8, device=dev)
+        return t, capi.Context.wrap(t.data_ptr(), width, height, fmt)
+    slots = [frame(w_in, h_in) for _ in range(2)]
+    t_cin, f_cin = frame(w_in, h_in)
+    lanes = [(frame(w, h), frame(w, h), frame(w, h, capi.FORMAT_MV_S8X2), frame(w, h)) for _ in range(n_lanes)]
+
+    def sync_comm():
+        if use_comm:
+            ctx.comm_sync()
+
+    class Transport(sharding.CapiTransport):
+        def issue(self, slot):
+            super().issue(slot)
+            if probe_us > 0:
+                self.ctx.comm_probe(8, probe_us, every_lane=not self.lane_only)
+
+    out = {"reserved_cus": ctx.comm_reserved_cus(), "prefilter_workgroups_at_most": None, "frames_in_flight": n_lanes, "steps": steps, "by_content": {},
+           "how": "own context, library streams (CU-masked: 248 of 256 CUs), one-rank communicator; step = wait(broadcast k) + issue(broadcast k + 1 = "
+                  "lfg_broadcast_frame_lane + lfg_comm_probe(8 workgroups, 170 us)) + scale(shared) + scale(curr) + motion + interpolate; the last entry "
+                  "is the pan with the always-safe lfg_broadcast_frame, which orders the broadcast behind everything every lane has been given"}
+    for name, lane_only in [(c, True) for c in contents] + [(contents[0], False)]:
+        p_in, c_in = make_content(name, w_in, h_in, 0, 0)
+        for t, _ in slots:
+            t.copy_(torch.from_numpy(p_in))
+        t_cin.copy_(torch.from_numpy(c_in))
+        torch.cuda.synchronize(dev)
+        bc = (sharding.SharedFrameBroadcaster(2, Transport(ctx, [f for _, f in slots], src=0, behind_selected_lane_only=lane_only), world_size=2, is_source=True)
+              if use_comm else sharding.SharedFrameBroadcaster(2, None, world_size=1, is_source=True))      # (diagnostic: the same loop without any communicator call)
+        def step(k, n):
+            j = k % n
+            (_, fp4), (_, fc4), (_, fmv), (_, fout) = lanes[j]
+            if n > 1:
+                ctx.lane_select(j)
+                ctx.lane_wait((k - 1) % n)
+            ctx.scale(slots[bc.acquire(k)][1], fp4)
+            ctx.scale(f_cin, fc4)
+            if n > 1:
+                ctx.lane_mark()
+            ctx.motion(fp4, fc4, fmv, 8, 16.0)
+            ctx.interpolate(fp4, fc4, fmv, fout, 0.5)
+        def timed(first, count, n):
+            ctx.sync(); sync_comm()
+            t0 = time.perf_counter()
+            for k in range(first, first + count):
+                step(k, n)
+            ctx.sync(); sync_comm()
+            return time.perf_counter() - t0
+        n_steps = steps if name == "translated" else max(12, steps // 8)
+        timed(0, 4 * n_lanes, n_lanes)
+        t = timed(4 * n_lanes, n_steps, n_lanes)
+        # the stand-in against the step it is ordered behind, one at a time: lane 0 runs a step, the probe is issued, lane 1 runs the next
+        behind = []
+        k0 = 4 * n_lanes + n_steps
+        if n_lanes > 1:
+            for r in range(3):
+                ctx.sync(); sync_comm()
+                step(k0, n_lanes); k0 += 1               # (its acquire issues the next broadcast + probe, ordered behind this step's lane ... )
+                lane_a = ctx.lane_current()
+                step(k0, n_lanes); k0 += 1               # ( ... and the next lane's step takes the chip)
+                lane_b = ctx.lane_current()
+                ctx.lane_select(lane_a); ctx.lane_sync()
+                ta = time.perf_counter()
+                sync_comm()
+                tb = time.perf_counter()
+                ctx.lane_select(lane_b); ctx.lane_sync()
+                tc = time.perf_counter()
+                behind.append([round((tb - ta) * 1e3, 3), round((tc - tb) * 1e3, 3)])
+        bc.drain()
+        ctx.sync(); sync_comm()
+        out["by_content"][name if lane_only else name + ", broadcast ordered behind EVERY lane (lfg_broadcast_frame)"] = {"frames_per_s": round(n_steps / t, 1), "ms_per_step": round(t / n_steps * 1e3, 5), "steps": n_steps,
+                                   "probe_ms_behind_its_step_and_ms_ahead_of_the_next": behind}
+    out["prefilter_workgroups_at_most"] = ctx.motion_plan()[1]
+    if n_lanes > 1:
+        ctx.lane_select(0)
+    if use_comm:
+        ctx.comm_destroy()
+    ctx.close()
+    return out
+
+
 STREAM_SEGMENTS = (("translated", 0), ("objects", 1), ("noisy", 2), ("translated", 7))     # (content, rank: its translation -- rank_motion)
 
 
@@ -805,9 +904,13 @@ def main():
 
     ctx = capi.Context(dev_index)
     stream = torch.cuda.current_stream(dev)
-    ctx.set_stream(stream.cuda_stream)
     if world > 1 and not share_gpu:
+        # With a communicator the library's OWN streams carry the CU mask that keeps 8 CUs for RCCL's kernel (include/linuxfg_hip.h:
+        # lfg_comm_reserved_cus); torch's current stream has none, and masked streams synchronise with the NULL stream: lane 0 stays on
+        # the context's own stream.  (Every hand-over between torch and the library below is a device-wide synchronise.)
         ctx.comm_init(world, rank, sharding.exchange_comm_id(dist, capi.Context.comm_unique_id, src=0))
+    else:
+        ctx.set_stream(stream.cuda_stream)
 
     def dev_frame(host: np.ndarray):
         t = torch.from_numpy(np.ascontiguousarray(host)).to(dev)
@@ -843,8 +946,9 @@ def main():
 
     transport = None
     if world > 1:
+        # (behind the selected lane only: the step has waited for the previous step's upscales -- the last readers of the slot -- by then)
         transport = (sharding.TorchTransport(dist, [t for t, _ in prev_slots], src=0) if share_gpu
-                     else sharding.CapiTransport(ctx, [f for _, f in prev_slots], src=0))
+                     else sharding.CapiTransport(ctx, [f for _, f in prev_slots], src=0, behind_selected_lane_only=True))
     shared_prev = sharding.SharedFrameBroadcaster(len(prev_slots), transport, world_size=world, is_source=rank == 0)
 
     # Frames in flight (`pipeline` workload; include/linuxfg_hip.h "Lanes").  Step k runs on lane k % n: its own stream,
@@ -1205,6 +1309,7 @@ def main():
                                                  "how": "the step every rank runs at N > 1 -- scale(shared previous INPUT frame) + scale(curr) + motion + interpolate -- "
                                                         "on this GPU, without the broadcast: the denominator a scaling curve over N should use"}
             del slots2, bufs2
+            extras["with_communicator"] = measure_with_communicator(torch, capi, sharding, dev, dev_index, n_lanes)
         # ---- the opt-in intended semantics (lfg_set_semantics: vectors displace by pixels, ties go to the shortest vector) -- the only
         # mode whose generated frames mean anything -- on the pan and on moving objects, frames in flight as `value`
         intended = {}

@@ -329,18 +329,51 @@ int  lfg_comm_ranks(const lfg_context *ctx);      /*  0 without a communicator *
  * whichever lane they were given to) and runs next to whatever is enqueued afterwards.  Nothing enqueued later, on any
  * lane, may touch the frame before that lane has passed an lfg_comm_wait() (or waits, lfg_lane_wait, for a lane that has). */
 int  lfg_broadcast_frame(lfg_context *ctx, lfg_frame *frame, int root);
+/* The same, ordered behind what the SELECTED lane has been given so far and behind nothing else.  For a caller that has
+ * already ordered the selected lane behind the frame's last readers (on a receiver) or producers (on the root), e.g. with
+ * lfg_lane_wait for the lane that marked (lfg_lane_mark) after reading it -- which is what a step with frames in flight
+ * does anyway (linux-fg_amd/sharding.py, bench.py: step k waits for step k - 1's upscales, the last readers of the slot
+ * that step k + 1's frame lands in).  With three frames in flight the call above makes the broadcast for step k + 1 wait
+ * for ALL of step k - 1 and step k + 1 for the broadcast: two frames in flight and a bubble (measured on one MI355X
+ * with a 170 us stand-in for the broadcast, NOTES_r05.md section 7).  Misuse corrupts frames; when in doubt use the call above. */
+int  lfg_broadcast_frame_lane(lfg_context *ctx, lfg_frame *frame, int root);
 /* Make everything enqueued on the SELECTED lane from now on wait (on the device) for ALL broadcasts issued so far.
  * Contract: the communication stream is in order and one event, re-recorded behind each broadcast, stands for every
  * broadcast before it -- so with two broadcasts in flight this waits for both, never for the older one alone (a caller
  * that double-buffers, like linux-fg_amd/sharding.py, waits for slot k before it issues k + 1 and loses nothing).  Other
  * lanes are not gated: they call lfg_comm_wait themselves or order behind this lane with lfg_lane_mark / lfg_lane_wait. */
 int  lfg_comm_wait(lfg_context *ctx);
+/* The HOST waits until every broadcast issued so far has completed (the counterpart of lfg_lane_sync). */
+int  lfg_comm_sync(lfg_context *ctx);
+/* Compute units kept free for the communicator.  RCCL's device kernel (gfx950: 256 threads, 261 - 280 vector registers
+ * per lane, 19.7 KB of LDS per channel) cannot share a CU with a workgroup of the persistent motion prefilter kernel
+ * (two of them fill a CU's register files), and those stay for the whole launch: 0.3 ms under a pan, 0.7 - 7 ms on noise,
+ * uncorrelated content or a scene cut.  So while a context has a communicator, every stream the LIBRARY owns (the
+ * context's own, the lanes') carries a CU mask that leaves 8 CUs -- one in each XCD -- alone, the communication stream
+ * is masked to exactly those 8 (a high-priority stream that may use any CU does NOT find them: tools/probe_cu_reserve.hip),
+ * RCCL's kernel is limited to as many channels (ncclConfig_t::maxCTAs), and the persistent grid is sized for the other 248.
+ * lfg_comm_init makes those streams again (it waits for them first); lfg_comm_destroy gives the CUs back.
+ * LFG_COMM_CUS=0|8|16|24|32 in the environment at context creation changes the number (0: no reservation).
+ * A stream the CALLER supplied (lfg_context_set_stream) is not touched: create it with
+ * hipExtStreamCreateWithCUMask and the mask lfg_comm_cu_mask returns (`words` 32-bit words, at least CUs / 32;
+ * bit i set = CU i may be used) or accept that a broadcast waits for a persistent launch to end.
+ * (A masked stream has default flags: it synchronises with the NULL stream, which the library itself never uses.) */
+int  lfg_comm_reserved_cus(const lfg_context *ctx);      /* 0 without a communicator */
+int  lfg_comm_cu_mask(const lfg_context *ctx, uint32_t *out_words, int words);
+/* Diagnostic: enqueue, ordered like a broadcast and on the same stream, `workgroups` (1 .. 64) workgroups of
+ * the footprint of RCCL's device kernel that stay `microseconds` each (csrc/comm_probe.hip).  A communicator of ONE
+ * rank launches nothing for a broadcast; this is how a single GPU shows whether a broadcast would find a CU while the
+ * lanes hold the chip (tests/test_gpu_comm.py).  lfg_comm_wait / lfg_comm_sync treat it as a broadcast. */
+int  lfg_comm_probe(lfg_context *ctx, int workgroups, int microseconds, int every_lane /* ordered like lfg_broadcast_frame (1) or lfg_broadcast_frame_lane (0) */);
+/* Device time of the LAST probe from "everything it was ordered behind has finished" to its own end, in milliseconds
+ * (waits for it): its `microseconds` plus however long its workgroups waited for a CU. */
+int  lfg_comm_probe_ms(lfg_context *ctx, float *out_ms);
 /* Collective teardown (also done by lfg_context_destroy).  Idempotent. */
 int  lfg_comm_destroy(lfg_context *ctx);
 
 /* ---------------------------------------------------------------- diagnostics */
 
-/* The motion kernel uses a hand-written correctly rounded sqrt (csrc/motion.hip: exact_sqrt).  This
+/* The motion kernel uses a hand-written correctly rounded sqrt (csrc/lfg_motion_common.hpp: exact_sqrt).  This
  * compares it on the device with the compiler's IEEE sqrtf for every float whose bit pattern lies
  * in [lo_bits, hi_bits] and returns the number of mismatches (expected 0).  Test-suite use only. */
 int  lfg_selftest_sqrt(lfg_context *ctx, uint32_t lo_bits, uint32_t hi_bits, uint64_t *out_mismatches);

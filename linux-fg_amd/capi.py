@@ -99,6 +99,12 @@ SIGNATURES = {
     "lfg_broadcast_frame": (_i, [_vp, _FP, _i]),
     "lfg_comm_wait": (_i, [_vp]),
     "lfg_comm_destroy": (_i, [_vp]),
+    "lfg_comm_sync": (_i, [_vp]),
+    "lfg_comm_reserved_cus": (_i, [_vp]),
+    "lfg_comm_cu_mask": (_i, [_vp, ctypes.POINTER(_u32), _i]),
+    "lfg_comm_probe": (_i, [_vp, _i, _i, _i]),
+    "lfg_broadcast_frame_lane": (_i, [_vp, _FP, _i]),
+    "lfg_comm_probe_ms": (_i, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "lfg_diag_scale_2x_strip": (_i, [_u32, _u32, _u32, ctypes.POINTER(_u32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "lfg_profile_enable": (_i, [_vp, _i]),
     "lfg_profile_reset": (_i, [_vp]),
@@ -115,6 +121,11 @@ def load() -> ctypes.CDLL:
         if not os.path.exists(LIB_PATH):
             raise LfgError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback)")
+        # HIP gives a process four hardware queues unless told otherwise, and streams beyond that share them: three lanes, a
+        # communication stream and a framework's own stream are five -- two lanes on one queue run in turn (measured on the MI355X:
+        # 3,684 -> 2,750 frames/s for every context of a process but its first; NOTES_r05.md section 7).  Read by the HIP runtime at
+        # its first call, so this has effect only if nothing in the process has touched the GPU yet; an explicit setting wins.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the symbol is not exported
@@ -391,6 +402,34 @@ class Context:
 
     def comm_wait(self):
         self._check(self.lib.lfg_comm_wait(self.h), "lfg_comm_wait")
+
+    def comm_sync(self):
+        """The host waits for every broadcast issued so far."""
+        self._check(self.lib.lfg_comm_sync(self.h), "lfg_comm_sync")
+
+    def comm_reserved_cus(self) -> int:
+        """CUs the library's own streams leave to the communicator (0 without one)."""
+        return int(self.lib.lfg_comm_reserved_cus(self.h))
+
+    def comm_cu_mask(self, words: int = 8) -> list[int]:
+        """The CU mask (32-bit words, bit i = CU i usable) a caller-supplied compute stream should be created with."""
+        buf = (_u32 * words)()
+        self._check(self.lib.lfg_comm_cu_mask(self.h, buf, words), "lfg_comm_cu_mask")
+        return [int(x) for x in buf]
+
+    def comm_probe(self, workgroups: int = 8, microseconds: int = 50, every_lane: bool = True):
+        """Diagnostic: a kernel of RCCL's device kernel's footprint where a broadcast would run (csrc/comm_probe.hip)."""
+        self._check(self.lib.lfg_comm_probe(self.h, workgroups, microseconds, int(every_lane)), "lfg_comm_probe")
+
+    def comm_probe_ms(self) -> float:
+        """Device milliseconds of the last probe from ready to done (waits for it)."""
+        ms = ctypes.c_float()
+        self._check(self.lib.lfg_comm_probe_ms(self.h, ctypes.byref(ms)), "lfg_comm_probe_ms")
+        return float(ms.value)
+
+    def broadcast_frame_lane(self, f: Frame, root: int = 0):
+        """lfg_broadcast_frame ordered behind the selected lane only (the caller has ordered that lane behind the frame's readers)."""
+        self._check(self.lib.lfg_broadcast_frame_lane(self.h, ctypes.byref(f), root), "lfg_broadcast_frame_lane")
 
     def comm_destroy(self):
         self._check(self.lib.lfg_comm_destroy(self.h), "lfg_comm_destroy")

@@ -239,7 +239,7 @@ int ensure_motion_tables(lfg_context *ctx) {
 
 // ---- scratch of the prefiltered motion path (per frame size; kept between calls)
 
-// Parts of the candidate order per rim segment (motion.hip: prefilter_plan), measured at 4K (frames/s):
+// Parts of the candidate order per rim segment (motion_plan.hip: prefilter_plan), measured at 4K (frames/s):
 //   4   the default with frames in flight (lfg_lanes >= 2), where the sum of all units' times is what counts: pan 2,838;
 //   48  four, and eight for the segments whose position rows leave the image at its top or bottom -- the strip a vertical pan
 //       exposes is the longest unit of a frame, and the launch is as long as its longest unit when ONE frame runs at a time:
@@ -260,6 +260,13 @@ int motion_rim_split(const lfg_context *ctx) {
 // frames in flight; noise -5 %, stills -4 %: which is why it is this plan only for those calls).  Both plans are resident.
 int motion_rim_split_lean(const lfg_context *ctx) {
     return (ctx->motion_lean && ctx->lanes.size() >= 2 && !ctx->rim_split_env) ? 48 : 0;
+}
+
+// Workgroups of the persistent kernel a launch of this context may have: what the device holds at once -- less the CUs a communicator
+// keeps, where the library's streams cannot place any (lfg_own_stream_create).
+int persistent_grid_most(const lfg_context *ctx) {
+    if (ctx->comm_cus <= 0 || ctx->device_cus <= ctx->comm_cus) return ctx->motion_slots;
+    return ctx->motion_slots / ctx->device_cus * (ctx->device_cus - ctx->comm_cus);
 }
 
 int ensure_motion_workspace(lfg_context *ctx, uint32_t width, uint32_t height) {
@@ -360,6 +367,45 @@ struct lfg_ring {
 
 // ================================================================== library / context
 
+// A stream of the library's own.  While a communicator exists (ctx->comm_cus > 0, lfg_comm.cpp) it carries a CU mask that leaves
+// the first comm_cus CUs to the communication stream, which is masked to exactly those: RCCL's device kernel needs CUs without a
+// persistent prefilter workgroup on them (comm_probe.hip), and only the pair of masks guarantees it gets them (lfg_comm_init).  Mask bit i is CU i / 8 of XCD i % 8 on an MI355X (tools/probe_cu_mask.hip
+// on the device: clearing bits 0 - 7 takes one CU out of each of the eight XCDs), so 8 | 16 | 24 | 32 bits are 1 - 4 CUs per XCD, where
+// the hardware's round-robin of workgroups over the XCDs puts the communicator's 8 - 32 channels.
+// (A stream made by hipExtStreamCreateWithCUMask has default flags: it synchronises with the NULL stream, which the library never uses.)
+hipError_t lfg_own_stream_create(const lfg_context *ctx, hipStream_t *out) {
+    if (!ctx || ctx->comm_cus <= 0) return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    int cus = 0;
+    hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    if (e != hipSuccess) return e;
+    if (cus <= ctx->comm_cus) return hipErrorInvalidValue;
+    std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0xffffffffu);
+    if (cus % 32) mask.back() = (1u << (cus % 32)) - 1u;
+    for (int i = 0; i < ctx->comm_cus; ++i) mask[(size_t)i / 32] &= ~(1u << (i % 32));
+    return hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data());
+}
+
+// Every stream the library owns is made again under the current reservation (the communicator has just come or gone).  A stream the
+// caller supplied (lfg_context_set_stream) is the caller's to mask: lfg_comm_cu_mask says how.
+int lfg_restream(lfg_context *ctx) {
+    LFG_HIP(ctx, hipSetDevice(ctx->device));
+    auto again = [&](hipStream_t &own, hipStream_t &used) -> hipError_t {
+        if (!own) return hipSuccess;
+        hipError_t e = hipStreamSynchronize(own);
+        hipStream_t fresh = nullptr;
+        if (e == hipSuccess) e = lfg_own_stream_create(ctx, &fresh);
+        if (e != hipSuccess) return e;
+        (void)hipStreamDestroy(own);
+        if (used == own) used = fresh;
+        own = fresh;
+        return hipSuccess;
+    };
+    LFG_HIP(ctx, again(ctx->own_stream, ctx->stream));
+    for (size_t j = 0; j < ctx->lanes.size(); ++j)
+        if ((int)j != ctx->lane) LFG_HIP(ctx, again(ctx->lanes[j].own_stream, ctx->lanes[j].stream));     // (the selected lane's are the context's own fields)
+    return LFG_OK;
+}
+
 LFG_EXPORT int lfg_abi_version(void) { return LFG_ABI_VERSION; }
 
 LFG_EXPORT int lfg_device_count(void) {
@@ -382,7 +428,8 @@ LFG_EXPORT int lfg_context_create(int device_ordinal, lfg_context **out_ctx) {
     lfg_context *ctx = new (std::nothrow) lfg_context();
     if (!ctx) return fail(nullptr, LFG_ERR_NOMEM, "lfg_context_create: out of host memory");
     ctx->device = dev;
-    e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    (void)hipDeviceGetAttribute(&ctx->device_cus, hipDeviceAttributeMultiprocessorCount, dev);
+    e = lfg_own_stream_create(ctx, &ctx->own_stream);
     if (e != hipSuccess) { delete ctx; return fail_hip(nullptr, e, "hipStreamCreate"); }
     ctx->stream = ctx->own_stream;
     ctx->tables.reserve(17);                 // AxisTable pointers handed out stay valid
@@ -403,6 +450,7 @@ LFG_EXPORT int lfg_context_create(int device_ordinal, lfg_context **out_ctx) {
     if (getenv("LFG_DEBUG")) ctx->knobs.debug = 1;
     if (getenv("LFG_DEBUG_DYN")) ctx->knobs.debugDyn = 1;
     if (const char *m = getenv("LFG_DEBUG_DYN_DEEP")) ctx->knobs.debugDynDeep = atoi(m);
+    if (const char *m = getenv("LFG_COMM_CUS")) { const int v = atoi(m); if (v == 0 || v == 8 || v == 16 || v == 24 || v == 32) ctx->knobs.commCus = v; }
     *out_ctx = ctx;
     return LFG_OK;
 }
@@ -483,7 +531,7 @@ LFG_EXPORT int lfg_lanes(lfg_context *ctx, int count) {
     while ((int)ctx->lanes.size() > count) { lane_release(ctx->lanes.back()); ctx->lanes.pop_back(); }
     while ((int)ctx->lanes.size() < count) {
         lfg_lane_state l;
-        hipError_t e = hipStreamCreateWithFlags(&l.own_stream, hipStreamNonBlocking);
+        hipError_t e = lfg_own_stream_create(ctx, &l.own_stream);
         if (e != hipSuccess) return fail_hip(ctx, e, "hipStreamCreate (lane)");
         l.stream = l.own_stream;
         ctx->lanes.push_back(l);
@@ -802,10 +850,11 @@ static int motion_run(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *
         bool othersBusy = false;
         for (size_t j = 0; j < ctx->lanes.size() && !othersBusy; ++j)
             if ((int)j != ctx->lane && ctx->lanes[j].stream && hipStreamQuery(ctx->lanes[j].stream) == hipErrorNotReady) othersBusy = true;
-        const int groupsCap = (flagWanted && othersBusy && ((uint32_t)ctx->lean_predict >> 31) != 0u) ? std::max(1, ctx->motion_slots * 5 / 8) : 0;
+        int groupsCap = (flagWanted && othersBusy && ((uint32_t)ctx->lean_predict >> 31) != 0u) ? std::max(1, ctx->motion_slots * 5 / 8) : 0;
         // ... and bit 30 whether that call sent a tile through the literal kernel (flat content under a fade, exact ties): if not, this
         // call's fallback launch is 64 workgroups instead of 2,048 -- they take whatever it flags after all, in turns (1.4 % of the
         // frame rate under a pan: workgroups of 42 KB of LDS that read a count and leave still have to be placed)
+        if (ctx->comm_cus > 0) groupsCap = groupsCap ? std::min(groupsCap, persistent_grid_most(ctx)) : persistent_grid_most(ctx);
         const bool expectNoFallback = flagWanted && ctx->lean_seen && (((uint32_t)ctx->lean_predict >> 30) & 1u) == 0u && !ctx->knobs.fallbackFull /* (measurement) */;
         e = lfg::launch_motion_prefiltered_8_16(ctx->stream, *prev, *curr, *mv, ctx->motion_ws, ctx->motion_ws_layout, ctx->motion_units,
                                                 rank2scan, order32, order32 + lfg::kMotionTableWords,
@@ -855,7 +904,7 @@ LFG_EXPORT int lfg_motion_workspace_size(lfg_context *ctx, uint32_t width, uint3
 LFG_EXPORT int lfg_motion_plan(const lfg_context *ctx, int *out_rim_split, int *out_workgroups) {
     if (!ctx) return LFG_ERR_INVALID;
     if (out_rim_split) *out_rim_split = motion_rim_split(ctx);
-    if (out_workgroups) *out_workgroups = ctx->motion_slots;
+    if (out_workgroups) *out_workgroups = persistent_grid_most(ctx);
     return LFG_OK;
 }
 

@@ -103,11 +103,12 @@ struct MotionKnobs {
     int debug = 0;            // LFG_DEBUG: reporting calls print what they read
     int debugDyn = 0;         // LFG_DEBUG_DYN: lfg_motion_last_stats prints the deepest private lists of the handed-over segments,
     int debugDynDeep = 14;    // LFG_DEBUG_DYN_DEEP: ... deeper than this
+    int commCus = 8;          // LFG_COMM_CUS = 0 | 8 | 16 | 24 | 32: CUs a communicator keeps free of the library's own kernels (lfg_comm.cpp)
 };
 
 struct MotionWorkspaceLayout { size_t colBand, rowBand /* [height], [width] words of the strip kernel (motion_strip.hip), inside the control area the hint kernel clears */; size_t verdict /* byte offset of the call's verdict word, order32[kCand + 2] of its own order table; orderFlags: of [kCand] */, orderFlags; size_t list, umin, count, tileFlags, segDone, segMap, queueCount, ctrl, order, plan, auxList, auxUmin, auxCount,
                                queue, dynList, dynUmin, dynCount, dynInit, openList, merge, mergeBytes, leanTiles, hardTiles, plan2, total; int queueCap, slots, rimSplit, listMain, listAux, listDyn, leanCount, leanLaunch /* with the partial tiles behind them */, rimSplit2, units, units2, units2Static /* the second plan's units without the lean kernel's tiles, which come last in its table */, tiles, lastLean /* the lane's last call went by the second plan */; };
-// Work units of the motion prefilter (motion.hip: prefilter_plan).  A unit is a 56 x 64 tile, or one of nChunks
+// Work units of the motion prefilter (motion_plan.hip: prefilter_plan).  A unit is a 56 x 64 tile, or one of nChunks
 // contiguous parts of a tile's candidate order, or one 16-row segment of a tile with its four waves on four parts of
 // the order; parts have private lists in the aux arrays (merged by the resolve kernel).
 struct PrefilterPlan {               // passed by value to the kernels
@@ -115,7 +116,7 @@ struct PrefilterPlan {               // passed by value to the kernels
     const uint32_t *unitMap;         // per unit: tile | (first) chunk << 20 | nChunks << 24 | segment unit << 28 | segment << 29
     const uint32_t *unitAux;         // per unit: index of its tile's first 56 x 64 block in the aux arrays (whole tiles: 0xFFFFFFFF)
     const uint32_t *tileMap;         // per tile: 0xFFFFFFFF (whole) or first aux index | nChunks << 24
-    uint32_t *auxList;               // records: csrc/motion.hip, Rec
+    uint32_t *auxList;               // records: csrc/lfg_motion_common.hpp, Rec
     float *auxUmin;
     uint32_t *auxCount;
     // Segments handed over at run time (a whole tile's segment that finds no match after the first batches): a queue
@@ -177,6 +178,7 @@ struct lfg_lane_state {
 
 struct lfg_context {
     int device = 0;
+    int device_cus = 0;                        // its compute units
     std::vector<lfg_lane_state> lanes;         // empty until lfg_lanes(); entry `lane` is stale while that lane is selected
     int lane = 0;
     hipEvent_t mark = nullptr;                 // the selected lane's (see lfg_lane_state)
@@ -218,6 +220,8 @@ struct lfg_context {
     hipStream_t comm_stream = nullptr;
     hipEvent_t comm_ready = nullptr, comm_done = nullptr;
     bool comm_pending = false;                 // some broadcast has been issued on this communicator (comm_done has been recorded)
+    hipEvent_t probe_begin = nullptr, probe_end = nullptr;     // lfg_comm_probe: device timestamps, ready and done
+    int comm_cus = 0;                          // CUs the library's own streams leave to the communicator's kernels (0: none reserved)
     // profiling
     bool profile = false;
     std::vector<lfg::ProfileSlot> prof_pending;
@@ -226,9 +230,17 @@ struct lfg_context {
     uint64_t prof_n[LFG_STAGE_COUNT] = {0, 0, 0};
 };
 
+// A stream of the library's own (lfg_capi.cpp): non-blocking; with `ctx->comm_cus` CUs reserved for a communicator, a stream whose
+// CU mask leaves those free.  lfg_restream: every stream the library owns is made again under the current reservation.
+hipError_t lfg_own_stream_create(const lfg_context *ctx, hipStream_t *out);
+int lfg_restream(lfg_context *ctx);
+
 namespace lfg {
 
-// Kernel launchers (scale.hip, motion.hip, interpolate.hip).  All enqueue on `s` and return the
+// A kernel of the footprint of RCCL's device kernel (comm_probe.hip): what lfg_comm_probe puts where a broadcast would run.
+hipError_t launch_comm_probe(hipStream_t s, int workgroups, int microseconds);
+
+// Kernel launchers (scale.hip, motion_*.hip, interpolate.hip).  All enqueue on `s` and return the
 // launch status; arguments have been validated by the caller.
 hipError_t launch_scale_generic(hipStream_t s, const lfg_frame &in, const lfg_frame &out,
                                 const AxisTable &tx, const AxisTable &ty);
@@ -243,10 +255,10 @@ hipError_t launch_motion_tiled_8_16(hipStream_t s, const lfg_frame &prev, const 
                                     const lfg_frame &mv, const uint32_t *tileFlags, const uint32_t *rank2scan,
                                     unsigned long long *merge = nullptr, uint32_t *flaggedTiles = nullptr, const FusedOut &fused = FusedOut(),
                                     bool expectNothing = false, uint32_t *verdictWord = nullptr, uint32_t *hostWord = nullptr);
-// Candidate tables of the blockSize 8 / searchRadius 16 paths for one tie-break rule (motion.hip: motion_tables).
+// Candidate tables of the blockSize 8 / searchRadius 16 paths for one tie-break rule (motion_order.hip: motion_tables).
 constexpr int kMotionTableWords = 1092;     // 33 * 33 candidates + the sentinel, padded to a multiple of 4
 void motion_tables(bool intended, uint32_t *rank2scan, uint32_t *order32, uint32_t *entryOfScan, uint32_t *baseScan);
-// Prefiltered motion path (motion.hip): MotionWorkspaceLayout = byte offsets of its scratch arrays.
+// Prefiltered motion path (motion_plan.hip, motion_prefilter.hip): MotionWorkspaceLayout = byte offsets of its scratch arrays.
 size_t motion_workspace_bytes(uint32_t width, uint32_t height, int slots, int rimSplit, int rimSplit2, MotionWorkspaceLayout *layout);   // rimSplit2: the plan used beside the lean kernel (0: none)
 PrefilterPlanHost prefilter_plan(uint32_t width, uint32_t height, int slots, int rimSplit);   // rimSplit: 4 or 8 parts of the order per rim segment
 int prefilter_slots();      // workgroups of the prefilter kernel the current device holds at once

@@ -1,4 +1,4 @@
-// Geometry and constants of the prefiltered motion path shared by csrc/motion.hip (the generic persistent kernel and everything
+// Geometry and constants of the prefiltered motion path shared by csrc/motion_prefilter.hip (the generic persistent kernel and everything
 // around it) and csrc/motion_lean.hip (the lean kernel for whole interior tiles).  blockSize 8, searchRadius 16:
 // shaders/motion.comp:16-57 as dispatched by src/frame_manager.cpp:325-344.
 #pragma once
@@ -26,12 +26,12 @@ static_assert(kLatC0 + 8 * (kLatCols - 1) == kPTW - 1 && kLatR0 + 8 * (kLatRows 
               "one lattice point in every pixel's block: the first at the far end of pixel 0's, the last at the near end of the last pixel's");
 constexpr int kRun = 7;                           // pixels per row-sum run: 8 runs x 7 = 56
 constexpr int kRunIn = kRun + kB - 1;             // 13
-constexpr float kRatio = 1.00008f;      // >= (1 + 3.6e-5) / (1 - 3.6e-5) with room for the product's rounding ("Bracket", motion.hip)
+constexpr float kRatio = 1.00008f;      // >= (1 + 3.6e-5) / (1 - 3.6e-5) with room for the product's rounding ("Bracket", motion_prefilter.hip)
 constexpr float kRestart = 0.9997f;     // S~ < thr kRestart: every earlier record of the pixel is dead ((1 - 2^-13) / kRatio^2 = 1 - 2.8e-4, with room)
 static_assert(kRestart < (1.0 - 1.0 / 8192.0) / (1.00008 * 1.00008) - 1e-5, "restart rule");
 static_assert(kPTW + kB - 1 <= 64 && kWinW >= kPTW + kB - 1 + 2 * kR, "one lane per position column");
 static_assert(kCand < 2048, "a rank fits eleven bits");
-// The one-point test alone decides while the wave's largest threshold is below this (motion.hip: LFG_ONEPOINT_MAX); the lean
+// The one-point test alone decides while the wave's largest threshold is below this (lfg_motion_tune.hpp: LFG_ONEPOINT_MAX); the lean
 // kernel keeps a segment only while that holds.
 constexpr float kOnePointOnly = 32.0f;
 // The strip kernel (motion_strip.hip) decides the outermost kStripCols pixel columns (left, right) and kStripRows pixel rows (top,
@@ -40,6 +40,6 @@ constexpr float kOnePointOnly = 32.0f;
 // so per pixel row / column: colBand[y] bit 0 = the left band of row y, bit 1 = the right band; rowBand[x] bit 0 = the top band of
 // column x, bit 1 = the bottom band (lfg_motion_common.hpp: strip_decided).
 constexpr int kStripCols = 12, kStripRows = 8;
-constexpr float kSadTestMax = 8.0f;     // ... by sums of absolute differences below this (motion.hip: LFG_SAD_TEST_MAX)
+constexpr float kSadTestMax = 8.0f;     // ... by sums of absolute differences below this (lfg_motion_tune.hpp: LFG_SAD_TEST_MAX)
 
 }  // namespace lfg

@@ -1,6 +1,6 @@
 // motion_lean.hip -- the prefilter of shaders/motion.comp:27-52 for the tiles that need almost none of it.
 //
-// Under a pan, or where nothing moves, nine work units in ten of the prefiltered motion path (csrc/motion.hip) are whole tiles
+// Under a pan, or where nothing moves, nine work units in ten of the prefiltered motion path (csrc/motion_prefilter.hip) are whole tiles
 // away from the image's rim whose every pixel finds its answer in the call's first hint: one evaluation (or none: the hint reads
 // the very bytes of the current frame), after which every other candidate fails the cheapest test there is -- one texel compare
 // at each of the 14 lattice points that put a point into every pixel's 8 x 8 block (lfg_motion_tile.hpp).  The generic persistent
@@ -11,13 +11,13 @@
 // window of its tiles lies inside prev), no queue, no parts of the order.  A wave owns a 16-row segment of a 56 x 64 tile as in
 // the generic kernel and keeps, per pixel, what the bracket argument needs and nothing else:
 //     thr   kRatio x the smallest S~ seen (or, for a candidate whose S~ is 0 and whose cost therefore is exactly 0, the smallest
-//           such rank, carried inside the word: motion.hip, "zeroCap"),
+//           such rank, carried inside the word: prefilter_records.inc, "zeroCap"),
 //     best  the rank of the candidate that set it,
 //     amb   "a second candidate came within the bracket of the best one" -- only the literal 64-term chain can decide between two
 //           such candidates, and this kernel has no business there.
 // S~ is the generic kernel's bracket value -- exact integer squared distances, v_sqrt_f32, a depth-6 pairwise tree: within 9 u of
 // 255 x the shader's real-arithmetic cost -- so "the only evaluated candidate with S~ <= kRatio min S~" IS the shader's first
-// strict minimum (motion.hip, "Bracket"); every candidate that is not evaluated in full has a lattice distance above the wave's
+// strict minimum (motion_prefilter.hip, "Bracket"); every candidate that is not evaluated in full has a lattice distance above the wave's
 // largest threshold and S~, a rounded sum of non-negative distances, is never below any of its terms.
 // A segment that does not fit the pattern -- its largest threshold after the hints is not small (noise, a moving object's rim,
 // an occlusion: the four- and sixteen-point tests, the narrow search and the hand-over are the generic kernel's), or two
@@ -53,7 +53,7 @@ struct LeanState {
     uint32_t amb;              // bit i: pixel i of row r8, bit 16 + i: of row r8 + 8
 };
 
-// n = |c|^2 + |p|^2 - 2 c.p as a float without conversions (motion.hip: columnSums): the dot products accumulate onto float bit
+// n = |c|^2 + |p|^2 - 2 c.p as a float without conversions (prefilter_sums.inc: columnSums): the dot products accumulate onto float bit
 // patterns, 0x4B000000 + k = 2^23 + k and 0x4B800000 + k = 2^24 + 2 k.
 __device__ __forceinline__ float lean_sqdist(uint32_t c, uint32_t cc, uint32_t p) {
     const float f1 = __builtin_bit_cast(float, __builtin_amdgcn_udot4(p, p, cc, false));
@@ -98,7 +98,7 @@ __device__ __forceinline__ void lean_update(LeanState &st, const f32x2 (&s2)[kRu
             const float cap = __builtin_fmaxf(s * kRatio, zeroCap);            // (zeroCap only for s == 0)
             const float t = pass ? __builtin_fminf(thr, cap) : thr;
             if (hb) st.thr[i].y = t; else st.thr[i].x = t;
-            // a candidate that undercuts the threshold by more than the bracket is wide kills everything before it (motion.hip,
+            // a candidate that undercuts the threshold by more than the bracket is wide kills everything before it (motion_prefilter.hip,
             // `restart`); one that merely passes stands beside the best one: ambiguous
             const bool record = pass && s != 0.0f;
             const bool restart = s < thr * kRestart;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(kPNT, 3) void motion_lean_kernel(
     const int tileY = tile / tilesX, tileX = tile - tileY * tilesX;
     const int tx0 = tileX * kPTW, ty0 = tileY * kPTH;
     const int bx0 = tx0 - kB / 2, by0 = ty0 - kB / 2;                  // image coordinates of block position (0, 0)
-    // this call's order: entry = rank | window offset << 16 (motion.hip: motion_order_kernel); [kCand + 1]: entries in front that are hints
+    // this call's order: entry = rank | window offset << 16 (motion_order.hip: motion_order_kernel); [kCand + 1]: entries in front that are hints
     // [kCand + 2]: most of the call's sample blocks have a near-exact match (motion_order_kernel) -- otherwise this is not the
     // content the kernel is for, and every workgroup leaves before it has staged anything
     // (a tile in which anything is left goes onto the list the generic kernel draws from behind its own table: here, all of them)
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(kPNT, 3) void motion_lean_kernel(
         lean_update(st, s2, rank);
     };
 
-    // The one-point test of `kA` candidates per lane at once (motion.hip, "LOOKAHEAD"): does some lattice point of the candidate
+    // The one-point test of `kA` candidates per lane at once (prefilter_tests.inc, "LOOKAHEAD"): does some lattice point of the candidate
     // come within the wave's largest threshold of the current frame's texel there?  By exact compare while the thresholds stand
     // for zero costs, by sums of absolute differences while they are small (a distance is at least half its SAD), by the
     // squared distance otherwise.
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(kPNT, 3) void motion_lean_kernel(
         open = open || (!(fx < 0.5f) && ((st.amb >> i) & 1u)) || (!(fy < 0.5f) && ((st.amb >> (16 + i)) & 1u));
     }
     if (__builtin_amdgcn_readfirstlane(__ballot(open) == 0ull)) {
-        // the 16 x 56 vectors through the wave's slab, out as 112 contiguous bytes per image row (motion.hip: "Settled in place")
+        // the 16 x 56 vectors through the wave's slab, out as 112 contiguous bytes per image row (prefilter_epilogue.inc)
         uint16_t *const rows = reinterpret_cast<uint16_t *>(sSlab[wave]);
         wave_lds_sync();
 #pragma unroll

@@ -44,6 +44,9 @@ static void PrintUsage() {
 }
 
 int main(int argc, char* argv[]) {
+    // (HIP's default of four hardware queues is one short of three lanes + a copy stream + a communication stream: streams that
+    //  share a queue run in turn.  Before the first HIP call; an explicit setting wins.  INTEGRATION.md, "Hardware queues".)
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     ScalerConfig config;
     config.enableInterpolation = true;
     config.interpolationFactor = 0.5f;

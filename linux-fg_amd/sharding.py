@@ -42,11 +42,19 @@ def exchange_comm_id(dist, make_id: Callable[[], bytes], src: int = 0, nbytes: i
 class CapiTransport:
     """The product transport: lfg_broadcast_frame / lfg_comm_wait on a context that has a communicator."""
 
-    def __init__(self, ctx, frames, src: int = 0):
-        self.ctx, self.frames, self.src = ctx, list(frames), src
+    def __init__(self, ctx, frames, src: int = 0, behind_selected_lane_only: bool = False):
+        """``behind_selected_lane_only``: lfg_broadcast_frame_lane -- for a step that has already ordered the selected lane
+        behind the last readers of the slot about to be overwritten (``lane_wait`` for the previous step's upscales, which
+        read slot (k + 1) % 2 last: SharedFrameBroadcaster issues the broadcast for step k + 1 inside step k's ``acquire``).
+        The default orders a broadcast behind everything every lane has been given: always safe, but with three frames in
+        flight step k + 1 then waits for all of step k - 1."""
+        self.ctx, self.frames, self.src, self.lane_only = ctx, list(frames), src, behind_selected_lane_only
 
     def issue(self, slot: int):
-        self.ctx.broadcast_frame(self.frames[slot], self.src)
+        if self.lane_only:
+            self.ctx.broadcast_frame_lane(self.frames[slot], self.src)
+        else:
+            self.ctx.broadcast_frame(self.frames[slot], self.src)
 
     def wait(self, slot: int):
         self.ctx.comm_wait()

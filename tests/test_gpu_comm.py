@@ -80,21 +80,24 @@ def test_shared_frame_broadcast_with_frames_in_flight():
             pinned = [ctx.staging_create(w * h * 4) for _ in range(steps + 1)]      # (asynchronous uploads: nothing here waits)
             for a, f in zip(pinned, frames):
                 a[:] = f.reshape(-1)
-            bcast = sharding.SharedFrameBroadcaster(
-                2, sharding.CapiTransport(ctx, slots, src=0), world_size=2, is_source=True,
-                refill=lambda step, slot: ctx.upload_async(slots[slot], pinned[step]))
-            bcast.start(0)
-            for k in range(steps):
-                ctx.lane_select(k % lanes)
-                ctx.lane_wait((k - 1) % lanes)
-                slot = bcast.acquire(k)
-                ctx.scale(slots[slot], ups[k])
-                ctx.lane_mark()
-                ctx.motion(ups[k], ups[k], mvs[k % lanes], 8, 16.0)      # something long on this lane after its upscale
-            bcast.drain()
-            ctx.sync()
-            for k in range(steps):
-                assert (ctx.download(ups[k]) == want[k]).all(), (lanes, k)
+            for lane_only in (False, True):                   # lfg_broadcast_frame, and lfg_broadcast_frame_lane: the step's lane_wait is what makes it safe
+                bcast = sharding.SharedFrameBroadcaster(
+                    2, sharding.CapiTransport(ctx, slots, src=0, behind_selected_lane_only=lane_only), world_size=2, is_source=True,
+                    refill=lambda step, slot: ctx.upload_async(slots[slot], pinned[step]))
+                ctx.lane_select(0)
+                bcast.start(0)
+                for k in range(steps):
+                    ctx.lane_select(k % lanes)
+                    ctx.lane_wait((k - 1) % lanes)
+                    slot = bcast.acquire(k)
+                    ctx.scale(slots[slot], ups[k])
+                    ctx.lane_mark()
+                    ctx.motion(ups[k], ups[k], mvs[k % lanes], 8, 16.0)      # something long on this lane after its upscale
+                bcast.drain()
+                ctx.sync()
+                for k in range(steps):
+                    assert (ctx.download(ups[k]) == want[k]).all(), (lanes, lane_only, k)
+                    ctx.upload(ups[k], np.zeros((2 * h, 2 * w, 4), np.uint8))
             ctx.lane_select(0)
             for f in slots + ups + mvs:
                 ctx.destroy_frame(f)
@@ -143,3 +146,96 @@ def test_broadcast_is_ordered_after_every_lane():
         for x in (f, up, fa, fb, mv):
             ctx.destroy_frame(x)
         ctx.lanes(1)
+
+
+def _probe_behind_a_full_grid(capi, inputs, rounds=3):
+    """Lane 0 runs a motion call that keeps the persistent kernel busy for a millisecond or two (a pan under sensor noise of +-8
+    levels), a probe of RCCL's device kernel's footprint is issued like a broadcast (it becomes ready when lane 0's call has
+    finished), and lane 1 is given a call on uncorrelated content at once (a persistent launch of 7 ms) -- whichever way the two
+    launches share the chip at first, lane 1's holds all of it for milliseconds once lane 0's has run out of work.  Returns, per
+    round, the probe's DEVICE time from ready to done (lfg_comm_probe_ms: 50 us of its own) and the host's milliseconds from
+    the probe's end to lane 1's."""
+    import time
+    out = []
+    with capi.Context(0) as ctx:
+        ctx.lanes(2)
+        ctx.comm_init(1, 0, capi.Context.comm_unique_id())
+        reserved = ctx.comm_reserved_cus()
+        h, w = inputs[0][0].shape[:2]
+        frames = []
+        for pair in inputs:                                   # upscaled like the benchmark's contents
+            ups = []
+            for x in pair:
+                f, up = ctx.frame_from(x), ctx.create_frame(2 * w, 2 * h)
+                ctx.scale(f, up)
+                ctx.sync()
+                ctx.destroy_frame(f)
+                ups.append(up)
+            frames.append(ups)
+        mvs = [ctx.create_frame(2 * w, 2 * h, capi.FORMAT_MV_S8X2) for _ in range(2)]
+        for j in range(2):                                    # workspaces, tables, verdicts: not in the measurement
+            ctx.lane_select(j)
+            ctx.motion(frames[j][0], frames[j][1], mvs[j], 8, 16.0)
+        ctx.sync()
+        for _ in range(rounds):
+            ctx.lane_select(0)
+            ctx.motion(frames[0][0], frames[0][1], mvs[0], 8, 16.0)
+            ctx.comm_probe(8, 50)
+            ctx.lane_select(1)
+            ctx.motion(frames[1][0], frames[1][1], mvs[1], 8, 16.0)
+            ms = ctx.comm_probe_ms()
+            t1 = time.perf_counter()
+            ctx.lane_sync()
+            out.append((ms, (time.perf_counter() - t1) * 1e3))
+        ctx.lane_select(0)
+        ctx.sync()
+        for x in [f for pair in frames for f in pair] + mvs:
+            ctx.destroy_frame(x)
+        ctx.lanes(1)
+    return reserved, out
+
+
+def test_a_broadcast_finds_a_cu_while_a_full_persistent_grid_runs(monkeypatch):
+    """RCCL's device kernel cannot share a CU with a workgroup of the persistent prefilter kernel, and
+    those stay for the whole launch -- so while a communicator exists the library's streams leave 8 CUs alone (CU masks).
+    A communicator of one rank launches nothing for a broadcast; lfg_comm_probe puts a kernel of the same footprint where
+    the broadcast would run.  With the reservation it runs as soon as it is ready, milliseconds before the call that holds
+    the chip by then ends; without (LFG_COMM_CUS=0) it waits for room in that call's persistent launch -- printed only."""
+    from linux_fg_amd import capi
+    w, h = 1920, 1080
+    prev = synth.make_prev(w, h, seed=811)
+    noise = synth.noise_bytes(w, h, 861) % 17
+    inputs = [(prev, np.clip(synth.translate(prev, (3, -2), 811).astype(np.int16) + noise.astype(np.int16) - 8, 0, 255).astype(np.uint8)),
+              (prev, synth.noise_bytes(w, h, 862))]
+    monkeypatch.delenv("LFG_COMM_CUS", raising=False)
+    reserved, with_cus = _probe_behind_a_full_grid(capi, inputs)
+    assert reserved == 8
+    monkeypatch.setenv("LFG_COMM_CUS", "0")
+    none, without = _probe_behind_a_full_grid(capi, inputs)
+    assert none == 0
+    print("probe ready -> done (device ms) / lane 1 behind the probe (host ms): 8 CUs kept", [(round(a, 3), round(b, 3)) for a, b in with_cus],
+          "none kept", [(round(a, 3), round(b, 3)) for a, b in without])
+    for took, ahead in with_cus:
+        assert took < 0.15, with_cus                         # the probe's own 50 us and a launch (measured: 0.054 - 0.055)
+        assert ahead > 0.5, with_cus                         # ... while the other call still has a millisecond or more to go
+    # (without the reservation, measured: 0.055, 0.505, 0.482 ms -- the probe gets in when workgroups of the persistent launch happen to
+    #  have left a CU of the shader engine its workgroups are handed to; nothing to assert on)
+
+
+def test_the_cu_mask_of_a_communicator_and_its_return():
+    from linux_fg_amd import capi
+    with capi.Context(0) as ctx:
+        full = ctx.comm_cu_mask()
+        assert ctx.comm_reserved_cus() == 0 and full == [0xFFFFFFFF] * 8
+        ctx.comm_init(1, 0, capi.Context.comm_unique_id())
+        assert ctx.comm_reserved_cus() == 8 and ctx.comm_cu_mask() == [0xFFFFFF00] + [0xFFFFFFFF] * 7
+        with pytest.raises(capi.LfgError):
+            ctx.comm_cu_mask(words=4)                         # 256 CUs do not fit 128 bits
+        a = synth.make_prev(320, 180, seed=9)
+        f, up = ctx.frame_from(a), ctx.create_frame(640, 360)
+        ctx.scale(f, up)                                      # kernels run on the masked stream as on any other
+        first = ctx.download(up).copy()
+        ctx.comm_destroy()
+        assert ctx.comm_reserved_cus() == 0 and ctx.comm_cu_mask() == full
+        ctx.scale(f, up)
+        assert (ctx.download(up) == first).all()

@@ -163,7 +163,7 @@ def as_int(mv_f32):
 @pytest.mark.parametrize("wh,shift", [((128, 64), (3, -2)), ((70, 45), (-5, 7)), ((64, 32), (0, 0)),
                                       ((200, 40), (16, -16)), ((33, 90), (-16, 16)),
                                       # purely vertical pans: the strip they expose is a few rows over the whole width -- the row
-                                      # band of the prefilter (motion.hip, "Row band"), at the bottom and at the top, in a segment's
+                                      # band of the prefilter (prefilter_rowband.inc, "Row band"), at the bottom and at the top, in a segment's
                                       # upper and lower half (160 rows: the last segment starts at row 144)
                                       ((224, 160), (0, 6)), ((224, 160), (0, -6)), ((180, 150), (0, -3)), ((180, 150), (1, 5))])
 def test_motion_translation_matches_oracle(ctx, oracle, wh, shift):
@@ -240,7 +240,7 @@ def run_motion_mode(ctx, prev, curr, mode):
 
 
 def _adversarial_pairs():
-    """Frame pairs aimed at the prefilter's error bracket (csrc/motion.hip, "Bracket") and its bookkeeping."""
+    """Frame pairs aimed at the prefilter's error bracket (csrc/motion_prefilter.hip, "Bracket") and its bookkeeping."""
     rng = np.random.default_rng(77)
     w, h = 200, 150                                    # 4 x 3 prefilter tiles, all partial at the far edges
     hi = rng.integers(254, 256, size=(h, w, 4), dtype=np.uint8)          # byte differences of 1 at the top of the
@@ -685,7 +685,7 @@ def test_motion_zoom_and_rotation_fields(ctx):
 
 
 def test_exact_sqrt_exhaustive(ctx):
-    """csrc/motion.hip: exact_sqrt (one Newton step on v_rsq_f32) against the compiler's IEEE sqrtf for
+    """csrc/lfg_motion_common.hpp: exact_sqrt (one Newton step on v_rsq_f32) against the compiler's IEEE sqrtf for
     every float from 2^-21 to 8 (the motion kernel feeds it sums of four squares in [0, 4], the
     smallest non-zero one being (1/255)^2 ~ 1.5e-5) and for 0."""
     lo = int(np.float32(2.0 ** -21).view(np.uint32))

@@ -1,6 +1,6 @@
 // Throughput probe for a candidate-per-lane full evaluation of the motion prefilter's cost bracket (gfx950).
 //
-// The prefilter's full evaluation (csrc/motion.hip: columnSums / transpose / rowSumsAndTest) gives a wave ONE candidate:
+// The prefilter's full evaluation (csrc/prefilter_sums.inc: columnSums / transpose / rowSumsAndTest) gives a wave ONE candidate:
 // lane = position column, the 8 x 8 sums go through a slab in LDS and come back transposed.  Here a wave takes 64 candidates,
 // one per lane: the lane walks the segment's 23 x 63 block positions column by column -- 23 distances, the shared pairwise
 // tree down the column, then the horizontal tree kept as a ring of seven partial sums per pixel row -- and compares the

@@ -1,4 +1,4 @@
-// Throughput probe: the prefilter's full evaluation in its own form (csrc/motion.hip: fetchWindow / columnSums / transpose /
+// Throughput probe: the prefilter's full evaluation in its own form (csrc/prefilter_sums.inc: fetchWindow / columnSums / transpose /
 // runSums + the packed "does anything pass" test; lane = position column, one candidate per pass, software-pipelined as
 // in the kernel) at TWO and at THREE waves per SIMD.  The shipped kernel holds 256 VGPRs and 77 KB of LDS per workgroup: two
 // workgroups per CU.  This loop alone -- no lattice tests, no record path, no narrow search -- is what a search-only kernel
