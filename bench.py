@@ -367,7 +367,7 @@ def spawn_ranks(args, argv) -> int:
     return subprocess.run(launch_command(args.gpus, argv, free_port()), env=env).returncode
 
 
-def measure_config5(torch, capi, dev, dev_index, n_lanes, steps=24, contents=("noisy", "objects")):
+def measure_config5(torch, capi, dev, dev_index, n_lanes, steps=24, contents=("noisy", "objects", "occluded")):
     """BASELINE config 5 on this GPU, short: 4K -> 8K, t = 1/4, 1/2, 3/4 (three generated 8K frames per pair: scale, motion ONCE,
     one pass of lfg_interpolate_multi), the benchmark's pan -- and, shorter still, the contents of `contents` (the pan is the
     motion stage's best case but `static`).  A context of its own; frames in flight as the headline run."""

@@ -141,8 +141,11 @@ __device__ __forceinline__ bool row_is_centre(const InterpTables &tb, int py) {
     return ((w >> (8 * (row & 3))) & 1u) != 0u;
 }
 
-// The host's verdict on whether the fast path may be used for these frames at all (launch_interpolate*): every row pitch and
-// base address aligned for the 8-byte vector loads and the 16-byte stores, the frames below 2 GiB (32-bit buffer offsets).
+// The host's verdict on whether the fast path may be used for these frames at all (launch_interpolate*): the frames below 2 GiB
+// (32-bit buffer offsets); the vectors' base and pitch multiples of 8 (one 8-byte load per quad) and the output's of 16 (fast_output: the
+// guarded 16-byte stores).  Of prev and curr only the BASE is asked to be 4-byte aligned and nothing of the pitch: their 16-byte
+// loads (load_quad_rows) are global loads, which gfx950 serves at any 4-byte address -- a pitch of W * 4 + 4 is legal and tested
+// (tests/test_gpu_parity.py: test_interpolate_fast_path_with_rows_that_are_only_4_byte_aligned); it costs bandwidth, not results.
 static bool fast_frames(const lfg_frame &prev, const lfg_frame &curr, const lfg_frame &mv) {
     const auto small = [](const lfg_frame &f) { return (uint64_t)f.pitch * f.height < (1ull << 31); };
     return small(prev) && small(curr) && (uintptr_t)prev.data % 4u == 0 && (uintptr_t)curr.data % 4u == 0 &&

@@ -819,6 +819,30 @@ def test_interpolate_every_pixel_where_it_samples(ctx, oracle, wh):
         assert (got == want).all(), f"one pass, t = {f}: {(got != want).any(-1).sum()} pixels differ"
 
 
+def test_interpolate_fast_path_with_rows_that_are_only_4_byte_aligned(ctx, oracle):
+    """The quad fast path reads 16 bytes per row and frame at row * pitch + 16 * quad: with a pitch of W * 4 + 4 those addresses
+    are 4-byte aligned and no more (csrc/interpolate.hip, fast_frames: that is all it asks of prev and curr).  Static content at 4K --
+    every pixel samples, the rows whose uv misses a texel centre (85 of 2160) take the generic path -- EVERY pixel against the
+    oracle; the vectors and the output stay tightly packed, so the fast path is the one that runs."""
+    from linux_fg_amd import capi
+    W, H = 3840, 2160
+    rng = np.random.default_rng(4242)
+    prev = rng.integers(0, 256, size=(H, W, 4), dtype=np.uint8)
+    curr = rng.integers(0, 256, size=(H, W, 4), dtype=np.uint8)
+    mv = np.zeros((H, W, 2), np.int8)
+    mv[1000:1030, 2000:2040] = (1, -1)
+    bp, vp = _pitched(ctx, prev, 1)
+    bc, vc = _pitched(ctx, curr, 1)
+    assert vp.pitch == W * 4 + 4 and vp.pitch % 8 != 0
+    m, out = ctx.frame_from(mv, capi.FORMAT_MV_S8X2), ctx.create_frame(W, H)
+    for t in (0.5, 0.3):
+        ctx.interpolate(vp, vc, m, out, t)
+        got, want = ctx.download(out), oracle.interpolate(prev, curr, mv.astype(np.float32), t)
+        assert (got == want).all(), f"t = {t}: {(got != want).any(-1).sum()} pixels differ, first at {np.argwhere((got != want).any(-1))[:4].tolist()}"
+    for f in (bp, bc, m, out):
+        ctx.destroy_frame(f)
+
+
 # ------------------------------------------------------------------------------ whole path
 
 def _run_interpolate_multi(ctx, prev, curr, mv_i8, factors):
