@@ -269,7 +269,7 @@ def pmc_executed(prefix="lfg::motion_"):
            "how": "VALU wave-instructions (SQ_INSTS_VALU) x cycles per instruction / (kernel time x 2.4 GHz x 1024 SIMDs).  simd32_2_cycles: a SIMD-32 issues "
                   "a plain wave64 VALU instruction in 2 cycles once two waves are resident -- the rate the 157.3 TFLOP/s fp32 peak corresponds to "
                   "(MI355X_MICROARCH.md:54,:473); cost_weighted: the same, each kernel's count x the mean issue cost of its STATIC opcode mix "
-                  "(transcendental and packed-f32 instructions twice a plain one; tools/valu_cost_histogram.py -- a proxy: the executed mix is not counted); "
+                  "(issue costs measured on this chip at four waves per SIMD, tools/bench_dpp.hip: transcendental 3.7, packed f32 2.1, v_dot4 2.1, DPP arithmetic 2.7 plain ops; tools/valu_cost_histogram.py -- a proxy: the executed mix is not counted; the clock under load is nearer 1.9 - 2.0 GHz than the 2.4 GHz all three figures assume, which would raise each by a fifth); "
                   "one_wave_alone_4_cycles: what one wave alone sustains, round 4's convention"}
     return out
 
