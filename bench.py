@@ -1288,6 +1288,18 @@ def main():
             for c in CONTENTS:
                 if c != args.content:
                     sweep_case(c, c, capi.MOTION_PREFILTERED)
+            # the pan under sensor noise of other amplitudes than the benchmark's +-2 levels (at the 1080p input): from +-3 on the lane's previous
+            # call selects the persistent kernel's variant with the walks by SADs (include/linuxfg_hip.h: lfg_motion_last_variant)
+            saved_amp = os.environ.get("LFG_BENCH_NOISE_AMP")
+            for amp in (1, 3, 4, 6, 8, 12):
+                os.environ["LFG_BENCH_NOISE_AMP"] = str(amp)
+                label = "noisy, +-%d levels" % amp
+                sweep_case(label, "noisy", capi.MOTION_PREFILTERED)
+                sweep[label]["persistent_kernel_variant"] = ctx.motion_last_variant()
+            if saved_amp is None:
+                os.environ.pop("LFG_BENCH_NOISE_AMP", None)
+            else:
+                os.environ["LFG_BENCH_NOISE_AMP"] = saved_amp
             sweep_case("literal kernel only (any content)", "translated", capi.MOTION_EXACT_ONLY)
             ctx.set_motion_mode(capi.MOTION_PREFILTERED)
             ctx.scale(f_prev_in, f_prev4)

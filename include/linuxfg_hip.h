@@ -216,9 +216,15 @@ int  lfg_motion_lean_stats(lfg_context *ctx, int *out_used, uint32_t *out_tiles,
  * left or right band decided that way and how many pixel columns their top or bottom band (synchronises; reporting and tests
  * only).  No reference counterpart (shaders/motion.comp:27-52 treats every pixel alike). */
 int  lfg_motion_strip_stats(lfg_context *ctx, uint32_t *out_rows, uint32_t *out_columns);
-/* With frames in flight three launch decisions of an lfg_motion go by what the lane's PREVIOUS finished call found (its
+/* The persistent motion kernel exists in two variants with identical results: the default, and one whose lattice walks go by sums
+ * of absolute differences first where a match costs a few hundred to a thousand -- sensor noise of +-3 levels and more at a
+ * 1080p input (4K, three frames in flight: +15 % at +-3, +27 % at +-4 .. +-12; -3 % at +-2 and below, which is why it is not the
+ * only one).  With frames in flight the lane's previous call decides (half its sample blocks matched with a SAD of 310 - 2,200);
+ * LFG_TIER_FORCE=0|1 at context creation overrides.  Returns the variant the context's last lfg_motion launched (0 / 1). */
+int  lfg_motion_last_variant(const lfg_context *ctx);
+/* With frames in flight four launch decisions of an lfg_motion go by what the lane's PREVIOUS finished call found (its
  * verdict word, stored into pinned host memory by that call's last launch): the lean kernel and the plan that goes with it,
- * the size of the persistent grid, the size of the second pass.  A wrong guess changes no result, only the call's duration.
+ * the size of the persistent grid and the variant of its kernel (counted together), the size of the second pass.  A wrong guess changes no result, only the call's duration.
  * Counters since the context was created, over all lanes: calls whose own verdict has been read back, and how many of them
  * had been launched on a guess that this verdict contradicts, per decision (does not synchronise; reporting only).
  * No reference counterpart: one queue, one dispatch per stage (src/frame_manager.cpp:342-366). */

@@ -105,6 +105,7 @@ SIGNATURES = {
     "lfg_comm_probe": (_i, [_vp, _i, _i, _i]),
     "lfg_broadcast_frame_lane": (_i, [_vp, _FP, _i]),
     "lfg_comm_probe_ms": (_i, [_vp, ctypes.POINTER(ctypes.c_float)]),
+    "lfg_motion_last_variant": (_i, [_vp]),
     "lfg_diag_scale_2x_strip": (_i, [_u32, _u32, _u32, ctypes.POINTER(_u32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "lfg_profile_enable": (_i, [_vp, _i]),
     "lfg_profile_reset": (_i, [_vp]),
@@ -324,6 +325,10 @@ class Context:
         n = ctypes.c_uint64()
         self._check(self.lib.lfg_motion_workspace_size(self.h, width, height, ctypes.byref(n)), "lfg_motion_workspace_size")
         return n.value
+
+    def motion_last_variant(self) -> int:
+        """Which variant of the persistent kernel the context's last lfg_motion launched: 0 the default, 1 the one for moderate sensor noise."""
+        return int(self.lib.lfg_motion_last_variant(self.h))
 
     def motion_plan(self):
         """(rim split, persistent workgroups) of the prefiltered motion path on this context (lfg_motion_plan)."""

@@ -450,6 +450,7 @@ LFG_EXPORT int lfg_context_create(int device_ordinal, lfg_context **out_ctx) {
     if (getenv("LFG_DEBUG")) ctx->knobs.debug = 1;
     if (getenv("LFG_DEBUG_DYN")) ctx->knobs.debugDyn = 1;
     if (const char *m = getenv("LFG_DEBUG_DYN_DEEP")) ctx->knobs.debugDynDeep = atoi(m);
+    if (const char *m = getenv("LFG_TIER_FORCE")) ctx->knobs.tierForce = atoi(m) & 1;
     if (const char *m = getenv("LFG_COMM_CUS")) { const int v = atoi(m); if (v == 0 || v == 8 || v == 16 || v == 24 || v == 32) ctx->knobs.commCus = v; }
     *out_ctx = ctx;
     return LFG_OK;
@@ -840,7 +841,7 @@ static int motion_run(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *
             const uint32_t said = (uint32_t)ctx->lean_predict, guess = ctx->lean_request_guess;
             ctx->pred_verdicts += 1;
             if ((guess & 2u) && ((guess ^ said) & 1u)) ctx->pred_lean_wrong += 1;
-            if ((guess ^ said) >> 31) ctx->pred_grid_wrong += 1;
+            if (((guess ^ said) >> 31) || (((guess ^ said) >> 29) & 1u)) ctx->pred_grid_wrong += 1;      // (the persistent launch: its grid, or its variant)
             if (((guess >> 30) & 1u) && ((said >> 30) & 1u)) ctx->pred_second_wrong += 1;       // (small grid, and tiles were flagged: the costly direction)
         }
         if (ctx->knobs.leanForce >= 0) ctx->lean_predict = (ctx->lean_predict & ~1) | ctx->knobs.leanForce;          // (measurement: 1 = every call, 0 = none)
@@ -855,15 +856,19 @@ static int motion_run(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *
         // call's fallback launch is 64 workgroups instead of 2,048 -- they take whatever it flags after all, in turns (1.4 % of the
         // frame rate under a pan: workgroups of 42 KB of LDS that read a count and leave still have to be placed)
         if (ctx->comm_cus > 0) groupsCap = groupsCap ? std::min(groupsCap, persistent_grid_most(ctx)) : persistent_grid_most(ctx);
+        // ... and bit 29 which variant of the persistent kernel: the one with the eight-point walk by SADs where half the sample blocks matched
+        // moderately well (sensor noise of +-3 .. +-6 levels at the input; motion_prefilter.hip, kTier)
+        const int tier = ctx->knobs.tierForce >= 0 ? ctx->knobs.tierForce : (flagWanted && ctx->lean_seen && (((uint32_t)ctx->lean_predict >> 29) & 1u)) ? 1 : 0;
+        ctx->motion_last_tier = fo.data ? 0 : tier;
         const bool expectNoFallback = flagWanted && ctx->lean_seen && (((uint32_t)ctx->lean_predict >> 30) & 1u) == 0u && !ctx->knobs.fallbackFull /* (measurement) */;
         e = lfg::launch_motion_prefiltered_8_16(ctx->stream, *prev, *curr, *mv, ctx->motion_ws, ctx->motion_ws_layout, ctx->motion_units,
                                                 rank2scan, order32, order32 + lfg::kMotionTableWords,
                                                 ctx->motion_tables + 6 * lfg::kMotionTableWords, ctx->motion_hints, ctx->lanes.size() >= 2, fo,
-                                                ctx->motion_ws_layout.lastLean != 0, (flagWanted && !ctx->lean_ev_pending) ? ctx->lean_flag : nullptr, groupsCap, expectNoFallback, ctx->knobs, ctx->semantics == 0);
+                                                ctx->motion_ws_layout.lastLean != 0, (flagWanted && !ctx->lean_ev_pending) ? ctx->lean_flag : nullptr, groupsCap, expectNoFallback, ctx->knobs, ctx->semantics == 0, tier);
         if (e == hipSuccess && flagWanted && !ctx->lean_ev_pending && !fo.data) {
             e = hipEventRecord(ctx->lean_ev, ctx->stream); ctx->lean_ev_pending = true;
             ctx->lean_request_guess = (ctx->motion_ws_layout.lastLean ? 1u : 0u) | ((leanPossible && ctx->motion_ws_layout.leanCount > 0) ? 2u : 0u) |
-                                      ((uint32_t)ctx->lean_predict & 0x80000000u) | (expectNoFallback ? 1u << 30 : 0u);
+                                      ((uint32_t)ctx->lean_predict & 0x80000000u) | (expectNoFallback ? 1u << 30 : 0u) | (tier ? 1u << 29 : 0u);
         }
     }
     else if (tiled) e = lfg::launch_motion_tiled_8_16(ctx->stream, *prev, *curr, *mv, nullptr, rank2scan, nullptr, nullptr, fo);
@@ -872,6 +877,8 @@ static int motion_run(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *
     if (fusedDone) *fusedDone = fo.data != nullptr;
     return LFG_OK;
 }
+
+LFG_EXPORT int lfg_motion_last_variant(const lfg_context *ctx) { return ctx ? ctx->motion_last_tier : -1; }
 
 LFG_EXPORT int lfg_motion(lfg_context *ctx, const lfg_frame *prev, const lfg_frame *curr, lfg_frame *mv,
                           int block_size, float search_radius) {
@@ -982,7 +989,7 @@ LFG_EXPORT int lfg_motion_last_stats(lfg_context *ctx, uint32_t *out_tiles, uint
         uint32_t flags[3] = {0, 0, 0};
         LFG_HIP(ctx, hipMemcpy(flags, ctx->motion_ws + ctx->motion_ws_layout.orderFlags, 12, hipMemcpyDeviceToHost));
         fprintf(stderr, "lfg: lean kernel: %d tiles listed, %u segments settled, %u left to the generic kernel (counted in -DLFG_LEAN_STATS builds); order flags: hand-over %u, hints %u, lean %u (sample blocks with a close match %u, with an exact one %u)\n",
-                ctx->motion_ws_layout.leanCount, lean[0], lean[1], flags[0], flags[1], flags[2] & 1u, (flags[2] >> 1) & 0x7FFu, (flags[2] >> 12) & 0x7FFFFu);
+                ctx->motion_ws_layout.leanCount, lean[0], lean[1], flags[0], flags[1], flags[2] & 1u, (flags[2] >> 1) & 0x7FFu, (flags[2] >> 12) & 0x7FFu);
     }
     if (ctx->knobs.debugDyn) {       // the deepest private lists of the handed-over segments: block (4 x queue slot + wave), pixel, records
         uint32_t handed[2] = {0, 0};

@@ -103,6 +103,7 @@ struct MotionKnobs {
     int debug = 0;            // LFG_DEBUG: reporting calls print what they read
     int debugDyn = 0;         // LFG_DEBUG_DYN: lfg_motion_last_stats prints the deepest private lists of the handed-over segments,
     int debugDynDeep = 14;    // LFG_DEBUG_DYN_DEEP: ... deeper than this
+    int tierForce = -1;       // LFG_TIER_FORCE = 0 | 1: the persistent kernel's variant whatever the verdict (-1: by the verdict)
     int commCus = 8;          // LFG_COMM_CUS = 0 | 8 | 16 | 24 | 32: CUs a communicator keeps free of the library's own kernels (lfg_comm.cpp)
 };
 
@@ -221,6 +222,7 @@ struct lfg_context {
     hipEvent_t comm_ready = nullptr, comm_done = nullptr;
     bool comm_pending = false;                 // some broadcast has been issued on this communicator (comm_done has been recorded)
     hipEvent_t probe_begin = nullptr, probe_end = nullptr;     // lfg_comm_probe: device timestamps, ready and done
+    int motion_last_tier = 0;                  // the persistent kernel's variant of the last lfg_motion on any lane (lfg_motion_last_variant)
     int comm_cus = 0;                          // CUs the library's own streams leave to the communicator's kernels (0: none reserved)
     // profiling
     bool profile = false;
@@ -269,7 +271,8 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
                                           const FusedOut &fused = FusedOut(), bool lean = false, uint32_t *leanFlagHost = nullptr,
                                           int groupsCap = 0 /* persistent workgroups at most (0: as many as the device holds) */,
                                           bool expectNoFallback = false /* the lane's previous call flagged no tile: a small fallback launch */,
-                                          const MotionKnobs &knobs = MotionKnobs(), bool rankIsScan = true);
+                                          const MotionKnobs &knobs = MotionKnobs(), bool rankIsScan = true,
+                                          int tier = 0 /* 1: the persistent kernel's variant for moderate sensor noise (motion_prefilter_kernel<false, 1>) */);
 // This call's visiting order (motion_order.hip): hint kernel (which also clears the call's control area) + order kernel.
 hipError_t launch_motion_order(hipStream_t s, const lfg_frame &prev, const lfg_frame &curr, uint32_t *hints, uint32_t *callOrder,
                                const uint32_t *entryOfScan, const uint32_t *baseScan, uint32_t *clearFrom, int clearWords, bool framesInFlight);

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kHints) void motion_order_kernel(
     __shared__ uint32_t sOwner[kCand];
     __shared__ uint32_t sVotes[kCand];
     constexpr int kWaves = kHints / 64;
-    __shared__ uint32_t sWaveSum[kWaves], sWaveClose[kWaves];
+    __shared__ uint32_t sWaveSum[kWaves], sWaveClose[kWaves], sWaveModerate[kWaves];
     __shared__ uint32_t sRunning, sTop;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t zero = baseScan[0];               // zero motion
@@ -160,7 +160,12 @@ __global__ __launch_bounds__(kHints) void motion_order_kernel(
     const uint32_t unmatched = (uint32_t)__popcll(__ballot((hint >> 11) >= 1020u));
     // (close: a match within the lean kernel's reach; the count of EXACT matches rides along in the upper half, for LFG_DEBUG)
     const uint32_t close = (uint32_t)__popcll(__ballot((float)(hint >> 11) < 2.0f * kOnePointOnly)) | ((uint32_t)__popcll(__ballot((hint >> 11) == 0u)) << 16);
-    if (lane == 0) { sWaveSum[wv] = unmatched; sWaveClose[wv] = close; }
+    // (moderate: a best SAD of 310 - 2,200 -- a match under sensor noise of +-3 levels and more at the 1080p input: the true candidate's SAD
+    //  is 228 - 292 (5 % - 95 % of 1,024 blocks) at +-2, 322 - 413 at +-3, 416 - 532 at +-4, 778 - 997 at +-8, 1,161 - 1,477 at +-12
+    //  (tools/hint_sad_by_noise.py) -- where the persistent kernel's variant with the walks by SADs pays, motion_prefilter_kernel<false, 1>:
+    //  +15 % at +-3, +27 % at +-4 .. +-12, +5 % at +-16, and -3 % at +-2 and below, -4 % at +-24: hence 310 and 2,200)
+    const uint32_t moderate = (uint32_t)__popcll(__ballot((hint >> 11) >= 310u && (hint >> 11) < 2200u));
+    if (lane == 0) { sWaveSum[wv] = unmatched; sWaveClose[wv] = close; sWaveModerate[wv] = moderate; }
     if (mine != zero) atomicMin(&sOwner[mine], (uint32_t)tid);
     atomicAdd(&sVotes[mine], 1u);
     __syncthreads();
@@ -183,9 +188,13 @@ __global__ __launch_bounds__(kHints) void motion_order_kernel(
         // frames with sensor noise (none close): the bar is 15 in 16 (63 in 64 until late in round 4).
         uint32_t closeAll = 0u;
         for (int w = 0; w < kWaves; ++w) closeAll += sWaveClose[w];
-        // (bit 0: the verdict; above it the two counts, for LFG_DEBUG; bit 31: most sample blocks have a match -- the host sizes the
-        //  persistent grid of the lane's next call by it)
-        order32[kCand + 2] = (((closeAll & 0xFFFFu) * 16u >= 15u * (uint32_t)kHints) ? 1u : 0u) | ((closeAll & 0xFFFFu) << 1) | (((closeAll >> 16) & 0x7FFFFu) << 12) | (mostMatch << 31);
+        uint32_t moderateAll = 0u;
+        for (int w = 0; w < kWaves; ++w) moderateAll += sWaveModerate[w];
+        // (bit 0: the verdict; above it the two counts, for LFG_DEBUG; bit 29: half the sample blocks or more match moderately well -- the
+        //  variant of the persistent kernel for the lane's next call; bit 30 is the literal pass's; bit 31: most sample blocks have a match
+        //  -- the host sizes the persistent grid of the lane's next call by it)
+        order32[kCand + 2] = (((closeAll & 0xFFFFu) * 16u >= 15u * (uint32_t)kHints) ? 1u : 0u) | ((closeAll & 0xFFFFu) << 1) | (((closeAll >> 16) & 0x7FFu) << 12) |
+                             ((moderateAll * 2u >= (uint32_t)kHints ? 1u : 0u) << 29) | (mostMatch << 31);
         order32[0] = entryOfScan[top];
         if (top != zero) order32[1] = entryOfScan[zero];
         sRunning = top != zero ? 2u : 1u;

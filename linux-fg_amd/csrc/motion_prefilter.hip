@@ -109,7 +109,7 @@ LFG_STAMP(__device__ unsigned long long gMotionStamps[8192 * 4 * 8];)      // (s
 
 // One work unit of the prefilter (see motion_prefilter_kernel below, which hands units to its workgroups).
 // `unit` indexes the plan's unit table, or -- fromQueue -- the queue of segments handed over at run time.
-template <bool kFused>
+template <bool kFused, int kTier>
 __device__ __forceinline__ void prefilter_unit(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int W, int H, Rec *__restrict__ list, float *__restrict__ uminOut,
@@ -262,7 +262,11 @@ LFG_STAMP(
 //   and the queue entries are written by atomics on other XCDs; the per-XCD L2s are not coherent for plain
 //   accesses) and sleeps ~14 us between polls.  Every wait is bounded by the running units, every workgroup of
 //   the grid is resident or finds nothing to wait for: no workgroup ever waits for one that has not started.
-template <bool kFused>
+// kTier: 0 = the kernel every call takes unless the lane's previous call says otherwise; 1 = the same with the eight-point walk by SADs
+// for thresholds of 300 - 768 (prefilter_walks.inc): sensor noise of +-3 .. +-6 levels at the input.  A kernel of its own and not a
+// run-time branch: round 4 measured the branch (noise +-4: +18 %) and dropped it because the second copy of a walk inside the one
+// kernel moved the register allocation of every other path (+-2: -3.4 %, +-8: -4.7 %, occlusions -1.1 %).
+template <bool kFused, int kTier = 0>
 __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
     const uint8_t *__restrict__ prev, int prevPitch, const uint8_t *__restrict__ curr, int currPitch,
     int W, int H, Rec *__restrict__ list, float *__restrict__ uminOut,
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(kPNT, LFG_PREF_OCC) void motion_prefilter_kernel(
         const uint32_t next = sNext[0], entry = sNext[1];
         if (next == kNoUnit) return;
         const bool fromQueue = (next >> 31) != 0u;
-        prefilter_unit<kFused>(prev, prevPitch, curr, currPitch, W, H, list, uminOut, countOut, tileFlags, flagTilesX, order32, sp,
+        prefilter_unit<kFused, kTier>(prev, prevPitch, curr, currPitch, W, H, list, uminOut, countOut, tileFlags, flagTilesX, order32, sp,
                        mv, mvPitch, rank2scan, segDone, (int)(next & 0x7FFFFFFFu), fromQueue, entry, sWin, sSlab, sOrder, sInv, sGiveUp, sNarrow, sPending);
         if (!fromQueue) {
             __syncthreads();               // every wave of the unit is past its pushes
@@ -370,7 +374,7 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
                                           const uint32_t *rank2scan, const uint32_t *order,
                                           const uint32_t *entryOfScan, const uint32_t *baseScan, bool useHints, bool framesInFlight,
                                           const FusedOut &fused, bool lean, uint32_t *leanFlagHost, int groupsCap, bool expectNoFallback,
-                                          const MotionKnobs &knobs, bool rankIsScan) {
+                                          const MotionKnobs &knobs, bool rankIsScan, int tier) {
     const int tilesX = ((int)curr.width + kTW - 1) / kTW;
     lean = lean && useHints && !fused.data && l.units2 > 0 && l.leanCount > 0 && curr.width >= 64u && curr.height >= 64u && lean_frames_ok(prev, curr, mv);
     if (lean) units = l.units2;          // the plan that goes with the lean kernel
@@ -450,7 +454,9 @@ hipError_t launch_motion_prefiltered_8_16(hipStream_t s, const lfg_frame &prev, 
                            (int)curr.width, (int)curr.height, list, umin, count, flags, tilesX, order, sp,
                            (int8_t *)mv.data, (int)mv.pitch, rank2scan, segDone, ctrl);
     };
-    if (fused.data) launchPersistent(motion_prefilter_kernel<true>); else launchPersistent(motion_prefilter_kernel<false>);
+    if (fused.data) launchPersistent(motion_prefilter_kernel<true>);
+    else if (tier == 1) launchPersistent(motion_prefilter_kernel<false, 1>);
+    else launchPersistent(motion_prefilter_kernel<false>);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     LFG_STAMP(motion_stamps_report(s, sp);)

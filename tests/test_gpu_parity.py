@@ -1761,6 +1761,34 @@ def test_oracle_on_a_tile_the_lean_kernel_left_and_on_a_rim_tiles_inner_segments
     lean_ctx.lane_select(0)
 
 
+def test_the_variant_for_moderate_noise_follows_the_content_and_agrees_with_the_literal_kernel(monkeypatch):
+    """motion_prefilter_kernel<false, 1> (the walks by sums of absolute differences; include/linuxfg_hip.h: lfg_motion_last_variant): chosen for
+    a lane's call when half the sample blocks of the lane's PREVIOUS call matched moderately well.  A pan, then the pan under noise of
+    +-4 levels (at the resolution of the frames: the walks see thresholds of several hundred), then the pan again, on two lanes: the
+    second noisy call of a lane and the first clean one after it run the variant, every call returns the literal kernel's vectors."""
+    from linux_fg_amd import capi
+    monkeypatch.delenv("LFG_TIER_FORCE", raising=False)
+    W, H = 1920, 1080
+    base = synth.make_prev(W, H, seed=synth.BASE_SEED + 606)
+    pan = synth.translate(base, (5, -3), synth.BASE_SEED + 606)
+    noise = synth.noise_bytes(W, H, 777) % 9
+    noisy = np.clip(pan.astype(np.int16) + noise.astype(np.int16) - 4, 0, 255).astype(np.uint8)
+    c = capi.Context(0)
+    try:
+        c.lanes(2)
+        want = {name: run_motion_mode(c, base, curr, capi.MOTION_EXACT_ONLY)[0] for name, curr in (("pan", pan), ("noisy", noisy))}
+        variants = []
+        for k, name in enumerate(["pan", "pan", "noisy", "noisy", "noisy", "noisy", "pan", "pan", "pan", "pan"]):
+            c.lane_select(k % 2)
+            got = run_motion(c, base, pan if name == "pan" else noisy)          # (synchronises: the verdict is there for the lane's next call)
+            variants.append(c.motion_last_variant())
+            assert (got == want[name]).all(), (k, name)
+        assert variants == [0, 0, 0, 0, 1, 1, 1, 1, 0, 0], variants
+        c.lane_select(0)
+    finally:
+        c.close()
+
+
 def test_lean_verdict_follows_the_content():
     """Without the override the host goes by the order kernel's verdict on the lane's previous call: results are the literal
     kernel's on a stream that changes from a pan to noise and back, whichever calls went through the lean kernel."""

@@ -24,7 +24,7 @@ for a in "$@"; do
   esac
 done
 MOTION="motion_literal motion_order motion_lean motion_strip motion_prefilter motion_resolve motion_plan"
-OBJS="$C/lfg_capi.cpp.o $C/lfg_comm.cpp.o $C/scale.hip.o"
+OBJS="$C/lfg_capi.cpp.o $C/lfg_comm.cpp.o $C/comm_probe.hip.o $C/scale.hip.o"
 for m in $MOTION; do
   if [ -n "$ONLY" ] && [ "motion_$ONLY" != "$m" ]; then OBJS="$OBJS $C/$m.hip.o"; continue; fi
   /opt/rocm/bin/hipcc $FLAGS "${DEFS[@]}" -c $W/$m.hip -o $W/$m.o &
