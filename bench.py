@@ -51,6 +51,10 @@ import time
 
 import numpy as np
 
+# HIP gives a process four hardware queues by default and streams beyond that share them (two lanes on one queue run in turn:
+# NOTES_r05.md section 7).  Read by the HIP runtime at its first call -- before torch or the library touch the GPU; an explicit setting wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -834,7 +838,8 @@ def assemble_line(r):
                    "frames_in_flight": n_lanes,       # lanes of the C-ABI; 1 = strictly one frame at a time
                    "devices": devices,                # HIP device ordinal of every rank, in rank order
                    "content": args.content + (" (the motion stage's best case but `static`; see content_sweep)" if args.content == "translated" and args.workload != "scale" else ""),
-                   "parallelism": f"one frame pair per GPU x{world}" + (", lfg_broadcast_frame (RCCL) of the shared previous input frame per step, upscaled on every rank" if world > 1 else "")},
+                   "parallelism": f"one frame pair per GPU x{world}" + (", lfg_broadcast_frame_lane (RCCL, 8 CUs kept for it) of the shared previous input frame per step, upscaled on every rank" if world > 1 else ""),
+                   "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},      # (HIP's default of 4 makes streams share hardware queues)
         "rccl_ranks": rccl_ranks,              # lfg_comm_ranks(): the size of the RCCL communicator every rank joined (0: one GPU, none)
         "repeats": {"regions": len(regions), "steps_per_region": steps, "median_ms_per_step": round(elapsed / steps * 1e3, 5),
                     "min_ms_per_step": round(min(regions) / steps * 1e3, 5), "max_ms_per_step": round(max(regions) / steps * 1e3, 5),

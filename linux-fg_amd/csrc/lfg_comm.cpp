@@ -90,16 +90,17 @@ LFG_EXPORT int lfg_comm_init(lfg_context *ctx, int nranks, int rank, const lfg_c
     if (ctx->comm) return fail(ctx, LFG_ERR_INVALID, "lfg_comm_init: this context already has a communicator");
     Rccl &r = rccl();
     if (!r.error.empty()) return fail(ctx, LFG_ERR_UNSUPPORTED, "lfg_comm_init: " + r.error);
+    const int reserve = (ctx->knobs.commCus > 0 && ctx->device_cus >= 8 * ctx->knobs.commCus) ? ctx->knobs.commCus : 0;    // (at most an eighth of the device)
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess && !ctx->comm_stream) {
-        if (ctx->knobs.commCus > 0 && ctx->device_cus > ctx->knobs.commCus) {
+        if (reserve > 0) {
             // The communication stream may use the reserved CUs and no others (and the library's compute streams every CU but those:
             // lfg_own_stream_create).  Measured on the MI355X (tools/probe_cu_reserve.hip): while a chip-filling launch of the persistent
             // kernel's footprint is resident, a kernel of RCCL's footprint on a HIGH-PRIORITY stream that may use any CU still waits for
             // that launch to end although eight CUs stand empty -- its workgroups are handed to shader engines in turn, not to where
             // there is room -- and on a stream masked to the empty CUs it starts at once (54 us for 8 workgroups of 50 us).
             std::vector<uint32_t> mask((size_t)(ctx->device_cus + 31) / 32, 0u);
-            for (int i = 0; i < ctx->knobs.commCus; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+            for (int i = 0; i < reserve; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
             e = hipExtStreamCreateWithCUMask(&ctx->comm_stream, (uint32_t)mask.size(), mask.data());
         } else {
             // no reservation: highest priority, so that the broadcast's few workgroups at least do not queue behind the compute lanes'
@@ -118,14 +119,14 @@ LFG_EXPORT int lfg_comm_init(lfg_context *ctx, int nranks, int rank, const lfg_c
     // The communicator's kernel gets at most as many workgroups (one per channel) as there are CUs kept for it: two of them do not fit a
     // CU (comm_probe.hip: 261 - 280 of a SIMD's 512 registers each), and a ninth would wait for one of the eight to leave.
     ncclConfig_t config = NCCL_CONFIG_INITIALIZER;
-    if (ctx->knobs.commCus > 0) { config.minCTAs = 1; config.maxCTAs = ctx->knobs.commCus; }
+    if (reserve > 0) { config.minCTAs = 1; config.maxCTAs = reserve; }
     const ncclResult_t rc = r.CommInitRankConfig(&comm, nranks, nid, rank, &config);       // collective: returns once every rank has called
     if (rc != ncclSuccess) return fail_nccl(ctx, rc, "ncclCommInitRankConfig");
     ctx->comm = comm; ctx->comm_ranks = nranks; ctx->comm_rank = rank; ctx->comm_pending = false;
     // From here on the library's own streams leave `commCus` CUs alone (lfg_own_stream_create): a broadcast that becomes
     // ready while a full persistent grid runs -- noise, uncorrelated content, a scene cut: launches of 0.7 - 7 ms -- starts at once
     // instead of when that grid's first workgroup leaves, which is when its last one does.
-    ctx->comm_cus = ctx->knobs.commCus;
+    ctx->comm_cus = reserve;
     return ctx->comm_cus > 0 ? lfg_restream(ctx) : LFG_OK;
 }
 
