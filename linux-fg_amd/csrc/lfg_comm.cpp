@@ -52,7 +52,7 @@ Rccl &rccl() {
         auto sym = [&](const char *n) { void *p = dlsym(r.handle, n); if (!p && r.error.empty()) r.error = std::string("librccl.so lacks ") + n; return p; };
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
-        r.CommInitRankConfig = reinterpret_cast<decltype(r.CommInitRankConfig)>(sym("ncclCommInitRankConfig"));
+        r.CommInitRankConfig = reinterpret_cast<decltype(r.CommInitRankConfig)>(dlsym(r.handle, "ncclCommInitRankConfig"));      // (optional: RCCL >= 2.18)
         r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
@@ -120,8 +120,10 @@ LFG_EXPORT int lfg_comm_init(lfg_context *ctx, int nranks, int rank, const lfg_c
     // CU (comm_probe.hip: 261 - 280 of a SIMD's 512 registers each), and a ninth would wait for one of the eight to leave.
     ncclConfig_t config = NCCL_CONFIG_INITIALIZER;
     if (reserve > 0) { config.minCTAs = 1; config.maxCTAs = reserve; }
-    const ncclResult_t rc = r.CommInitRankConfig(&comm, nranks, nid, rank, &config);       // collective: returns once every rank has called
-    if (rc != ncclSuccess) return fail_nccl(ctx, rc, "ncclCommInitRankConfig");
+    // (collective: returns once every rank has called.  An RCCL without ncclCommInitRankConfig cannot be told how many channels to use:
+    //  the reservation stands, a kernel of more channels than reserved CUs runs some of them in turn.)
+    const ncclResult_t rc = r.CommInitRankConfig ? r.CommInitRankConfig(&comm, nranks, nid, rank, &config) : r.CommInitRank(&comm, nranks, nid, rank);
+    if (rc != ncclSuccess) return fail_nccl(ctx, rc, r.CommInitRankConfig ? "ncclCommInitRankConfig" : "ncclCommInitRank");
     ctx->comm = comm; ctx->comm_ranks = nranks; ctx->comm_rank = rank; ctx->comm_pending = false;
     // From here on the library's own streams leave `commCus` CUs alone (lfg_own_stream_create): a broadcast that becomes
     // ready while a full persistent grid runs -- noise, uncorrelated content, a scene cut: launches of 0.7 - 7 ms -- starts at once
