@@ -61,6 +61,7 @@ constexpr float LFG_SAD_TEST_MAX = 8.0f;
 constexpr float LFG_ONEPOINT_MAX = 32.0f;           // below: the one-point test alone
 constexpr float LFG_ONEPOINT_OFF = 96.0f;           // above: no one-point test (a distance is at most 510, but few exceed a threshold of a hundred)
 constexpr float LFG_FOURPOINT_MAX = 4.0f * 510.0f;
+constexpr int LFG_ORDER_BY_BANK = 1;                // the fixed visiting order dealt out by LDS bank (motion_order.hip: motion_tables)
 constexpr float LFG_FOUR_SAD_MAX = 300.0f;          // the four-point walk by SADs below this
 constexpr float LFG_EIGHT_SAD_MIN = 220.0f;         // (below it the four-point walk by SADs as in the default kernel; 300: noise of +-3 levels 1,180 instead of 1,390 frames/s, 150: +-2 1,420 instead of 1,590)
 constexpr float LFG_EIGHT_SAD_MAX = 768.0f;         // kTier 1 (motion_prefilter_kernel<false, 1>): from there up to this the EIGHT-point walk by SADs takes the four-point walk's place

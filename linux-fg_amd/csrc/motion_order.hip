@@ -39,6 +39,26 @@ void motion_tables(bool intended, uint32_t *rank2scan, uint32_t *order32, uint32
     for (int i = 0; i < kCand; ++i) {
         if (order[i] == kR * kSide + kR) { order[i] = order[0]; order[0] = (uint16_t)(kR * kSide + kR); break; }
     }
+    // ... and (round 5) that any 32 consecutive entries read 32 different LDS banks.  A lattice test reads the window at the
+    // candidate's offset (dx+R)*kWinH + (dy+R) plus constants, one ds_read_b32 per point: its bank is that offset mod 32, conflicts count
+    // within each half of the wave, and 32 random offsets put three or four on the busiest bank -- SQ_LDS_BANK_CONFLICT / SQ_INSTS_LDS was
+    // 2.8 since round 2, "the pseudo-random order's lattice reads".  So the permutation is dealt out by bank: the candidates of each of
+    // the 32 classes offset mod 32 keep their pseudo-random order among themselves, and the visiting order takes one from every class in
+    // turn -- entry j has class j mod 32 (classes that run out are skipped: the last few entries), so every window of 32 entries holds each
+    // class once wherever it starts; the hints a call moves to the front leave a duplicate or two.  Still "unrelated to position": which
+    // member of a class comes when is the shuffle's.
+    if (LFG_ORDER_BY_BANK) {
+        uint16_t byClass[32][kCand / 32 + 2];
+        int have[32] = {0};
+        for (int i = 1; i < kCand; ++i) {
+            const int scan = order[i], cls = ((scan % kSide) * kWinH + scan / kSide) & 31;
+            byClass[cls][have[cls]++] = (uint16_t)scan;
+        }
+        int at = 1;
+        for (int k = 0; at < kCand; ++k)
+            for (int cls = 0; cls < 32; ++cls)
+                if (k < have[cls]) order[at++] = byClass[cls][k];
+    }
     for (int scan = 0; scan < kCand; ++scan) {
         const uint32_t dyi = scan / kSide, dxi = scan % kSide;
         entryOfScan[scan] = rankOf[scan] | ((dxi * kWinH + dyi) << 16);
