@@ -1,8 +1,10 @@
 // comm_probe.hip -- a stand-in for RCCL's device kernel where no second rank exists (lfg_comm_probe, lfg_comm.cpp).
 //
-// What a broadcast needs from the chip is decided by the kernel RCCL launches for it.  From the gfx950 code object inside
-// librccl.so (ROCm 7.2; `llvm-readelf --notes`): rcclGenericKernel<1|2|4, false|true>: 256 threads per workgroup, 261 - 280 vector
-// registers per lane (17 - 32 of them accumulation registers), 19,744 bytes of LDS, one workgroup per channel.  A SIMD has 512
+// What a broadcast needs from the chip is decided by the kernel RCCL launches for it.  From the gfx950 code objects inside the
+// image's two librccl.so (tools/rccl_kernel_footprint.py, profiles/r05_rccl_kernel_footprint.txt): PyTorch's RCCL 2.26.6,
+// rcclGenericKernel<1|2|4, false|true>: 256 threads per workgroup, 261 - 280 vector registers per lane (17 - 32 of them accumulation
+// registers), 19,744 bytes of LDS, one workgroup per channel; ROCm 7.2's RCCL 2.27.7, ncclDevKernel_Generic_1|2|4: 512 threads, 248 - 256
+// registers (two waves per SIMD: 496 - 512 of its 512), 37,664 bytes -- a CU to itself per channel in both.  A SIMD has 512
 // registers per lane: a wave of that kernel cannot share a SIMD with a wave of the persistent prefilter kernel (256 registers), and a
 // prefilter workgroup puts a wave on every SIMD of its CU -- the broadcast needs CUs that hold NO prefilter workgroup
 // (the library's streams leave such CUs free while a communicator exists: lfg_own_stream_create).
