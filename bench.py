@@ -93,6 +93,9 @@ def parse_args():
                          "pixels, ties resolve to the shortest vector) -- a labelled variant, never the headline")
     ap.add_argument("--stream", action="store_true",
                     help="only the changing-stream measurement (extras.stream; see measure_stream): K = 12 distinct pairs whose content changes every three steps")
+    ap.add_argument("--config5", action="store_true", help="only BASELINE config 5 on this GPU, short (extras.config5; see measure_config5)")
+    ap.add_argument("--with-communicator", action="store_true",
+                    help="only the N > 1 step with a one-rank communicator on this GPU (extras.with_communicator; see measure_with_communicator)")
     ap.add_argument("--no-extras", action="store_true", help="skip scale_only / scale_interpolate / content_sweep (profiling runs)")
     return ap.parse_args()
 
@@ -371,7 +374,7 @@ def spawn_ranks(args, argv) -> int:
     return subprocess.run(launch_command(args.gpus, argv, free_port()), env=env).returncode
 
 
-def measure_config5(torch, capi, dev, dev_index, n_lanes, steps=24, contents=("noisy", "objects", "occluded")):
+def measure_config5(torch, capi, dev, dev_index, n_lanes, steps=96, contents=("noisy", "objects", "occluded")):
     """BASELINE config 5 on this GPU, short: 4K -> 8K, t = 1/4, 1/2, 3/4 (three generated 8K frames per pair: scale, motion ONCE,
     one pass of lfg_interpolate_multi), the benchmark's pan -- and, shorter still, the contents of `contents` (the pan is the
     motion stage's best case but `static`).  A context of its own; frames in flight as the headline run."""
@@ -409,12 +412,12 @@ def measure_config5(torch, capi, dev, dev_index, n_lanes, steps=24, contents=("n
             step(k, n)
         ctx.sync(); torch.cuda.synchronize(dev)
         return time.perf_counter() - t0
-    timed(2 * n_lanes, n_lanes)
+    timed(8 * n_lanes, n_lanes)                    # (a fresh process: clocks, page tables, the lanes' verdicts)
     t = timed(steps, n_lanes)
     if n_lanes > 1:
         ctx.lane_select(0)
     ctx.profile_reset(); ctx.profile_enable(True)
-    timed(max(4, steps // 3), 1)
+    timed(max(4, steps // 12), 1)
     per = {}
     for name, sid in (("scale", capi.STAGE_SCALE), ("motion", capi.STAGE_MOTION), ("interpolate", capi.STAGE_INTERPOLATE)):
         ms, n = ctx.profile_get(sid)
@@ -440,15 +443,15 @@ def measure_config5(torch, capi, dev, dev_index, n_lanes, steps=24, contents=("n
         ctx.scale(f_pin, f_p8)
         ctx.sync()
         timed(2 * n_lanes, n_lanes)
-        tt = timed(steps, n_lanes)
+        tt = timed(max(24, steps // 4), n_lanes)
         if n_lanes > 1:
             ctx.lane_select(0)
         ctx.profile_reset(); ctx.profile_enable(True)
-        timed(max(4, steps // 3), 1)
+        timed(8, 1)
         ms, cnt = ctx.profile_get(capi.STAGE_MOTION)
         ctx.profile_enable(False)
-        by_content[name] = {"interpolated_frames_per_s": round(steps * len(factors) / tt, 1), "ms_per_pair": round(tt / steps * 1e3, 4),
-                            "motion_ms_one_call_at_a_time": round(ms / max(cnt, 1), 4), "fallback_tiles": ctx.motion_last_stats()[1], "steps": steps}
+        by_content[name] = {"interpolated_frames_per_s": round(max(24, steps // 4) * len(factors) / tt, 1), "ms_per_pair": round(tt / max(24, steps // 4) * 1e3, 4),
+                            "motion_ms_one_call_at_a_time": round(ms / max(cnt, 1), 4), "fallback_tiles": ctx.motion_last_stats()[1], "steps": max(24, steps // 4)}
     out["other_contents"] = by_content
     ctx.close()
     return out
@@ -460,7 +463,8 @@ def measure_with_communicator(torch, capi, sharding, dev, dev_index, n_lanes, co
     buffered broadcast of the shared previous INPUT frame issued a step ahead through lfg_broadcast_frame / lfg_comm_wait as on rank 0
     of a node -- and, because one rank's ncclBroadcast launches nothing, lfg_comm_probe in its place: 8 workgroups of RCCL's device
     kernel's footprint that stay 170 us (8.3 MB at 50 GB/s of one xGMI link).  `probe_ms_behind_its_step`: host clock from the end of
-    the step the stand-in was ordered behind to its own end, sampled without frames in flight around it."""
+    the step the stand-in was ordered behind to its own end, sampled without frames in flight around it.  Run in a process of its own
+    (`bench.py --with-communicator`): what a rank is."""
     w_in, h_in = SIZES["1080p"]
     w, h = 2 * w_in, 2 * h_in
     ctx = capi.Context(dev_index)
@@ -900,6 +904,15 @@ def main():
                           "library_sha16": library_sha16()}), flush=True)
         return
 
+    if args.config5:
+        print(json.dumps({"config5": measure_config5(torch, capi, dev, dev_index, max(1, min(args.in_flight, capi.MAX_LANES))),
+                          "library_sha16": library_sha16()}), flush=True)
+        return
+    if args.with_communicator:             # ... and the N > 1 step with a communicator alone (the default run starts this as a process of its own)
+        print(json.dumps({"with_communicator": measure_with_communicator(torch, capi, sharding, dev, dev_index, max(1, min(args.in_flight, capi.MAX_LANES))),
+                          "library_sha16": library_sha16()}), flush=True)
+        return
+
     w_in, h_in = SIZES[args.input]
     w, h = 2 * w_in, 2 * h_in
     factors = [float(x) for x in args.factors.split(",") if x]
@@ -1160,6 +1173,17 @@ def main():
 
     # ---- the same run, rank 0, one GPU: the two HBM-bound configurations and the other contents
     extras = {}
+
+    def own_process(flag, key):
+        """One of the labelled extras measured by `bench.py FLAG` in a process of its own (a context of its own on this GPU while this process
+        waits): {...} of its JSON line, or {"skipped": why} -- an extra must not take the line down."""
+        import subprocess
+        try:
+            sub = subprocess.run([sys.executable, os.path.abspath(__file__), flag, "--in-flight", str(n_lanes)], capture_output=True, text=True, timeout=300)
+            last = [ln for ln in sub.stdout.strip().splitlines() if ln.startswith("{")]
+            return json.loads(last[-1])[key] if last else {"skipped": "no output: " + sub.stderr[-300:]}
+        except Exception as e:           # noqa: BLE001
+            return {"skipped": repr(e)}
     if rank == 0 and world == 1 and not args.no_extras and args.workload == "pipeline" and args.input == "1080p" and args.semantics == "reference":
         n2 = 4000
         b_scale = algorithmic_bytes("scale", w_in, h_in, w, h)
@@ -1326,7 +1350,9 @@ def main():
                                                  "how": "the step every rank runs at N > 1 -- scale(shared previous INPUT frame) + scale(curr) + motion + interpolate -- "
                                                         "on this GPU, without the broadcast: the denominator a scaling curve over N should use"}
             del slots2, bufs2
-            extras["with_communicator"] = measure_with_communicator(torch, capi, sharding, dev, dev_index, n_lanes)
+            # (a process of its own, as a rank is: this one holds the headline context's streams as well, and with more streams than
+            #  hardware queues -- GPU_MAX_HW_QUEUES -- two lanes share one and run in turn: 2,420 instead of 3,400 frames/s measured here)
+            extras["with_communicator"] = own_process("--with-communicator", "with_communicator")
         # ---- the opt-in intended semantics (lfg_set_semantics: vectors displace by pixels, ties go to the shortest vector) -- the only
         # mode whose generated frames mean anything -- on the pan and on moving objects, frames in flight as `value`
         intended = {}
@@ -1360,9 +1386,11 @@ def main():
         intended["how"] = ("lfg_set_semantics(INTENDED) on the headline context, same step and frames in flight as `value`; under these semantics interpolate "
                            "samples displaced texels on every content (no rejected samples), and ties resolve to the shortest vector")
         extras["intended_semantics"] = intended
-        extras["stream"] = measure_stream(torch, capi, dev, dev_index, n_lanes)
+        # (contexts of their own in processes of their own, like with_communicator above: beside the headline context's streams theirs share
+        #  hardware queues -- config 5 measured 3 % slower inside this process than alone)
+        extras["stream"] = own_process("--stream", "stream")
         extras["pcie_inclusive"] = measure_pcie_inclusive(torch, capi, ctx, dev, w_in, h_in, w, h)
-        extras["config5"] = measure_config5(torch, capi, dev, dev_index, n_lanes)
+        extras["config5"] = own_process("--config5", "config5")
         extras["content_sweep"] = {"frames_per_s_by_content": sweep, "worst_case_frames_per_s": worst,
                                    "note": "same kernels, same results discipline (bit-exact vectors on every content); the motion "
                                            "stage's run time depends on how much of the frame has an exact or near match inside the "
