@@ -397,7 +397,7 @@ def test_motion_flat_areas_with_a_brightness_change(ctx, oracle):
     assert (got == want).all()
 
 
-def _mixed_pair(w, h, seed):
+def _mixed_pair(w, h, seed, max_amp=4):
     """A frame pair that mixes what the prefilter treats differently: a translation, sensor noise on part of the
     frame, patches of fresh noise, a static flat area and a flat area one level apart (ties at a non-zero cost)."""
     rng = np.random.default_rng(seed)
@@ -406,7 +406,7 @@ def _mixed_pair(w, h, seed):
     curr = synth.translate(prev, shift, seed)
     if rng.random() < 0.7:                                   # sensor noise on a band of rows
         y0, y1 = sorted(int(v) for v in rng.integers(0, h, 2))
-        amp = int(rng.integers(1, 5))
+        amp = int(rng.integers(1, max_amp + 1))     # (max_amp 4: the suite's seeded cases; tools/fuzz_motion_4k.py asks for more)
         n = synth.noise_bytes(w, h, seed + 1) % (2 * amp + 1)
         noisy = np.clip(curr.astype(np.int16) + n.astype(np.int16) - amp, 0, 255).astype(np.uint8)
         curr[y0:y1] = noisy[y0:y1]
@@ -1785,6 +1785,40 @@ def test_the_variant_for_moderate_noise_follows_the_content_and_agrees_with_the_
             assert (got == want[name]).all(), (k, name)
         assert variants == [0, 0, 0, 0, 1, 1, 1, 1, 0, 0], variants
         c.lane_select(0)
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("amp", [4, 8])
+def test_the_variant_for_moderate_noise_against_the_oracle_at_4k(monkeypatch, oracle, amp):
+    """motion_prefilter_kernel<false, 1> on what it is for -- the benchmark's pan under sensor noise of +-4 and +-8 levels at the 1080p input,
+    both frames upscaled on the device: thresholds of 400 - 1,000, the eight- and sixteen-point walks by SADs decide nearly every batch --
+    forced for every call (LFG_TIER_FORCE=1), against the ORACLE on regions inside the frame and at its rim, and against the literal kernel
+    everywhere."""
+    from linux_fg_amd import capi
+    monkeypatch.setenv("LFG_TIER_FORCE", "1")
+    w, h = 1920, 1080
+    pin = synth.make_prev(w, h, seed=synth.BASE_SEED)
+    noise = synth.noise_bytes(w, h, 4242 + amp) % (2 * amp + 1)
+    cin = np.clip(synth.translate(pin, (3, -2), synth.BASE_SEED).astype(np.int16) + noise.astype(np.int16) - amp, 0, 255).astype(np.uint8)
+    c = capi.Context(0)
+    try:
+        c.lanes(2)
+        p, q = c.frame_from(pin), c.frame_from(cin)
+        W, H = 2 * w, 2 * h
+        P, C = c.create_frame(W, H), c.create_frame(W, H)
+        c.scale(p, P); c.scale(q, C)
+        Pn, Cn = c.download(P), c.download(C)
+        for f in (p, q, P, C):
+            c.destroy_frame(f)
+        a, _ = run_motion_mode(c, Pn, Cn, capi.MOTION_PREFILTERED)
+        assert c.motion_last_variant() == 1
+        b, _ = run_motion_mode(c, Pn, Cn, capi.MOTION_EXACT_ONLY)
+        assert (a == b).all(), f"+-{amp}: {(a != b).any(-1).sum()} pixels differ from the literal kernel"
+        for roi in [(1000, 1000, 1100, 1024), (2500, 300, 2580, 324), (40, 1500, 120, 1524), (W - 130, 800, W - 50, 824)]:
+            x0, y0, x1, y1 = roi
+            want = as_int(oracle.motion(Pn, Cn, roi=roi))[y0:y1, x0:x1]
+            assert (a[y0:y1, x0:x1] == want).all(), f"+-{amp}, {roi}: {(a[y0:y1, x0:x1] != want).any(-1).sum()} pixels differ from the oracle"
     finally:
         c.close()
 

@@ -10,7 +10,8 @@ final library (lean kernel incl. the rim tiles' inner segments, row band, eight-
 entries, handed-over segments in four parts with frames in flight): 0 differences in 300 cases one frame at a time, 200 with
 LFG_FUZZ_LANES=3 and 160 with LFG_FUZZ_LANES=3 LFG_LEAN_FORCE=1 (every call through the lean kernel); and again behind the
 launches sized by the lane's previous call (persistent grid, resolve grid, the looping fallback pass): 200 with LFG_FUZZ_LANES=3,
-120 without, no differences."""
+120 without, no differences; round 5 (the variant of the persistent kernel for moderate noise forced, LFG_TIER_FORCE=1, noise amplitudes
+up to 12 levels, LFG_FUZZ_MAX_AMP=12; the visiting order dealt out by LDS bank): see NOTES_r05.md section 6."""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
@@ -24,7 +25,7 @@ bad = 0
 for case in range(int(os.environ.get("LFG_FUZZ_CASES", "48"))):
     rng = np.random.default_rng(77000 + case)
     w, h = int(rng.integers(2500, 3900)), int(rng.integers(1400, 2200))
-    prev, curr = T._mixed_pair(w, h, 77000 + case)
+    prev, curr = T._mixed_pair(w, h, 77000 + case, int(os.environ.get("LFG_FUZZ_MAX_AMP", "4")))    # (12: costs of up to a thousand -- the walks by SADs of the persistent kernel's variant, LFG_TIER_FORCE=1)
     if case % 4 == 3: ctx.set_semantics(capi.SEMANTICS_INTENDED)
     a, st = T.run_motion_mode(ctx, prev, curr, capi.MOTION_PREFILTERED)
     b, _ = T.run_motion_mode(ctx, prev, curr, capi.MOTION_EXACT_ONLY)
