@@ -11,7 +11,9 @@ entries, handed-over segments in four parts with frames in flight): 0 difference
 LFG_FUZZ_LANES=3 and 160 with LFG_FUZZ_LANES=3 LFG_LEAN_FORCE=1 (every call through the lean kernel); and again behind the
 launches sized by the lane's previous call (persistent grid, resolve grid, the looping fallback pass): 200 with LFG_FUZZ_LANES=3,
 120 without, no differences; round 5 (the variant of the persistent kernel for moderate noise forced, LFG_TIER_FORCE=1, noise amplitudes
-up to 12 levels, LFG_FUZZ_MAX_AMP=12; the visiting order dealt out by LDS bank): see NOTES_r05.md section 6."""
+up to 12 levels, LFG_FUZZ_MAX_AMP=12; the visiting order dealt out by LDS bank): 384 cases, see NOTES_r05.md section 6; round 5's final library
+(tools/gpu_r5_fuzz_final.sh): 300 cases one frame at a time, 200 with LFG_FUZZ_LANES=3, 160 more with LFG_LEAN_FORCE=1 and 160 with
+LFG_MOTION_STRIP=1 (the strip kernel), no differences."""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
