@@ -239,3 +239,37 @@ def test_the_cu_mask_of_a_communicator_and_its_return():
         assert ctx.comm_reserved_cus() == 0 and ctx.comm_cu_mask() == full
         ctx.scale(f, up)
         assert (ctx.download(up) == first).all()
+
+
+def test_sixteen_cus_for_the_communicator(monkeypatch):
+    """LFG_COMM_CUS=16: two CUs in each XCD, a probe of sixteen workgroups of RCCL's footprint runs at once while the lanes hold the chip."""
+    from linux_fg_amd import capi
+    monkeypatch.setenv("LFG_COMM_CUS", "16")
+    w, h = 1920, 1080
+    prev = synth.make_prev(w, h, seed=911)
+    pair = (prev, synth.noise_bytes(w, h, 912))
+    with capi.Context(0) as ctx:
+        ctx.lanes(2)
+        ctx.comm_init(1, 0, capi.Context.comm_unique_id())
+        assert ctx.comm_reserved_cus() == 16 and ctx.comm_cu_mask()[0] == 0xFFFF0000
+        ups = []
+        for x in pair:
+            f, up = ctx.frame_from(x), ctx.create_frame(2 * w, 2 * h)
+            ctx.scale(f, up); ctx.sync(); ctx.destroy_frame(f); ups.append(up)
+        mvs = [ctx.create_frame(2 * w, 2 * h, capi.FORMAT_MV_S8X2) for _ in range(2)]
+        for j in range(2):
+            ctx.lane_select(j)
+            ctx.motion(ups[0], ups[1], mvs[j], 8, 16.0)
+        ctx.sync()
+        assert ctx.motion_plan()[1] == 480                    # two persistent workgroups on each of the other 240 CUs
+        ctx.lane_select(0)
+        ctx.motion(ups[0], ups[1], mvs[0], 8, 16.0)
+        ctx.comm_probe(16, 50)
+        ctx.lane_select(1)
+        ctx.motion(ups[0], ups[1], mvs[1], 8, 16.0)               # 7 ms of a full persistent grid behind lane 0's
+        assert ctx.comm_probe_ms() < 0.15
+        ctx.lane_select(0)
+        ctx.sync()
+        for f in ups + mvs:
+            ctx.destroy_frame(f)
+        ctx.lanes(1)
